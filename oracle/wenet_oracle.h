@@ -1,0 +1,84 @@
+/*
+ * wenet_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement (plain C, scalar, single thread) of the reference's
+ * `fsk_demod | drs232_ldpc` / `wenet_ldpc` hot path.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
+ * The shipped product (wenet_amd/, include/) never links, imports or calls it.
+ *
+ * Parity status: PINNED.  tests/test_oracle_vs_ref.py checks every function
+ * here bit-for-bit against the reference itself (oracle/_ref, built from the
+ * unmodified sources by oracle/Makefile) and against the reference's embedded
+ * known-answer vector (src/H2064_516_sparse.h:27-33); tests/golden/ holds
+ * fixtures generated from the reference by tests/golden/make_golden.py.
+ */
+#ifndef WENET_ORACLE_H
+#define WENET_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { float real, imag; } ora_comp;
+
+/* sample formats of the fsk_demod CLI (src/fsk_demod.c:273-296) + raw COMP */
+enum { ORA_FMT_S16_REAL = 0, ORA_FMT_CS16 = 1, ORA_FMT_CU8 = 2, ORA_FMT_CF32 = 3 };
+
+typedef struct ora_fsk ora_fsk;
+
+/* src/fsk.c:128-259 (fsk_create_hbr); tx_f1=1200, tx_fs=400 as src/fsk_demod.c:214 */
+ora_fsk *ora_fsk_create_hbr(int Fs, int Rs, int P, int M);
+void     ora_fsk_destroy(ora_fsk *f);
+void     ora_fsk_set_est_limits(ora_fsk *f, int est_min, int est_max);   /* fsk.c:522-528 */
+int      ora_fsk_nin(const ora_fsk *f);                                  /* fsk.c:485-487 */
+/* one modem frame: exactly ora_fsk_nin() input samples (fsk.c:679-1108).
+   rx_bits / rx_sd may each be NULL, as fsk_demod / fsk_demod_sd (fsk.c:1110-1116). */
+void     ora_fsk_demod_frame(ora_fsk *f, uint8_t *rx_bits, float *rx_sd, const ora_comp *in);
+
+/* geometry + carried state, for traces */
+int   ora_fsk_geom(const ora_fsk *f, int what);   /* 0 Ndft 1 N 2 Ts 3 Nmem 4 P 5 Nsym 6 Nbits 7 nstash 8 M 9 est_min 10 est_max 11 est_space */
+void  ora_fsk_get_f_est(const ora_fsk *f, float out[4]);
+void  ora_fsk_get_phi_c(const ora_fsk *f, float out[8]);
+void  ora_fsk_get_fft_est(const ora_fsk *f, float *out);
+void  ora_fsk_get_hann(const ora_fsk *f, float *out);
+void  ora_fsk_get_samp_old(const ora_fsk *f, float *out);
+float ora_fsk_get_scalar(const ora_fsk *f, int what); /* 0 norm_rx_timing 1 ppm 2 EbNodB 3 snr_est 4 stats.rx_timing 5 foff */
+int   ora_fsk_get_eye(const ora_fsk *f, float *out /*8*160*/, int *neyetr, int *neyesamp);
+
+/* src/fsk_demod.c:273-296: convert n samples of a raw format to COMP */
+void  ora_convert_samples(int fmt, const void *raw, long n, ora_comp *out);
+
+/* whole-capture driver = the fsk_demod main loop (src/fsk_demod.c:270-413):
+   reads nin samples per frame until a short read; returns number of frames.
+   sd_out gets Nbits floats per frame (soft mode), bits_out Nbits bytes per frame
+   (hard mode); either may be NULL.  trace (optional) gets 8 floats per frame:
+   f_est[0..3], nin(after the frame), norm_rx_timing, ppm, EbNodB. */
+long  ora_demod_capture(int fmt, const void *raw, long nsamples,
+                        int Fs, int Rs, int P, int M, int est_lo, int est_hi,
+                        float *sd_out, uint8_t *bits_out, long cap_frames,
+                        float *trace);
+
+/* ---- LDPC ------------------------------------------------------------- */
+float ora_phi0(float xf);                                        /* src/phi0.c:13-218 */
+void  ora_sd_to_llr(float *llr, const double *sd, int n);        /* mpdecode_core.c:569-595 */
+/* run_ldpc_decoder (mpdecode_core.c:494-566) for the fixed Wenet code; returns iterations.
+   *pcc is only written when SumProduct would write it (mpdecode_core.c:479). */
+int   ora_ldpc_decode(const float *llr, int max_iter, uint8_t *bits /*2580*/, int *pcc);
+void  ora_ldpc_encode(const uint8_t *ibits /*2064*/, uint8_t *pbits /*516*/); /* mpdecode_core.c:72-91 == tx/ldpc_enc.c:33-48 */
+uint16_t ora_crc16(const uint8_t *data, int len);                /* drs232_ldpc.c:91-102 */
+
+/* ---- deframer + decode = main() of drs232_ldpc.c (mode 1) / wenet_ldpc.c (mode 2) ----
+   Processes nsym soft symbols; every completed packet i (valid CRC or not) reports
+   pkt_start[i] (index of its first collected symbol), pkt_iter[i], pkt_crc_ok[i] and its
+   258 packed bytes in pkt_bytes[i*258..]; llr_dump (optional) gets 2580 floats per packet.
+   Returns the number of completed packets (<= cap).  CRC-valid packets, in order, are what
+   the reference writes to its output (first 256 bytes each). */
+long  ora_deframe_decode(int mode, const float *sd, long nsym, int max_iter, long cap,
+                         long *pkt_start, int *pkt_iter, uint8_t *pkt_crc_ok,
+                         uint8_t *pkt_bytes, float *llr_dump);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

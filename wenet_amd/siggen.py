@@ -1,0 +1,213 @@
+"""Synthetic Wenet test-signal generator (own code).
+
+Builds what a Wenet transmitter puts on air, so that the receive path can be
+exercised without the reference's external captures:
+
+* frame format          tx/PacketTX.py:65-66,123-137 -- 16 x 0x55 preamble, unique word
+                        0xABCDEF01, 256-byte payload, CRC-16/CCITT-FALSE packed little-endian,
+                        65 bytes of LDPC parity (516 bits + 4 zero pad bits)
+* LDPC parity           tx/ldpc_enc.c:33-48 (repeat-accumulate: running XOR of row parities)
+* v1 ("RS232") bits     tx/radio_wrappers.py:553-560 -- start 0, 8 data bits LSB first, stop 1
+* v2 ("I2S") bits       tx/radio_wrappers.py:385-417 -- payload+crc+parity XORed with the
+                        125-byte scramble code (not the preamble/UW), MSB first
+* tone placement        start_rx.sh:103-108 -- centre Rs*(Os/4 - 0.25); deviation +-71797 Hz for
+                        v1 (tx/radio_wrappers.py:99-102), +-Rs/2 for v2 (:104); bit 1 = upper tone
+* noise                 benchmarking/generate_lowsnr.py:70-89 -- sigma^2 = var(x)*Fs/(Rs*EbN0*bps),
+                        complex Gaussian, then divide by max|x|
+* cu8 conversion        csdr convert_f_u8 restated as (uint8)(x*127.5 + 128) (SURVEY.md 8c;
+                        parity unpinned for that external tool -- goldens start from cu8 bytes)
+
+Everything is deterministic given the seed (numpy.random.default_rng).
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+UNIQUE_WORD = bytes([0xAB, 0xCD, 0xEF, 0x01])
+PREAMBLE = b"\x55" * 16
+PAYLOAD_BYTES = 256
+N_DATA_BITS = 2064
+N_PARITY_BITS = 516
+ROW_WEIGHT = 12
+
+
+def _load_inc(name):
+    txt = open(os.path.join(_HERE, "csrc", "tables", name)).read()
+    txt = txt[txt.index("*/") + 2:]
+    return np.array([int(t) for t in txt.replace("\n", " ").split(",") if t.strip()])
+
+
+_H_ROWS = None
+_SCRAMBLE = None
+
+
+def h_rows() -> np.ndarray:
+    """516 x 12 table of 0-based data-bit indices per parity check."""
+    global _H_ROWS
+    if _H_ROWS is None:
+        _H_ROWS = _load_inc("ldpc_h2064_516_rows.inc").reshape(N_PARITY_BITS, ROW_WEIGHT)
+    return _H_ROWS
+
+
+def scramble_bytes() -> np.ndarray:
+    global _SCRAMBLE
+    if _SCRAMBLE is None:
+        _SCRAMBLE = _load_inc("scramble_v2_bits.inc").astype(np.uint8)
+    return _SCRAMBLE
+
+
+def crc16_ccitt_false(data: bytes) -> int:
+    crc = 0xFFFF
+    for b in data:
+        crc ^= b << 8
+        for _ in range(8):
+            crc = ((crc << 1) ^ 0x1021) & 0xFFFF if crc & 0x8000 else (crc << 1) & 0xFFFF
+    return crc
+
+
+def ldpc_parity_bits(ibits: np.ndarray) -> np.ndarray:
+    """RA encoder: p[k] = (sum of the 12 data bits of row k + p[k-1]) mod 2."""
+    row_par = ibits[h_rows()].sum(axis=1) & 1
+    return (np.cumsum(row_par) & 1).astype(np.uint8)
+
+
+def frame_packet(payload: bytes, mode: int) -> bytes:
+    """mode 1 = v1/RS232 (no scrambling), mode 2 = v2/I2S (scrambled)."""
+    assert len(payload) == PAYLOAD_BYTES
+    crc = crc16_ccitt_false(payload)
+    body = payload + bytes([crc & 0xFF, crc >> 8])
+    ibits = np.unpackbits(np.frombuffer(body, dtype=np.uint8))
+    parity = np.packbits(ldpc_parity_bits(ibits)).tobytes()        # 516 bits -> 65 bytes (4 pad zeros)
+    coded = np.frombuffer(body + parity, dtype=np.uint8)
+    if mode == 2:
+        code = scramble_bytes()
+        coded = coded ^ code[np.arange(coded.size) % code.size]
+    return PREAMBLE + UNIQUE_WORD + coded.tobytes()
+
+
+def bytes_to_air_bits(data: bytes, mode: int) -> np.ndarray:
+    b = np.unpackbits(np.frombuffer(data, dtype=np.uint8)).reshape(-1, 8)
+    if mode == 1:
+        out = np.empty((b.shape[0], 10), dtype=np.uint8)
+        out[:, 0] = 0
+        out[:, 1:9] = b[:, ::-1]
+        out[:, 9] = 1
+        return out.reshape(-1)
+    return b.reshape(-1)
+
+
+@dataclass
+class ModemConfig:
+    name: str
+    mode: int          # framing: 1 = drs232_ldpc, 2 = wenet_ldpc
+    M: int             # 2 or 4 FSK
+    Fs: int
+    Rs: int
+    f_low: float       # frequency of tone 0
+    f_space: float     # tone spacing
+
+    @property
+    def Ts(self):
+        return self.Fs // self.Rs
+
+    @property
+    def symbols_per_frame(self):
+        bits = (16 + 4 + 256 + 2 + 65) * (10 if self.mode == 1 else 8)
+        return bits if self.M == 2 else bits // 2
+
+
+def config_v1():
+    Rs, Os = 115177, 8
+    fc = Rs * (Os / 4 - 0.25)
+    return ModemConfig("v1", 1, 2, Rs * Os, Rs, fc - 71797, 2 * 71797)
+
+
+def config_v2():
+    Rs, Os = 96000, 10
+    fc = Rs * (Os / 4 - 0.25)
+    return ModemConfig("v2", 2, 2, Rs * Os, Rs, fc - Rs / 2, Rs)
+
+
+def config_4fsk():
+    # BASELINE config 4 made legal: Rs 57600 sym/s, Fs 1 843 200 (Ts 32), v1 framing
+    Rs, Fs = 57600, 1843200
+    return ModemConfig("4fsk", 1, 4, Fs, Rs, 200000.0, float(Rs))
+
+
+CONFIGS = {"v1": config_v1, "v2": config_v2, "4fsk": config_4fsk}
+
+
+def modulate(bits: np.ndarray, cfg: ModemConfig, ppm: float = 0.0) -> np.ndarray:
+    """Continuous-phase M-FSK, unit amplitude complex baseband, Ts samples per symbol.
+    ppm != 0 emulates a transmitter symbol-clock error by resampling the symbol index."""
+    if cfg.M == 2:
+        sym = bits.astype(np.int64)
+    else:
+        b = bits.reshape(-1, 2).astype(np.int64)
+        sym = (b[:, 0] << 1) | b[:, 1]
+    n = sym.size * cfg.Ts
+    if ppm == 0.0:
+        idx = np.repeat(np.arange(sym.size), cfg.Ts)
+    else:
+        t = np.arange(n, dtype=np.float64) * (1.0 + ppm * 1e-6) / cfg.Ts
+        idx = np.minimum(t.astype(np.int64), sym.size - 1)
+    f = cfg.f_low + cfg.f_space * sym[idx]
+    ph = 2.0 * np.pi * np.cumsum(f) / cfg.Fs
+    return np.exp(1j * ph)
+
+
+def add_noise(x: np.ndarray, cfg: ModemConfig, ebno_db: float, rng) -> np.ndarray:
+    bps = 1.0 if cfg.M == 2 else 2.0
+    ebno = 10.0 ** (ebno_db / 10.0)
+    nv = np.var(x) * cfg.Fs / (cfg.Rs * ebno * bps)
+    s = np.sqrt(nv / 2.0)
+    noisy = x + s * rng.standard_normal(x.size) + 1j * s * rng.standard_normal(x.size)
+    return noisy / np.max(np.abs(noisy))
+
+
+def to_cu8(x: np.ndarray) -> np.ndarray:
+    out = np.empty(2 * x.size, dtype=np.float64)
+    out[0::2] = x.real
+    out[1::2] = x.imag
+    return (out * 127.5 + 128.0).astype(np.uint8)          # C cast: truncation toward zero
+
+
+def to_cs16(x: np.ndarray, scale: float = 16000.0) -> np.ndarray:
+    out = np.empty(2 * x.size, dtype=np.float64)
+    out[0::2] = x.real
+    out[1::2] = x.imag
+    return np.round(out * scale).astype(np.int16)
+
+
+def make_capture(cfg: ModemConfig, n_packets: int, ebno_db: float, seed: int,
+                 fmt: str = "cu8", ppm: float = 0.0, lead_symbols: int = 0,
+                 payloads=None):
+    """Returns (raw_sample_array, list_of_payload_bytes).  Frames are back to back."""
+    rng = np.random.default_rng(seed)
+    if payloads is None:
+        payloads = [rng.integers(0, 256, PAYLOAD_BYTES, dtype=np.uint8).tobytes() for _ in range(n_packets)]
+    air = [bytes_to_air_bits(frame_packet(p, cfg.mode), cfg.mode) for p in payloads]
+    bits = np.concatenate(air)
+    if lead_symbols:
+        k = lead_symbols * (1 if cfg.M == 2 else 2)
+        bits = np.concatenate([rng.integers(0, 2, k, dtype=np.uint8), bits])
+    if cfg.M == 4 and bits.size % 2:
+        bits = np.concatenate([bits, np.zeros(1, np.uint8)])
+    x = modulate(bits, cfg, ppm)
+    x = add_noise(x, cfg, ebno_db, rng)
+    if fmt == "cu8":
+        raw = to_cu8(x)
+    elif fmt == "cs16":
+        raw = to_cs16(x)
+    elif fmt == "s16":
+        raw = np.round(x.real * 16000.0).astype(np.int16)
+    elif fmt == "cf32":
+        raw = x.astype(np.complex64)
+    else:
+        raise ValueError(fmt)
+    return raw, payloads
