@@ -1,0 +1,179 @@
+/*
+ * wenet_rx.h -- C ABI of libwenet_rx.so: the MI355X (gfx950) implementation of Wenet's
+ * receive hot path  fsk_demod | drs232_ldpc  /  wenet_ldpc.
+ *
+ * The reference has no FFI for this path; its boundary is two command lines plus the C
+ * functions those mains call.  This header mirrors exactly that surface (same names with a
+ * wenet_ prefix, same argument meaning, same error behaviour) and adds the batch entry points a
+ * GPU needs.  Every declaration cites the reference interface it replaces (file:line relative to
+ * the reference tree).  Plain pointers and sizes only; no C++ or torch types.
+ *
+ * Unless a function says "device", pointers are HOST pointers and the library moves the data.
+ * All functions are synchronous with respect to the caller unless they take a stream.
+ * Handles are independent and not re-entrant (as the reference's structs).
+ * A GPU is mandatory: create functions return NULL (and log to stderr) if no gfx950 device or
+ * the kernels cannot be launched -- there is no CPU fallback.
+ */
+#ifndef WENET_RX_H
+#define WENET_RX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* src/comp.h:33-36 */
+typedef struct { float real, imag; } wenet_comp;
+
+/* sample formats of the fsk_demod command line (src/fsk_demod.c:112-119,273-296) + raw COMP */
+enum {
+    WENET_FMT_S16_REAL = 0,   /* neither -c nor -d */
+    WENET_FMT_CS16 = 1,       /* -c / --cs16 */
+    WENET_FMT_CU8 = 2,        /* -d / --cu8  */
+    WENET_FMT_CF32 = 3        /* COMP[] as passed to fsk_demod()/fsk_demod_sd() */
+};
+
+/* framing modes = which L2 binary: src/drs232_ldpc.c (1) or src/wenet_ldpc.c (2) */
+enum { WENET_FRAMING_DRS232 = 1, WENET_FRAMING_WENET_V2 = 2 };
+
+/* ------------------------------------------------------------------------------------------
+ * L1  FSK demodulator                                                  src/fsk.h:100-202
+ * ------------------------------------------------------------------------------------------ */
+typedef struct wenet_fsk wenet_fsk;
+
+/* fsk_create_hbr (src/fsk.h:113, src/fsk.c:128-259).  Illegal parameters (the reference's
+ * asserts at fsk.c:137-146) return NULL instead of aborting. */
+wenet_fsk *wenet_fsk_create_hbr(int Fs, int Rs, int P, int M, int tx_f1, int tx_fs);
+/* fsk_destroy (src/fsk.h:131) */
+void wenet_fsk_destroy(wenet_fsk *fsk);
+/* fsk_set_est_limits (src/fsk.h:126, src/fsk.c:522-528) */
+void wenet_fsk_set_est_limits(wenet_fsk *fsk, int fmin, int fmax);
+/* fsk_nin (src/fsk.h:159, src/fsk.c:485-487) */
+uint32_t wenet_fsk_nin(wenet_fsk *fsk);
+/* fsk_demod (src/fsk.h:175): one modem frame of exactly wenet_fsk_nin() samples -> Nbits hard bits */
+void wenet_fsk_demod(wenet_fsk *fsk, uint8_t rx_bits[], const wenet_comp fsk_in[]);
+/* fsk_demod_sd (src/fsk.h:186): -> Nbits float32 soft decisions */
+void wenet_fsk_demod_sd(wenet_fsk *fsk, float rx_sd[], const wenet_comp fsk_in[]);
+
+/* struct FSK fields the callers read (src/fsk.h:43-90): 0 Ndft 1 N 2 Ts 3 Nmem 4 P 5 Nsym 6 Nbits
+ * 7 nstash 8 mode(M) 9 est_min 10 est_max 11 est_space 12 Fs 13 Rs */
+int wenet_fsk_info(wenet_fsk *fsk, int what);
+
+/* The fsk_demod main loop (src/fsk_demod.c:270-413) for a block of raw samples: demodulates as
+ * many whole frames as `nsamples` holds (each frame consumes fsk_nin() samples), carrying state to
+ * the next call.  out receives Nbits float32 (soft != 0) or Nbits uint8 per frame.
+ * *consumed = samples used; the caller re-presents the rest.  Returns frames produced, <0 on error.
+ * trace (optional, may be NULL): 10 floats per frame = f_est[0..3], nin(next), norm_rx_timing,
+ * ppm, meanebno, stdebno, rx_timing (the reference's modem_probe points, src/fsk.c:726,909-910). */
+long wenet_fsk_demod_stream(wenet_fsk *fsk, int fmt, const void *raw, long nsamples, int soft,
+                            void *out, long cap_frames, long *consumed, float *trace);
+
+/* modem statistics of the last demodulated frame = fsk_get_demod_stats (src/fsk.h:202,
+ * src/fsk.c:496-517) reduced to what src/fsk_demod.c:351-392 prints. */
+typedef struct {
+    float snr_est;              /* "EbNodB" */
+    float ppm;                  /* fsk->ppm */
+    float f_est[4];             /* f1_est.. */
+    float rx_timing, foff;
+    int   neyetr, neyesamp;
+    float rx_eye[8][160];       /* MODEM_STATS_ET_MAX x MODEM_STATS_EYE_IND_MAX (src/modem_stats.h:40-41) */
+    int   nfft_est;             /* Ndft/2 */
+    float fft_est[2048];        /* "samp_fft" */
+} wenet_modem_stats;
+/* Enable statistics: a snapshot is kept for every `period`-th frame starting at frame `first`
+ * (src/fsk_demod.c:345-401 prints when stats_ctr<0 => first=1, period=stats_loop+1). */
+void wenet_fsk_enable_stats(wenet_fsk *fsk, long first, long period);
+/* Stats snapshots produced by the last wenet_fsk_demod_stream call; returns how many were copied. */
+int wenet_fsk_get_stats(wenet_fsk *fsk, wenet_modem_stats *out, int cap);
+
+/* ------------------------------------------------------------------------------------------
+ * L2  LDPC core                                                   src/mpdecode_core.h:18-39
+ * ------------------------------------------------------------------------------------------ */
+/* struct LDPC (src/mpdecode_core.h:18-33).  Only the Wenet code (CodeLength 2580, 516 parity bits,
+ * src/H2064_516_sparse.h:9-15) is supported: H_rows/H_cols may be NULL (built-in tables are used);
+ * other geometries make wenet_run_ldpc_decoder return -1. */
+struct wenet_ldpc {
+    int max_iter;
+    int dec_type;
+    int q_scale_factor;
+    int r_scale_factor;
+    int CodeLength;
+    int NumberParityBits;
+    int NumberRowsHcols;
+    int max_row_weight;
+    int max_col_weight;
+    int data_bits_per_frame;
+    int coded_bits_per_frame;
+    int coded_syms_per_frame;
+    uint16_t *H_rows;
+    uint16_t *H_cols;
+};
+/* run_ldpc_decoder (src/mpdecode_core.h:37, src/mpdecode_core.c:494-566): returns iterations;
+ * *parityCheckCount is written only where SumProduct writes it (mpdecode_core.c:479). */
+int wenet_run_ldpc_decoder(struct wenet_ldpc *ldpc, uint8_t out_char[], float input[], int *parityCheckCount);
+/* sd_to_llr (src/mpdecode_core.h:39, src/mpdecode_core.c:569-595); n <= 2880 */
+void wenet_sd_to_llr(float llr[], double sd[], int n);
+/* batched forms (own design): npk packets of 2580 LLRs -> bits[npk][2580], iters[npk], pcc[npk]
+ * (pcc[i] left untouched where the reference would not write it).  Returns 0, <0 on error. */
+int wenet_ldpc_decode_batch(const float *llr, int npk, int max_iter, uint8_t *bits, int *iters, int *pcc);
+
+/* ------------------------------------------------------------------------------------------
+ * L2  deframer + decoder = main() of src/drs232_ldpc.c:105-285 / src/wenet_ldpc.c
+ * ------------------------------------------------------------------------------------------ */
+typedef struct wenet_deframer wenet_deframer;
+wenet_deframer *wenet_deframer_create(int framing_mode, int max_iter);
+void wenet_deframer_destroy(wenet_deframer *d);
+/* Feed soft symbols (the float32 stream fsk_demod -s writes).  Every packet COMPLETED inside the
+ * data seen so far is decoded; for each, in stream order, pkt_info[i] = {iter, crc_ok} and the
+ * 258 decoded bytes go to pkt_bytes (all packets, valid or not).  The reference writes to its
+ * output exactly the first 256 bytes of the crc_ok packets, in this order.
+ * Returns the number of packets reported (<= cap), <0 on error. */
+typedef struct { int iter; int crc_ok; long long start_symbol; } wenet_packet_info;
+long wenet_deframer_push(wenet_deframer *d, const float *symbols, long nsym,
+                         uint8_t *pkt_bytes /* cap*258 */, wenet_packet_info *pkt_info, long cap);
+
+/* ------------------------------------------------------------------------------------------
+ * Batch receive chain (own design): many independent captures -> packets, one GPU
+ * ------------------------------------------------------------------------------------------ */
+typedef struct wenet_rx wenet_rx;
+/* est_lo/est_hi: fsk_demod's -b/-u (src/fsk_demod.c:215-218), 0/0 = defaults */
+wenet_rx *wenet_rx_create(int Fs, int Rs, int P, int M, int framing_mode, int max_iter,
+                          int est_lo, int est_hi);
+void wenet_rx_destroy(wenet_rx *rx);
+/* Process nchan captures that start from reset modem state (= one run of the reference pipe per
+ * capture).  raw[c] points to nsamples[c] samples of format fmt.  device != 0: raw[c] are DEVICE
+ * pointers (HBM-resident input, nothing is copied).  stream: hipStream_t or NULL.
+ * Blocks until the results are on the host.  Returns 0, <0 on error. */
+int wenet_rx_process(wenet_rx *rx, int nchan, const void *const *raw, const long long *nsamples,
+                     int fmt, int device, void *stream);
+/* Same, but returns after enqueueing the kernels on `stream` (device pointers only); results are
+ * fetched by wenet_rx_collect (which synchronises). */
+int wenet_rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const long long *nsamples,
+                     int fmt, void *stream);
+int wenet_rx_collect(wenet_rx *rx);
+/* results of the last process/collect */
+long long wenet_rx_frames(wenet_rx *rx, int ch);            /* modem frames demodulated */
+long long wenet_rx_packets(wenet_rx *rx, int ch);           /* packets completed (valid or not) */
+/* copies up to cap packets of channel ch: 258 bytes each + info; returns count */
+long long wenet_rx_get_packets(wenet_rx *rx, int ch, uint8_t *pkt_bytes, wenet_packet_info *info, long long cap);
+/* soft-decision stream of channel ch (Nbits per frame); returns floats copied */
+long long wenet_rx_get_soft(wenet_rx *rx, int ch, float *sd, long long cap);
+/* per-frame trace of channel ch (10 floats per frame, see wenet_fsk_demod_stream); enable before process */
+void wenet_rx_enable_trace(wenet_rx *rx, int on);
+long long wenet_rx_get_trace(wenet_rx *rx, int ch, float *trace, long long cap_frames);
+/* per-packet LLRs (2580 floats per packet); enable before process */
+void wenet_rx_enable_llr_dump(wenet_rx *rx, int on);
+long long wenet_rx_get_llrs(wenet_rx *rx, int ch, float *llr, long long cap_packets);
+/* timing of the last enqueue in milliseconds (HIP events on the launch stream):
+ * what: 0 demod kernel, 1 deframe kernel, 2 decode kernel, 3 total */
+float wenet_rx_last_ms(wenet_rx *rx, int what);
+
+/* library / device info: 0 = device count, 1 = multiprocessor count of device 0 */
+int wenet_rx_device_info(int what);
+const char *wenet_rx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

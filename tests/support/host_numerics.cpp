@@ -1,0 +1,79 @@
+// TEST SUPPORT: compiles the product's host/device numeric headers for the x86-64 host and
+// compares them with the host's own libm / x87 long double.  Built by tests/test_host_numerics.py
+// with g++ -O2 -ffp-contract=off.
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include "../../wenet_amd/csrc/glibc_atan2f.h"
+#include "../../wenet_amd/csrc/x87emu.h"
+
+static inline uint64_t splitmix(uint64_t &s) {
+    uint64_t z = (s += 0x9e3779b97f4a7c15ULL);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    return z ^ (z >> 31);
+}
+static inline bool same_f(float a, float b) {
+    if (std::isnan(a) && std::isnan(b)) return true;
+    uint32_t x, y; memcpy(&x, &a, 4); memcpy(&y, &b, 4); return x == y;
+}
+
+extern "C" {
+// every float bit pattern with a stride, vs atanf
+long check_atanf(long stride, long *first_bad) {
+    long bad = 0;
+    for (uint64_t u = 0; u < (1ULL << 32); u += (uint64_t)stride) {
+        float x = wg_u2f((uint32_t)u);
+        if (!same_f(wg_atanf(x), atanf(x))) { if (!bad) *first_bad = (long)u; bad++; }
+    }
+    return bad;
+}
+// random (y,x) pairs incl. full exponent range + timing-estimator-like magnitudes
+long check_atan2f(long n, uint64_t seed, uint32_t *first_bad) {
+    long bad = 0; uint64_t s = seed;
+    for (long i = 0; i < n; i++) {
+        uint64_t r = splitmix(s);
+        float y, x;
+        if (i & 1) { y = wg_u2f((uint32_t)r); x = wg_u2f((uint32_t)(r >> 32)); }
+        else {      // moderate magnitudes, like the spectral-line sum
+            uint64_t r2 = splitmix(s);
+            y = (float)((double)(int64_t)r * (1.0 / 9.2e18) * 1e3);
+            x = (float)((double)(int64_t)r2 * (1.0 / 9.2e18) * 1e3);
+        }
+        if (!same_f(wg_atan2f(y, x), atan2f(y, x))) { if (!bad) { first_bad[0] = wg_f2u(y); first_bad[1] = wg_f2u(x); } bad++; }
+    }
+    // specials
+    const float sp[] = {0.0f, -0.0f, 1.0f, -1.0f, INFINITY, -INFINITY, NAN, 1e-40f, -1e-40f, 3e38f, -3e38f, 0.5f, 2.0f};
+    for (float y : sp) for (float x : sp)
+        if (!same_f(wg_atan2f(y, x), atan2f(y, x))) { if (!bad) { first_bad[0] = wg_f2u(y); first_bad[1] = wg_f2u(x); } bad++; }
+    return bad;
+}
+// estEsN0 = 1.0/(2.0L*v + 1E-3) and llr = 4.0L*e*sd vs native long double
+long check_x87(long n, uint64_t seed, double *first_bad) {
+    long bad = 0; uint64_t s = seed;
+    for (long i = 0; i < n; i++) {
+        uint64_t r = splitmix(s), r2 = splitmix(s), r3 = splitmix(s);
+        double v, sd;
+        switch (i % 5) {
+        case 0: v = wx_u2d(r); break;                                            // any bit pattern
+        case 1: v = (double)(r >> 11) * (1.0 / 9007199254740992.0); break;         // [0,1)
+        case 2: v = (double)(r >> 11) * (1.0 / 9007199254740992.0) * 1e-3; break;  // near the 1E-3 term
+        case 3: v = -5e-4 + ((double)(int64_t)r2) * 1e-35; break;                  // cancellation with 1E-3
+        default: v = ldexp((double)(r >> 11), (int)(r2 % 200) - 150); break;
+        }
+        if (!wx_finite(v)) continue;
+        volatile double ref_e = 1.0 / (2.0L * v + 1E-3);
+        double e = wx_est_esn0(v);
+        if (memcmp((const void *)&ref_e, &e, 8) != 0 && !(std::isnan(ref_e) && std::isnan(e))) { if (!bad) { first_bad[0] = v; first_bad[1] = 0; } bad++; continue; }
+        if (i % 3 == 0) sd = (double)wg_u2f((uint32_t)r3);                           // float-valued sd (the CLI path)
+        else if (i % 3 == 1) sd = wx_u2d(r3);                                      // any double
+        else sd = ((double)(int64_t)r3) * (1.0 / 9.2e18);
+        if (!wx_finite(sd) || !wx_finite(e)) continue;
+        volatile float ref_l = 4.0L * e * sd;
+        float l = wx_llr(e, sd);
+        if (!same_f(ref_l, l)) { if (!bad) { first_bad[0] = e; first_bad[1] = sd; } bad++; }
+    }
+    return bad;
+}
+}

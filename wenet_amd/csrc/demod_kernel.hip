@@ -1,0 +1,445 @@
+// demod_kernel.hip -- non-coherent M-FSK demodulator for gfx950 (MI355X).
+//
+// One 64-lane wavefront per channel walks that channel's modem frames in order, with all
+// state that the reference carries in struct FSK (src/fsk.h:43-90) resident in LDS/registers
+// for the whole launch.  Inside a frame every step that the reference's arithmetic leaves
+// order-free is spread over the 64 lanes; the three float recurrences whose rounding depends on
+// evaluation order (NCO phasor chain fsk.c:791-824, integrator slot sums :833-840, spectral-line
+// sum :862-874) are evaluated in exactly the reference order, so soft decisions are bit-identical
+// to the CPU pipeline.
+//
+// Reference map (file:line in /root/reference/src):
+//   sample conversion            fsk_demod.c:273-296
+//   tone estimator               fsk.c:540-677   (window :583-603, FFT kiss_fft.c, IIR :625-628, peaks :633-672)
+//   NCO set-up / down-conversion fsk.c:756-842
+//   state save                   fsk.c:845-851
+//   fine timing, nin             fsk.c:858-907
+//   resample / decide / soft out fsk.c:913-993, Eb/N0 accumulators :995-1007
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "glibc_atan2f.h"
+#include "wenet_internal.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {   // comp_prim.h:57-65
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// one sample of the channel's raw input -> COMP (fsk_demod.c:273-296)
+__device__ __forceinline__ float2 load_sample(const void *raw, int fmt, long long idx) {
+    if (fmt == WR_FMT_CU8) {
+        const uchar2 v = ((const uchar2 *)raw)[idx];
+        // ((float)u8 - 127.0)/128.0 is exact in float
+        return make_float2(((float)v.x - 127.0f) / 128.0f, ((float)v.y - 127.0f) / 128.0f);
+    } else if (fmt == WR_FMT_CS16) {
+        const short2 v = ((const short2 *)raw)[idx];
+        return make_float2((float)v.x / 1000.0f, (float)v.y / 1000.0f);   // FDMDV_SCALE
+    } else if (fmt == WR_FMT_S16_REAL) {
+        const short v = ((const short *)raw)[idx];
+        return make_float2((float)v / 1000.0f, 0.0f);
+    } else {
+        return ((const float2 *)raw)[idx];
+    }
+}
+
+struct BestBin { float v; int i; };
+
+__device__ __forceinline__ BestBin better(BestBin a, BestBin b) {
+    // first maximum wins: strictly greater value, or equal value at a lower bin
+    if (b.v > a.v || (b.v == a.v && b.i < a.i)) return b;
+    return a;
+}
+
+}  // namespace
+
+template <int M>
+__global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const WrChan *chans, int nchan) {
+    const int ch = blockIdx.x;
+    if (ch >= nchan) return;
+    const int lane = threadIdx.x;
+    const WrChan C = chans[ch];
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float2 *X  = (float2 *)(smem + cfg.off_X);    // [nstash + N + Ts/2]  old tail | new block
+    float2 *FB = (float2 *)(smem + cfg.off_FB);   // [Ndft]               FFT work buffer
+    float2 *PH = (float2 *)(smem + cfg.off_PH);   // [M][Lpad]            NCO phasors -> down-converted samples -> timing products
+    float2 *FI = (float2 *)(smem + cfg.off_FI);   // [M][NI]              integrator outputs
+    float  *FE = (float *)(smem + cfg.off_FE);    // [Ndft/2]             IIR-smoothed spectrum (fsk->fft_est)
+    float  *FW = (float *)(smem + cfg.off_FW);    // [Ndft/2]             peak-search working copy
+    float  *SDL = (float *)(smem + cfg.off_SD);   // [Nbits]              last soft decisions (kept across a NaN frame)
+    float  *SC = (float *)(smem + cfg.off_SC);    // [4*Nsym + 16]        scratch
+
+    const int Ts = cfg.Ts, N = cfg.N, P = cfg.P, Nmem = cfg.Nmem, nstash = cfg.nstash;
+    const int Ndft = cfg.Ndft, NH = cfg.Ndft / 2, L = cfg.L, NI = cfg.NI, q = cfg.q, Lpad = cfg.Lpad;
+    const int Nbits = cfg.Nbits;
+
+    // ---- load carried state ---------------------------------------------------------------
+    WrChanHdr *hdr = (WrChanHdr *)C.state;
+    float *st_fft = C.state + cfg.st_fft_est;
+    float2 *st_old = (float2 *)(C.state + cfg.st_samp_old);
+    float *st_sd = C.state + cfg.st_sd_last;
+    for (int i = lane; i < NH; i += 64) FE[i] = st_fft[i];
+    for (int i = lane; i < nstash; i += 64) X[i] = st_old[i];
+    for (int i = lane; i < Nbits; i += 64) SDL[i] = st_sd[i];
+    float2 phi_c = (lane < M) ? hdr->phi_c[lane] : make_float2(0.f, 0.f);
+    int fbin_prev[M];
+#pragma unroll
+    for (int m = 0; m < M; m++) fbin_prev[m] = hdr->f_bin[m];
+    float norm_rx_timing_st = hdr->norm_rx_timing;
+    float ppm = hdr->ppm;
+    int nin = hdr->nin;
+    __syncthreads();
+
+    long long off = 0, frames = 0;
+    while (off + nin <= C.nsamples && frames < C.cap_frames) {
+        const int nold = Nmem - nin;                                    // fsk.c:698
+        // ---- new samples -> X[nstash ..] ---------------------------------------------------
+        for (int i = lane; i < nin; i += 64) X[nstash + i] = load_sample(C.raw, C.fmt, off + i);
+        __syncthreads();
+
+        // ---- tone estimator (fsk.c:540-677) ------------------------------------------------
+        const int fft_loops = nin / Ndft;
+        for (int jl = 0; jl < fft_loops; jl++) {
+            const int samps = nin - (jl + 1) * Ndft;                   // fsk.c:583
+            const int fft_samps = samps >= Ndft ? Ndft : samps;        // fsk.c:584
+            // window + digit-reversed placement (kf_work leaves, kiss_fft.c:273-278)
+            for (int n = lane; n < Ndft; n += 64) {
+                const int idx = cfg.fft_src[n];
+                float2 v = make_float2(0.f, 0.f);
+                if (idx < fft_samps) {
+                    const float h = cfg.hann[idx];
+                    const float2 x = X[nstash + idx + Ndft * jl];
+                    v = make_float2(h * x.x, h * x.y);
+                }
+                FB[n] = v;
+            }
+            __syncthreads();
+            for (int s = cfg.nstages - 1; s >= 0; s--) {               // innermost butterflies first
+                const int m = cfg.mstage[s], p = cfg.radix[s], fs = cfg.fstride[s];
+                const int nb = Ndft / p;
+                for (int b = lane; b < nb; b += 64) {
+                    const int blk = b / m, k = b - blk * m;
+                    float2 *F = FB + blk * m * p + k;
+                    if (p == 4) {                                      // kf_bfly4 (kiss_fft.c:44-90), forward
+                        const float2 s0 = cmul(F[m], cfg.tw[k * fs]);
+                        const float2 s1 = cmul(F[2 * m], cfg.tw[k * fs * 2]);
+                        const float2 s2 = cmul(F[3 * m], cfg.tw[k * fs * 3]);
+                        float2 f0 = F[0];
+                        const float2 s5 = make_float2(f0.x - s1.x, f0.y - s1.y);
+                        f0 = make_float2(f0.x + s1.x, f0.y + s1.y);
+                        const float2 s3 = make_float2(s0.x + s2.x, s0.y + s2.y);
+                        const float2 s4 = make_float2(s0.x - s2.x, s0.y - s2.y);
+                        F[2 * m] = make_float2(f0.x - s3.x, f0.y - s3.y);
+                        F[0] = make_float2(f0.x + s3.x, f0.y + s3.y);
+                        F[m] = make_float2(s5.x + s4.y, s5.y - s4.x);
+                        F[3 * m] = make_float2(s5.x - s4.y, s5.y + s4.x);
+                    } else {                                           // kf_bfly2 (kiss_fft.c:21-42)
+                        const float2 t = cmul(F[m], cfg.tw[k * fs]);
+                        const float2 f0 = F[0];
+                        F[m] = make_float2(f0.x - t.x, f0.y - t.y);
+                        F[0] = make_float2(f0.x + t.x, f0.y + t.y);
+                    }
+                }
+                __syncthreads();
+            }
+            // |X|^2, band limits, IIR (fsk.c:612-628)
+            for (int i = lane; i < NH; i += 64) {
+                const float2 v = FB[i];
+                float mag = (v.x * v.x) + (v.y * v.y);
+                if (i < cfg.f_min) mag = 0.f;
+                if (cfg.f_max - 1 >= 0 && i >= cfg.f_max - 1) mag = 0.f;
+                const float e = (FE[i] * cfg.one_minus_tc) + (sqrtf(mag) * cfg.tc);
+                FE[i] = e;
+                FW[i] = e;
+            }
+            __syncthreads();
+        }
+        if (fft_loops == 0) {          // not reachable for hbr geometries (nin >= Ndft); defined behaviour anyway
+            for (int i = lane; i < NH; i += 64) FW[i] = 0.f;
+            __syncthreads();
+        }
+        // M peaks: first-maximum argmax, blank +-f_zero, ascending sort (fsk.c:633-667)
+        int fbin[M];
+#pragma unroll
+        for (int k = 0; k < M; k++) {
+            BestBin best; best.v = 0.f; best.i = 0;
+            for (int j = lane; j < NH; j += 64) {
+                const float v = FW[j];
+                if (v > best.v) { best.v = v; best.i = j; }
+            }
+#pragma unroll
+            for (int sh = 32; sh >= 1; sh >>= 1) {
+                BestBin o;
+                o.v = __shfl_xor(best.v, sh, 64);
+                o.i = __shfl_xor(best.i, sh, 64);
+                best = better(best, o);
+            }
+            // all-zero spectrum: best.v stays 0 and lanes disagree on .i only through ties at v==0,
+            // where the reference keeps imax=0 (nothing is > 0)
+            const int imax = (best.v > 0.f) ? best.i : 0;
+            int lo = imax - cfg.f_zero; lo = lo < 0 ? 0 : lo;
+            int hi = imax + cfg.f_zero; hi = hi > NH ? NH : hi;        // only bins < Ndft/2 are ever read again
+            __syncthreads();
+            for (int j = lo + lane; j < hi; j += 64) FW[j] = 0.f;
+            __syncthreads();
+            fbin[k] = imax;
+        }
+#pragma unroll
+        for (int a = 1; a < M; a++) {                                  // ascending insertion sort of M ints
+#pragma unroll
+            for (int b = a; b > 0; b--) {
+                if (fbin[b - 1] > fbin[b]) { const int t = fbin[b]; fbin[b] = fbin[b - 1]; fbin[b - 1] = t; }
+            }
+        }
+        // first run: no valid previous estimate (fsk.c:750-753)
+        if (cfg.bin_freq[fbin_prev[0]] < 1.0f) {
+#pragma unroll
+            for (int m = 0; m < M; m++) fbin_prev[m] = fbin[m];
+        }
+
+        // ---- NCO phasor chain, lanes 0..M-1 (fsk.c:756-764, 781-798, 807-824) ---------------
+        if (lane < M) {
+            int bp = fbin_prev[0], bc = fbin[0];
+#pragma unroll
+            for (int m = 1; m < M; m++) if (lane == m) { bp = fbin_prev[m]; bc = fbin[m]; }
+            const int ncase = (nin < N) ? 0 : ((nin > N) ? 2 : 1);
+            float2 phi = cmul(cfg.backoff_tab[ncase * NH + bp], phi_c);   // back the phase off
+            float2 d = cfg.dphi_tab[bp];                                   // step with the PREVIOUS estimate
+            float2 *ph = PH + lane * Lpad;
+            int s = 0;
+            for (; s < nold; s++) { ph[s] = phi; phi = cmul(phi, d); }     // old samples
+            {                                                              // comp_normalize, new estimate
+                const float av = sqrtf(phi.x * phi.x + phi.y * phi.y);
+                phi = make_float2(phi.x / av, phi.y / av);
+                d = cfg.dphi_tab[bc];
+            }
+            for (; s < L; s++) { ph[s] = phi; phi = cmul(phi, d); }        // new samples
+            phi_c = phi;                                                   // saved un-normalised (fsk.c:846)
+        }
+#pragma unroll
+        for (int m = 0; m < M; m++) fbin_prev[m] = fbin[m];                // fsk.c:847
+        __syncthreads();
+
+        // ---- down-convert: sample * conj(phasor), in place (fsk.c:791,817) ------------------
+        {
+            const float2 *src = X + (nstash - nold);                       // fsk.c:775: old tail then new block, contiguous
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                float2 *row = PH + m * Lpad;
+                for (int s = lane; s < L; s += 64) {
+                    const float2 x = src[s];
+                    const float2 p = row[s];
+                    const float2 pc = make_float2(p.x, -p.y);
+                    row[s] = cmul(x, pc);
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- integrate-and-dump: every output re-sums the Ts circular-buffer slots in slot order
+        //      (fsk.c:829-840).  Output i covers samples [i*q, i*q+Ts); sample s sits in slot s % Ts.
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            const float2 *row = PH + m * Lpad;
+            for (int i = lane; i < NI; i += 64) {
+                const int base = i * q;
+                const int r = base % Ts;
+                float it_r = 0.f, it_i = 0.f;
+                int o = (r == 0) ? 0 : Ts - r;                             // window offset of slot 0
+                for (int j = 0; j < Ts; j++) {
+                    const float2 v = row[base + o];
+                    it_r += v.x;
+                    it_i += v.y;
+                    o++;
+                    if (o == Ts) o = 0;
+                }
+                FI[m * NI + i] = make_float2(it_r, it_i);
+            }
+        }
+        __syncthreads();
+
+        // ---- stash the tail of the new block for the next frame (fsk.c:851) ------------------
+        for (int i = lane; i < nstash; i += 64) X[i] = X[nstash + nin - nstash + i];
+
+        // ---- fine timing: sum_i (sum_m |f_int|^2) * phi_ft[i]  (fsk.c:858-874) ---------------
+        float2 *TP = PH;                                                   // down-converted samples are dead now
+        for (int i = lane; i < NI; i += 64) {
+            float ft1 = 0.f;
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                const float2 v = FI[m * NI + i];
+                ft1 += (v.x * v.x) + (v.y * v.y);
+            }
+            const float2 pf = cfg.phi_ft[i];
+            TP[i] = make_float2(ft1 * pf.x, ft1 * pf.y);
+        }
+        __syncthreads();
+        float tcr = 0.f, tci = 0.f;
+        if (lane == 0) {
+            int i = 0;
+            for (; i + 8 <= NI; i += 8) {
+                float2 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) v[u] = TP[i + u];
+#pragma unroll
+                for (int u = 0; u < 8; u++) { tcr = tcr + v[u].x; tci = tci + v[u].y; }
+            }
+            for (; i < NI; i++) { const float2 v = TP[i]; tcr = tcr + v.x; tci = tci + v.y; }
+        }
+        tcr = __shfl(tcr, 0, 64);
+        tci = __shfl(tci, 0, 64);
+
+        int nin_next = nin;
+        float tr_mean = 0.f, tr_std = 0.f, tr_rxt = 0.f;
+        const bool nan_frame = (tcr != tcr) || (tci != tci);               // fsk.c:878-880: return, outputs untouched
+        if (!nan_frame) {
+            // fsk.c:883-907 (double-typed sub-expressions written out)
+            const float at = wg_atan2f(tci, tcr);
+            const float norm_rx_timing = (float)((double)at / (2 * 3.14159265358979323846));
+            const float rx_timing = norm_rx_timing * cfg.P_f;
+            const float d_nrt = norm_rx_timing - norm_rx_timing_st;
+            norm_rx_timing_st = norm_rx_timing;
+            if ((double)fabsf(d_nrt) < .2) {
+                const float appm = (float)(1e6 * (double)d_nrt / (double)cfg.nsym_f);
+                ppm = (float)(.9 * (double)ppm + .1 * (double)appm);
+            }
+            if (norm_rx_timing > 0.25f) nin_next = N + Ts / 2;
+            else if (norm_rx_timing < -0.25f) nin_next = N - Ts / 2;
+            else nin_next = N;
+
+            // ---- resample, decide, soft decisions (fsk.c:913-993) ---------------------------
+            const int low_sample = (int)floorf(rx_timing);
+            const float fract = rx_timing - (float)low_sample;
+            const int high_sample = (int)ceilf(rx_timing);
+            const float omf = 1 - fract;
+            tr_rxt = rx_timing;
+            float mymax = 0.f;
+            if (lane < WR_NSYM) {
+                const int st = (lane + 1) * P;
+                float tmax[M];
+#pragma unroll
+                for (int m = 0; m < M; m++) {
+                    const float2 a = FI[m * NI + st + low_sample];
+                    const float2 b = FI[m * NI + st + high_sample];
+                    float tr = omf * a.x, ti = omf * a.y;
+                    tr = tr + fract * b.x;
+                    ti = ti + fract * b.y;
+                    tmax[m] = (tr * tr) + (ti * ti);
+                }
+                float mx = tmax[0];
+                int sym = 0;
+#pragma unroll
+                for (int m = 0; m < M; m++) if (tmax[m] > mx) { mx = tmax[m]; sym = m; }
+                mymax = mx;
+                if (C.bits_out) {
+                    uint8_t *bo = C.bits_out + frames * Nbits;
+                    if (M == 2) bo[lane] = (uint8_t)(sym == 1);
+                    else { bo[lane * 2 + 1] = (uint8_t)(sym & 1); bo[lane * 2] = (uint8_t)((sym & 2) >> 1); }
+                }
+#pragma unroll
+                for (int m = 0; m < M; m++) tmax[m] = sqrtf(tmax[m]);
+                if (M == 2) {
+                    SDL[lane] = tmax[0] - tmax[1];
+                } else {                                                   // fsk.c:969-980, same accumulation order
+                    float s1 = -tmax[0], s0 = -tmax[0];
+                    s1 += tmax[1 % M];  s0 += -tmax[1 % M];
+                    s1 += -tmax[2 % M]; s0 += tmax[2 % M];
+                    s1 += tmax[3 % M];  s0 += tmax[3 % M];
+                    SDL[lane * 2 + 1] = s1;
+                    SDL[lane * 2] = s0;
+                }
+            }
+            if (cfg.stats) {                                               // Eb/N0 accumulators (fsk.c:984-1007)
+                if (lane < WR_NSYM) { SC[lane] = mymax; SC[WR_NSYM + lane] = sqrtf(mymax); }
+                __syncthreads();
+                if (lane == 0) {
+                    float stdebno = 0.f, meanebno = 0.f;
+                    for (int i = 0; i < WR_NSYM; i++) { stdebno += SC[i]; meanebno += SC[WR_NSYM + i]; }
+                    meanebno = meanebno / cfg.nsym_f;
+                    stdebno = (stdebno / cfg.nsym_f) - (meanebno * meanebno);
+                    if ((double)stdebno > 0.0) stdebno = (float)sqrt((double)stdebno); else stdebno = 0.0f;
+                    SC[2 * WR_NSYM] = meanebno;
+                    SC[2 * WR_NSYM + 1] = stdebno;
+                }
+                __syncthreads();
+                tr_mean = SC[2 * WR_NSYM];
+                tr_std = SC[2 * WR_NSYM + 1];
+            }
+            // ---- stats snapshot for the JSON side channel (fsk.c:1037-1066, fsk_demod.c:366-385):
+            //      raw eye traces |f_int[m][ind]| and the smoothed spectrum; normalisation is host work
+            if (C.dump && frames >= C.dump_first && ((frames - C.dump_first) % C.dump_period) == 0) {
+                const long long slot = (frames - C.dump_first) / C.dump_period;
+                if (slot < C.dump_cap) {
+                    float *d = C.dump + slot * cfg.dump_floats;
+                    const int neye = cfg.eye_traces * M * cfg.neyesamp;
+                    for (int e = lane; e < neye; e += 64) {
+                        const int j = e % cfg.neyesamp;
+                        const int tm = e / cfg.neyesamp;                 // = i*M + m
+                        const int i = tm / M, m = tm - i * M;
+                        const int ind = 2 * P * i + (high_sample + 1) + j * cfg.eye_dec;
+                        float v = 0.f;                                   // reference reads out of bounds when ind<0
+                        if (ind >= 0 && ind < NI) { const float2 f = FI[m * NI + ind]; v = sqrtf(f.x * f.x + f.y * f.y); }
+                        d[e] = v;
+                    }
+                    for (int i = lane; i < NH; i += 64) d[neye + i] = FE[i];
+                    if (lane == 0) { d[neye + NH] = (float)high_sample; d[neye + NH + 1] = (float)frames; }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- emit the frame's outputs (fsk_demod.c:403-407): a NaN frame re-emits the previous buffer
+        if (C.sd_out) {
+            float *so = C.sd_out + frames * Nbits;
+            for (int i = lane; i < Nbits; i += 64) so[i] = SDL[i];
+        }
+        if (C.trace && lane == 0) {
+            float *tr = C.trace + frames * WR_TRACE_FLOATS;
+#pragma unroll
+            for (int m = 0; m < WR_M_MAX; m++) tr[WR_TR_FEST + m] = (m < M) ? cfg.bin_freq[fbin[m < M ? m : 0]] : 0.f;
+            tr[WR_TR_NIN] = (float)nin_next;
+            tr[WR_TR_NRT] = norm_rx_timing_st;
+            tr[WR_TR_PPM] = ppm;
+            tr[WR_TR_MEAN] = tr_mean;
+            tr[WR_TR_STD] = tr_std;
+            tr[WR_TR_RXT] = tr_rxt;
+        }
+        off += nin;
+        nin = nin_next;
+        frames++;
+        __syncthreads();
+    }
+
+    // ---- save carried state ---------------------------------------------------------------
+    for (int i = lane; i < NH; i += 64) st_fft[i] = FE[i];
+    for (int i = lane; i < nstash; i += 64) st_old[i] = X[i];
+    for (int i = lane; i < Nbits; i += 64) st_sd[i] = SDL[i];
+    if (lane < M) hdr->phi_c[lane] = phi_c;
+    if (lane == 0) {
+#pragma unroll
+        for (int m = 0; m < M; m++) hdr->f_bin[m] = fbin_prev[m];
+        hdr->norm_rx_timing = norm_rx_timing_st;
+        hdr->ppm = ppm;
+        hdr->nin = nin;
+        hdr->frames_total += frames;
+        hdr->frames_call = frames;
+        hdr->consumed_call = off;
+    }
+}
+
+// explicit instantiations + launcher
+extern "C" hipError_t wr_launch_demod(const WrDemodCfg *cfg, const WrChan *d_chans, int nchan, hipStream_t stream) {
+    if (nchan <= 0) return hipSuccess;
+    dim3 grid(nchan), block(64);
+    if (cfg->M == 2) {
+        (void)hipFuncSetAttribute((const void *)wenet_demod_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, cfg->lds_bytes);
+        hipLaunchKernelGGL(wenet_demod_kernel<2>, grid, block, cfg->lds_bytes, stream, *cfg, d_chans, nchan);
+    } else {
+        (void)hipFuncSetAttribute((const void *)wenet_demod_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, cfg->lds_bytes);
+        hipLaunchKernelGGL(wenet_demod_kernel<4>, grid, block, cfg->lds_bytes, stream, *cfg, d_chans, nchan);
+    }
+    return hipGetLastError();
+}

@@ -1,0 +1,117 @@
+// glibc_atan2f.h -- op-for-op float evaluation of atan2f as glibc 2.35 (the libm of this image,
+// sysdeps/ieee754/flt-32/e_atan2f.c + s_atanf.c, fdlibm lineage) computes it, so that the timing
+// estimator's  atan2f(t_c.imag, t_c.real)  (reference src/fsk.c:883) gives the SAME float on
+// gfx950 as the reference gives on the x86-64 host.  OCML's atan2f differs in the last bit for a
+// noticeable fraction of arguments, and that bit feeds the resampling fraction of every soft
+// decision of the frame (fsk.c:913-934).
+//
+// The algorithm is the published fdlibm one: reduce |y/x| into one of five intervals, evaluate an
+// odd/even split degree-11 polynomial in single precision, add the tabulated atan(0.5|1|1.5|inf)
+// hi/lo parts, then fix the quadrant.  Constants are given by their IEEE bit patterns.
+// tests/test_host_numerics.py checks this restatement against the host's atan2f/atanf on
+// hundreds of millions of arguments (all exponents, both signs, special values); it must be
+// compiled with -ffp-contract=off.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define WG_HD __host__ __device__ __forceinline__
+#else
+#define WG_HD static inline
+#endif
+
+WG_HD float wg_u2f(uint32_t u) { union { float f; uint32_t u; } c; c.u = u; return c.f; }
+WG_HD uint32_t wg_f2u(float f) { union { float f; uint32_t u; } c; c.f = f; return c.u; }
+
+WG_HD float wg_atanf(float x) {
+    const float atanhi0 = wg_u2f(0x3eed6338u), atanhi1 = wg_u2f(0x3f490fdau),
+                atanhi2 = wg_u2f(0x3f7b985eu), atanhi3 = wg_u2f(0x3fc90fdau);
+    const float atanlo0 = wg_u2f(0x31ac3769u), atanlo1 = wg_u2f(0x33222168u),
+                atanlo2 = wg_u2f(0x33140fb4u), atanlo3 = wg_u2f(0x33a22168u);
+    const float aT0 = wg_u2f(0x3eaaaaabu), aT1 = wg_u2f(0xbe4ccccdu), aT2 = wg_u2f(0x3e124925u),
+                aT3 = wg_u2f(0xbde38e38u), aT4 = wg_u2f(0x3dba2e6eu), aT5 = wg_u2f(0xbd9d8795u),
+                aT6 = wg_u2f(0x3d886b35u), aT7 = wg_u2f(0xbd6ef16bu), aT8 = wg_u2f(0x3d4bda59u),
+                aT9 = wg_u2f(0xbd15a221u), aT10 = wg_u2f(0x3c8569d7u);
+    const float one = 1.0f;
+    float w, s1, s2, z, hi = 0.0f, lo = 0.0f;
+    int32_t hx = (int32_t)wg_f2u(x);
+    int32_t ix = hx & 0x7fffffff;
+    int id;
+    if (ix >= 0x4c000000) {                      // |x| >= 2^25
+        if (ix > 0x7f800000) return x + x;       // NaN
+        if (hx > 0) return atanhi3 + atanlo3;
+        return -atanhi3 - atanlo3;
+    }
+    if (ix < 0x3ee00000) {                       // |x| < 0.4375
+        if (ix < 0x31000000) return x;           // |x| < 2^-29
+        id = -1;
+    } else {
+        x = wg_u2f((uint32_t)ix);                // fabsf
+        if (ix < 0x3f980000) {                   // |x| < 1.1875
+            if (ix < 0x3f300000) { id = 0; x = (2.0f * x - one) / (2.0f + x); hi = atanhi0; lo = atanlo0; }
+            else                 { id = 1; x = (x - one) / (x + one);         hi = atanhi1; lo = atanlo1; }
+        } else {
+            if (ix < 0x401c0000) { id = 2; x = (x - 1.5f) / (one + 1.5f * x); hi = atanhi2; lo = atanlo2; }
+            else                 { id = 3; x = -1.0f / x;                     hi = atanhi3; lo = atanlo3; }
+        }
+    }
+    z = x * x;
+    w = z * z;
+    s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
+    s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
+    if (id < 0) return x - x * (s1 + s2);
+    z = hi - ((x * (s1 + s2) - lo) - x);
+    return (hx < 0) ? -z : z;
+}
+
+WG_HD float wg_atan2f(float y, float x) {
+    const float tiny = 1.0e-30f;
+    const float pi_o_4 = wg_u2f(0x3f490fdbu), pi_o_2 = wg_u2f(0x3fc90fdbu),
+                pi = wg_u2f(0x40490fdbu), pi_lo = wg_u2f(0xb3bbbd2eu);
+    float z;
+    int32_t hx = (int32_t)wg_f2u(x), hy = (int32_t)wg_f2u(y);
+    int32_t ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
+    int32_t k, m;
+    if (ix > 0x7f800000 || iy > 0x7f800000) return x + y;           // NaN
+    if (hx == 0x3f800000) return wg_atanf(y);                       // x == 1.0
+    m = ((hy >> 31) & 1) | ((hx >> 30) & 2);                        // 2*sign(x) + sign(y)
+    if (iy == 0) {
+        switch (m) {
+        case 0: case 1: return y;
+        case 2: return pi + tiny;
+        default: return -pi - tiny;
+        }
+    }
+    if (ix == 0) return (hy < 0) ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    if (ix == 0x7f800000) {
+        if (iy == 0x7f800000) {
+            switch (m) {
+            case 0: return pi_o_4 + tiny;
+            case 1: return -pi_o_4 - tiny;
+            case 2: return 3.0f * pi_o_4 + tiny;
+            default: return -3.0f * pi_o_4 - tiny;
+            }
+        } else {
+            switch (m) {
+            case 0: return 0.0f;
+            case 1: return -0.0f;
+            case 2: return pi + tiny;
+            default: return -pi - tiny;
+            }
+        }
+    }
+    if (iy == 0x7f800000) return (hy < 0) ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    k = (iy - ix) >> 23;
+    if (k > 60) z = pi_o_2 + 0.5f * pi_lo;                          // |y/x| > 2^60
+    else if (hx < 0 && k < -60) z = 0.0f;                           // |y|/x < -2^60
+    else {
+        float q = y / x;
+        z = wg_atanf(wg_u2f(wg_f2u(q) & 0x7fffffffu));              // atanf(fabsf(y/x))
+    }
+    switch (m) {
+    case 0: return z;
+    case 1: return wg_u2f(wg_f2u(z) ^ 0x80000000u);
+    case 2: return pi - (z - pi_lo);
+    default: return (z - pi_lo) - pi;
+    }
+}

@@ -1,0 +1,379 @@
+// ldpc_kernel.hip -- unique-word deframer and (2580,2064) LDPC sum-product decoder for gfx950.
+//
+// Reference map (file:line in /root/reference/src):
+//   UW search / packet collection     drs232_ldpc.c:176-225, wenet_ldpc.c:171-208
+//   RS232 strip / v2 descramble       drs232_ldpc.c:220-225 / wenet_ldpc.c:207
+//   sd_to_llr                         mpdecode_core.c:569-595
+//   Tanner graph (H1=1, shift=0)      mpdecode_core.c:152-379
+//   SumProduct                        mpdecode_core.c:385-489, phi0 phi0.c:13-218
+//   pack + CRC gate                   drs232_ldpc.c:234-257, gen_crc16 :91-102
+//
+// Deframer: one wavefront per channel.  64 consecutive soft symbols become a 64-bit ballot of
+// hard bits; every lane forms the 40/32-bit window that ENDS at its symbol and scores it against
+// the unique word with one xor+popcount, so a detection is a ballot + find-first.  The reference's
+// state machine semantics are kept exactly: the symbol after the detection is packet symbol 0, and
+// while a packet is collected the window is frozen, so the search resumes on the stream with the
+// collected span excised.
+//
+// Decoder: one 576-thread workgroup per packet.  The graph is static (built once on the host,
+// the reference rebuilds it per packet).  Edge messages live in LDS in slot-major order
+// msg[slot*516 + check]: the check pass (thread = check) is bank-conflict free, the variable pass
+// (thread = variable) reaches its 1..3 edges through a 16-bit address table.  A message carries
+// its sign in the float sign bit (phi0 >= 0, so -0.0f is a valid "negative zero magnitude").
+// All float sums run in the reference's order, so iteration counts and bits are identical.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "wenet_internal.h"
+#include "x87emu.h"
+
+#pragma clang fp contract(off)
+
+// =============================================================================================
+// deframer
+// =============================================================================================
+__global__ __launch_bounds__(64) void wenet_deframe_kernel(const WrDeframeChan *chans, int nchan, int mode) {
+    const int ch = blockIdx.x;
+    if (ch >= nchan) return;
+    const int lane = threadIdx.x;
+    const WrDeframeChan C = chans[ch];
+    const long long n = C.nframes_src ? (*C.nframes_src) * (long long)C.nbits_per_frame : C.nsym;
+
+    // unique words, oldest bit first (drs232_ldpc.c:77-86: 0xAB 0xCD 0xEF 0x01 with RS232 start/stop
+    // bits, LSB first; wenet_ldpc.c:77-82: the same bytes MSB first)
+    const int uw_bits = (mode == 1) ? 40 : 32;
+    const int thr = uw_bits - ((mode == 1) ? 5 : 4);
+    const unsigned long long UW = (mode == 1) ? 0x6AD677BD01ULL : 0xABCDEF01ULL;
+    const unsigned long long wmask = (1ULL << uw_bits) - 1ULL;
+    const int spp = (256 + 2 + 65) * ((mode == 1) ? 10 : 8);              // SYMBOLS_PER_PACKET
+
+    unsigned long long hist = C.state->hist;
+    int collecting = C.state->collecting;
+    long long pos = 0, npk = 0, resume = -1;
+
+    if (collecting) {                       // buffer starts at packet symbol 0
+        if (spp <= n) {
+            if (npk < C.cap_packets && lane == 0) C.starts[npk] = 0;
+            npk++;
+            pos = spp;
+            collecting = 0;
+        } else {
+            resume = 0;
+        }
+    }
+    while (resume < 0 && pos < n) {
+        const long long rem = n - pos;
+        const int nv = rem >= 64 ? 64 : (int)rem;
+        const bool valid = lane < nv;
+        const float s = valid ? C.sd[pos + lane] : 0.f;
+        const unsigned long long cur = __ballot(valid && (s < 0.f));       // bit l = hard bit of symbol pos+l
+        // window after shifting in symbols pos..pos+lane (newest = LSB)
+        const unsigned long long rev = __brevll(cur);
+        const unsigned long long W = (((hist << lane) << 1) | (rev >> (63 - lane)));
+        const int score = uw_bits - __popcll((W ^ UW) & wmask);
+        const unsigned long long dm = __ballot(valid && score >= thr);
+        if (dm == 0ULL) {
+            hist = __shfl(W, nv - 1, 64);
+            pos += nv;
+            continue;
+        }
+        const int first = __ffsll((long long)dm) - 1;
+        hist = __shfl(W, first, 64);                                      // window frozen during collection
+        const long long start = pos + first + 1;
+        if (start + spp <= n) {
+            if (npk < C.cap_packets && lane == 0) C.starts[npk] = start;
+            npk++;
+            pos = start + spp;
+        } else {
+            collecting = 1;
+            resume = start;
+        }
+    }
+    if (lane == 0) {
+        C.state->hist = hist;
+        C.state->collecting = collecting;
+        C.state->resume = (resume >= 0) ? resume : n;
+        C.state->npackets = npk < C.cap_packets ? npk : C.cap_packets;
+    }
+}
+
+// =============================================================================================
+// decoder
+// =============================================================================================
+namespace {
+
+// phi0 (phi0.c:13-218) through a 90-entry LDS table: entry = {u_lo | u_hi<<16, v0, v1, v2},
+// value = x >= u_hi ? v2 : x >= u_lo ? v1 : v0   (built and exhaustively checked in wenet_rx.hip).
+__device__ __forceinline__ float phi0_dev(float xf, const uint4 *lut) {
+    const float y = xf * 65536.0f;
+    // x86 cvttss2si semantics of (int32_t)(float): NaN / out of range -> INT32_MIN
+    const int x = (y >= -2147483648.0f && y < 2147483648.0f) ? (int)y : (int)0x80000000;
+    if (x >= 655360) return 0.0f;                  // SI16(10.0f)
+    if (x < 1) return 10.0f;
+    int idx;
+    if (x >= 327680) idx = 80 + (19 - (x >> 15));  // [5,10)
+    else if (x >= 65536) idx = 16 + (79 - (x >> 12));   // [1,5)
+    else idx = 31 - __clz(x);                      // exponent class below 1.0
+    const uint4 e = lut[idx];
+    const int u_lo = (int)(e.x & 0xffffu), u_hi = (int)(e.x >> 16);
+    return (x >= u_hi) ? __uint_as_float(e.w) : ((x >= u_lo) ? __uint_as_float(e.z) : __uint_as_float(e.y));
+}
+
+__device__ __forceinline__ float with_sign(float mag, int neg) {
+    return __uint_as_float(__float_as_uint(mag) | (neg ? 0x80000000u : 0u));
+}
+
+// edge address of variable v's socket k (data bits through the table, parity bits by arithmetic:
+// mpdecode_core.c:296-303,334-341 with mpdecode_core.c:226-234)
+__device__ __forceinline__ int var_degree(int v) { return v < WR_NDATA ? 3 : (v == WR_NCODE - 1 ? 1 : 2); }
+__device__ __forceinline__ int var_edge(int v, int k, const uint16_t *vedge_lds) {
+    if (v < WR_NDATA) return vedge_lds[v * 3 + k];
+    const int c = v - WR_NDATA;
+    if (k == 0) return ((c == 0) ? 12 : 13) * WR_NPAR + c;    // last sub of check c
+    return 12 * WR_NPAR + (c + 1);                               // second-to-last sub of check c+1
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(WR_DEC_THREADS) void wenet_decode_kernel(WrDecodeArgs A) {
+    const int pk = blockIdx.x, ch = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int slot = ch * A.max_pk + pk;
+
+    // ---- how many packets does this channel have?  (uniform early exit) ----------------------
+    long long npk;
+    const float *sd_stream = nullptr;
+    long long start = 0;
+    if (A.input_kind == WR_DEC_IN_STREAM) {
+        const WrDeframeChan D = A.dchans[ch];
+        npk = D.state->npackets;
+        if (pk >= npk) return;
+        sd_stream = D.sd;
+        start = D.starts[pk];
+    } else {
+        npk = A.npk_direct[ch];
+        if (pk >= npk) return;
+    }
+    const int n = (A.input_kind == WR_DEC_IN_SD64) ? A.n_sd : WR_NCODE;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // prologue view: double XS[n] (sd, then x = sd/mean - sign)
+    // decode view  : float msg[14*516] | uint16 vedge[2064*3] | uint4 lut[90] | misc
+    double   *XS   = (double *)smem;
+    float    *msg  = (float *)smem;
+    uint16_t *vedge = (uint16_t *)(smem + 14 * WR_NPAR * 4);                       // 28896
+    uint4    *lut  = (uint4 *)(smem + 14 * WR_NPAR * 4 + WR_NDATA * 3 * 2 + 0);    // 28896+12384 = 41280 (16B aligned)
+    double   *bc   = (double *)(smem + 41280 + WR_PHI0_LUT_ENTRIES * 16);          // broadcast scratch (8 doubles)
+    uint8_t  *bitbuf = (uint8_t *)(bc + 8);                                        // [2580] decoded bits, then [258] bytes
+
+    float llr[WR_VARS_PER_THREAD];
+    WrPacketOut *out = A.out ? &A.out[slot] : nullptr;
+
+    if (A.input_kind != WR_DEC_IN_LLR) {
+        // ---- gather the packet's soft symbols as doubles --------------------------------------
+        double sdv[WR_VARS_PER_THREAD];
+#pragma unroll
+        for (int t = 0; t < WR_VARS_PER_THREAD; t++) {
+            const int i = tid + t * WR_DEC_THREADS;
+            double v = 0.0;
+            if (i < n) {
+                if (A.input_kind == WR_DEC_IN_SD64) {
+                    v = A.sd64[(long long)slot * n + i];
+                } else if (A.mode == 1) {                       // RS232: out[8b+j] = in[10b + 8 - j]
+                    const int b = i >> 3, j = i & 7;
+                    v = (double)sd_stream[start + 10 * b + 8 - j];
+                } else {                                        // v2: symbol * scramble_code[ind % 1000]
+                    const int kb = i % 1000;
+                    const int neg = (A.scramble[kb >> 3] >> (7 - (kb & 7))) & 1;
+                    const double code = neg ? -1.0 : 1.0;
+                    v = (double)sd_stream[start + i] * code;
+                }
+                XS[i] = v;
+            }
+            sdv[t] = v;
+        }
+        __syncthreads();
+        // ---- sd_to_llr (mpdecode_core.c:569-595): the three running sums are sequential double
+        //      additions; one lane replays them in order, everything else is parallel.
+        if (tid == 0) {
+            double sum = 0.0;
+            for (int i = 0; i < n; i++) sum += fabs(XS[i]);
+            bc[0] = sum / n;
+        }
+        __syncthreads();
+        const double mean = bc[0];
+#pragma unroll
+        for (int t = 0; t < WR_VARS_PER_THREAD; t++) {
+            const int i = tid + t * WR_DEC_THREADS;
+            if (i < n) {
+                const double s = sdv[t];
+                const double sign = (double)((s > 0.0) - (s < 0.0));
+                XS[i] = s / mean - sign;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double sum = 0.0, sumsq = 0.0;
+            for (int i = 0; i < n; i++) { const double x = XS[i]; sum += x; sumsq += x * x; }
+            const double estvar = (n * sumsq - sum * sum) / (n * (n - 1));
+            bc[1] = wx_est_esn0(estvar);                        // 1.0/(2.0L*estvar + 1E-3), x87 rounding
+        }
+        __syncthreads();
+        const double estEsN0 = bc[1];
+#pragma unroll
+        for (int t = 0; t < WR_VARS_PER_THREAD; t++) {
+            const int i = tid + t * WR_DEC_THREADS;
+            llr[t] = (i < n) ? wx_llr(estEsN0, sdv[t]) : 0.f;   // (float)(4.0L*estEsN0*sd)
+            if (A.llr_out && i < n) A.llr_out[(long long)slot * n + i] = llr[t];
+        }
+        __syncthreads();                                        // XS is dead from here on
+    } else {
+#pragma unroll
+        for (int t = 0; t < WR_VARS_PER_THREAD; t++) {
+            const int i = tid + t * WR_DEC_THREADS;
+            llr[t] = (i < WR_NCODE) ? A.llr_in[(long long)slot * WR_NCODE + i] : 0.f;
+        }
+    }
+    if (A.stop_after_llr) return;
+
+    // ---- tables into LDS ----------------------------------------------------------------------
+    for (int i = tid; i < WR_NDATA * 3; i += WR_DEC_THREADS) vedge[i] = A.vedge[i];
+    for (int i = tid; i < WR_PHI0_LUT_ENTRIES; i += WR_DEC_THREADS) lut[i] = A.phi0_lut[i];
+    __syncthreads();
+
+    // ---- initial variable->check messages: phi0(|llr|), sign = llr<0 (mpdecode_core.c:353-359)
+#pragma unroll
+    for (int t = 0; t < WR_VARS_PER_THREAD; t++) {
+        const int v = tid + t * WR_DEC_THREADS;
+        if (v < WR_NCODE) {
+            const float m0 = with_sign(phi0_dev(fabsf(llr[t]), lut), llr[t] < 0.f);
+            const int d = var_degree(v);
+            for (int k = 0; k < d; k++) msg[var_edge(v, k, vedge)] = m0;
+        }
+    }
+    __syncthreads();
+
+    int result = A.max_iter, pcc = 0, pcc_written = 0;
+    unsigned bits = 0;                                          // bit t = hard decision of variable tid+t*576
+    for (int iter = 0; iter < A.max_iter; iter++) {
+        // ---- update r: thread = check (mpdecode_core.c:414-436) ------------------------------
+        int ok = 0;
+        if (tid < WR_NPAR) {
+            const int deg = (tid == 0) ? 13 : 14;
+            float mv[14];
+            unsigned sgn = 0, sbits = 0;
+            float phi_sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < 14; k++) {
+                if (k < deg) {
+                    const float m = msg[k * WR_NPAR + tid];
+                    const unsigned sb = __float_as_uint(m) >> 31;
+                    sbits |= sb << k;
+                    sgn ^= sb;
+                    mv[k] = fabsf(m);
+                    phi_sum = (k == 0) ? mv[0] : (phi_sum + mv[k]);
+                } else mv[k] = 0.f;
+            }
+            ok = (sgn == 0);
+#pragma unroll
+            for (int k = 0; k < 14; k++) {
+                if (k < deg) {
+                    const float r = phi0_dev(phi_sum - mv[k], lut);
+                    const unsigned neg = sgn ^ ((sbits >> k) & 1u);
+                    msg[k * WR_NPAR + tid] = neg ? -r : r;
+                }
+            }
+        }
+        const int ssum = __syncthreads_count(ok);
+        // ---- update q: thread = variable (mpdecode_core.c:439-464) ---------------------------
+        int any_data = 0;
+        bits = 0;
+#pragma unroll
+        for (int t = 0; t < WR_VARS_PER_THREAD; t++) {
+            const int v = tid + t * WR_DEC_THREADS;
+            if (v < WR_NCODE) {
+                const int d = var_degree(v);
+                int ea[3];
+                float cm[3];
+                float Qi = llr[t];
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    if (k < d) {
+                        ea[k] = var_edge(v, k, vedge);
+                        cm[k] = msg[ea[k]];
+                        Qi += cm[k];
+                    }
+                }
+                const int b = Qi < 0.f;
+                bits |= (unsigned)b << t;
+                if (b && v < WR_NDATA) any_data = 1;
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    if (k < d) {
+                        const float temp_sum = Qi - cm[k];
+                        const float mag = phi0_dev(fabsf(temp_sum), lut);
+                        msg[ea[k]] = with_sign(mag, !(temp_sum > 0.f));
+                    }
+                }
+            }
+        }
+        const int any = __syncthreads_or(any_data);
+        // ---- stop rules (mpdecode_core.c:466-483) --------------------------------------------
+        if (!any) { result = iter + 1; break; }                 // "zero bit errors" against the all-zero data[]
+        pcc = ssum; pcc_written = 1;
+        if (ssum == WR_NPAR) { result = iter + 1; break; }
+    }
+
+    // ---- pack MSB-first, CRC-16/CCITT-FALSE gate (drs232_ldpc.c:234-257) ----------------------
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < WR_VARS_PER_THREAD; t++) {
+        const int v = tid + t * WR_DEC_THREADS;
+        if (v < WR_NCODE) {
+            bitbuf[v] = (uint8_t)((bits >> t) & 1u);
+            if (A.bits_out) A.bits_out[(long long)slot * WR_NCODE + v] = (uint8_t)((bits >> t) & 1u);
+        }
+    }
+    __syncthreads();
+    uint8_t *bytes = bitbuf + 2592;
+    if (tid < 258) {
+        unsigned a = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) a |= (unsigned)bitbuf[8 * tid + j] << (7 - j);
+        bytes[tid] = (uint8_t)a;
+        if (out) out->bytes[tid] = (uint8_t)a;
+    }
+    __syncthreads();
+    if (tid == 0 && out) {
+        unsigned crc = 0xFFFFu;
+        for (int i = 0; i < 256; i++) {
+            unsigned x = ((crc >> 8) ^ bytes[i]) & 0xffu;
+            x ^= x >> 4;
+            crc = ((crc << 8) ^ (x << 12) ^ (x << 5) ^ x) & 0xffffu;
+        }
+        const unsigned tx = (unsigned)bytes[256] | ((unsigned)bytes[257] << 8);
+        out->crc_ok = (uint8_t)(crc == tx);
+        out->iter = result;
+        out->pcc = pcc;
+        out->pcc_written = pcc_written;
+        out->done = 1;
+    }
+}
+
+#define WR_DEC_LDS_BYTES (41280 + WR_PHI0_LUT_ENTRIES * 16 + 64 + 2592 + 272)
+
+extern "C" hipError_t wr_launch_deframe(const WrDeframeChan *d_chans, int nchan, int mode, hipStream_t stream) {
+    if (nchan <= 0) return hipSuccess;
+    hipLaunchKernelGGL(wenet_deframe_kernel, dim3(nchan), dim3(64), 0, stream, d_chans, nchan, mode);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t wr_launch_decode(const WrDecodeArgs *args, hipStream_t stream) {
+    if (args->nchan <= 0 || args->max_pk <= 0) return hipSuccess;
+    int lds = WR_DEC_LDS_BYTES;
+    const int need_prologue = (args->input_kind == WR_DEC_IN_SD64 ? args->n_sd : WR_NCODE) * 8 + 64;
+    if (args->input_kind != WR_DEC_IN_LLR && need_prologue > lds) lds = need_prologue;
+    (void)hipFuncSetAttribute((const void *)wenet_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL(wenet_decode_kernel, dim3(args->max_pk, args->nchan), dim3(WR_DEC_THREADS), lds, stream, *args);
+    return hipGetLastError();
+}

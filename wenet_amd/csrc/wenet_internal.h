@@ -1,0 +1,167 @@
+// wenet_internal.h -- layouts shared by the host side and the gfx950 kernels of libwenet_rx.so.
+#pragma once
+#include <stdint.h>
+
+#define WR_M_MAX        4
+#define WR_MAX_STAGES   12
+#define WR_NSYM         48          // symbols per modem frame (reference src/fsk.c:135)
+#define WR_TRACE_FLOATS 10          // per-frame trace record, see WR_TR_*
+
+// trace record (optional, tests/diagnostics): what the reference's modem_probe points
+// t_f_est, t_nin, t_norm_rx_timing, t_ppm, t_EbNodB expose (src/fsk.c:726,909-910,1089-1091)
+#define WR_TR_FEST   0   // [0..3] tone estimates in Hz
+#define WR_TR_NIN    4   // nin for the NEXT frame
+#define WR_TR_NRT    5   // norm_rx_timing
+#define WR_TR_PPM    6
+#define WR_TR_MEAN   7   // meanebno (fsk.c:998)   -> EbNodB is finished on the host (log10f)
+#define WR_TR_STD    8   // stdebno  (fsk.c:1001-1007)
+#define WR_TR_RXT    9   // rx_timing
+
+enum { WR_FMT_S16_REAL = 0, WR_FMT_CS16 = 1, WR_FMT_CU8 = 2, WR_FMT_CF32 = 3 };
+
+// ---- demodulator configuration: everything that is a function of (Fs,Rs,P,M,est limits) ----
+struct WrDemodCfg {
+    int Fs, Rs, Ts, N, P, Nsym, Nmem, Nbits, M, Ndft, nstash;
+    int L;            // samples down-converted per frame per tone = Nmem - Ts/P
+    int NI;           // integrator outputs per tone = (Nsym+1)*P
+    int q;            // Ts/P
+    int Lpad;         // row pitch of the phasor/down-converted rows in LDS
+    int f_min, f_max, f_zero;           // estimator band edges in bins (fsk.c:568-570)
+    int nstages;
+    int radix[WR_MAX_STAGES];           // outermost first (kiss_fft.c:308-330)
+    int mstage[WR_MAX_STAGES];
+    int fstride[WR_MAX_STAGES];
+    float tc, one_minus_tc;             // fsk.c:573, :626
+    float P_f;                          // (float)P
+    float nsym_f;                       // (float)nsym
+    int stats;                          // compute Eb/N0 accumulators + trace
+    int eye_dec, neyesamp, eye_traces;  // fsk.c:1037-1047
+    int dump_floats;                    // floats per stats snapshot: eye (8/M*M*neyesamp) + Ndft/2 + 2
+    // device tables
+    const float  *hann;                 // [Ndft]   fsk.c:94-111
+    const float2 *tw;                   // [Ndft]   kiss_fft.c:356-364
+    const int    *fft_src;              // [Ndft]   digit reversal of the DIT recursion
+    const float2 *dphi_tab;             // [Ndft/2] e^{j 2 pi f/Fs}, f = bin*Fs/Ndft (fsk.c:763)
+    const float2 *backoff_tab;          // [3][Ndft/2] fsk.c:758 for nin = N-Ts/2, N, N+Ts/2
+    const float2 *phi_ft;               // [NI]     running product of e^{j 2 pi/P} (fsk.c:858-873)
+    const float  *bin_freq;             // [Ndft/2] (float)bin*((float)Fs/(float)Ndft) (fsk.c:671)
+    // LDS carve-up (bytes)
+    int off_X, off_FB, off_PH, off_FI, off_FE, off_FW, off_SD, off_SC, lds_bytes;
+    // per-channel state block layout (floats from the block start)
+    int st_fft_est, st_samp_old, st_sd_last, st_floats;
+};
+
+// state header (first 24 floats/ints of the per-channel state block)
+struct WrChanHdr {
+    float2 phi_c[WR_M_MAX];     // fsk.h:61 (un-normalised, as saved at fsk.c:846)
+    int    f_bin[WR_M_MAX];     // previous frame's tone bins (fsk->f_est as bin index)
+    float  norm_rx_timing;      // fsk.h:64
+    float  ppm;                 // fsk.h:80
+    int    nin;                 // fsk.h:83
+    int    pad0;
+    long long frames_total;     // frames demodulated since create
+    long long frames_call;      // frames produced by the last launch
+    long long consumed_call;    // samples consumed by the last launch
+};
+
+struct WrChan {
+    const void *raw;            // interleaved samples of this launch
+    long long   nsamples;       // available samples
+    int         fmt;
+    int         pad;
+    float      *state;          // state block (WrChanHdr + arrays)
+    float      *sd_out;         // Nbits floats per frame (or null)
+    uint8_t    *bits_out;       // Nbits bytes per frame (or null)
+    long long   cap_frames;
+    float      *trace;          // WR_TRACE_FLOATS per frame (or null)
+    float      *dump;           // stats snapshots (or null): every dump_period-th frame from dump_first
+    long long   dump_first, dump_period, dump_cap;
+};
+
+// ---- deframer ----
+struct WrDeframeState {
+    unsigned long long hist;    // last 64 hard bits seen while looking for the UW (LSB = newest)
+    int collecting;             // 1: the buffer starts inside a packet (first symbol = packet symbol 0)
+    int pad;
+    long long resume;           // out: first symbol the next call must start from
+    long long npackets;         // out: completed packets found in this buffer
+};
+
+struct WrDeframeChan {
+    const float *sd;
+    long long    nsym;          // symbols available (ignored if nsym_src != null)
+    const long long *nframes_src;  // if non-null: nsym = *nframes_src * nbits_per_frame
+    int          nbits_per_frame;
+    int          pad;
+    WrDeframeState *state;
+    long long   *starts;        // out: first-symbol index of each completed packet
+    long long    cap_packets;
+};
+
+// ---- decoder ----
+#define WR_NPAR   516
+#define WR_NDATA  2064
+#define WR_NCODE  2580
+#define WR_ROWW   12
+#define WR_DEC_THREADS 576
+#define WR_VARS_PER_THREAD 5   // ceil(2580/576)
+
+struct WrPacketOut {            // one per packet slot
+    uint8_t bytes[258];         // 256 payload + 2 CRC bytes as decoded (drs232_ldpc.c:234-239)
+    uint8_t crc_ok;             // drs232_ldpc.c:243-254
+    uint8_t done;
+    int     iter;               // SumProduct result
+    int     pcc;                // parityCheckCount (only meaningful if pcc_written)
+    int     pcc_written;
+    int     pad;
+};
+
+enum { WR_DEC_IN_STREAM = 0, WR_DEC_IN_SD64 = 1, WR_DEC_IN_LLR = 2 };
+
+struct WrDecodeArgs {
+    int input_kind;             // WR_DEC_IN_*
+    int mode;                   // 1 = v1/RS232 strip (drs232_ldpc.c:220-225), 2 = v2 descramble (wenet_ldpc.c:207)
+    int max_iter;
+    int stop_after_llr;         // sd_to_llr API: only produce LLRs
+    int nchan;
+    int max_pk;                 // packet slots per channel (grid.x)
+    // WR_DEC_IN_STREAM
+    const WrDeframeChan *dchans;        // sd stream, starts[], state->npackets
+    // WR_DEC_IN_SD64 / WR_DEC_IN_LLR: dense arrays, packet p of channel c at index c*max_pk+p
+    const double *sd64;  int n_sd;      // n_sd doubles per packet (n for sd_to_llr)
+    const float  *llr_in;
+    const int    *npk_direct;           // packets per channel for the dense kinds
+    // outputs
+    WrPacketOut *out;                   // [nchan*max_pk]
+    float       *llr_out;               // optional [nchan*max_pk*n]
+    uint8_t     *bits_out;              // optional [nchan*max_pk*2580] all decoded bits (run_ldpc_decoder API)
+    // tables
+    const uint16_t *vedge;              // [2064*3] edge address (slot*516+check) per data bit, socket order
+    const uint4    *phi0_lut;           // [90]
+    const uint8_t  *scramble;           // [125]
+};
+
+// ---- phi0 (reference src/phi0.c:13-218) as data ---------------------------------------------
+// value tables; the comparison tree below 1.0 is a sorted threshold search
+static const float WR_PHI0_5_10[10] = {   // x in [5,10): index 19-(x>>15)
+    0.000116589f, 0.000192223f, 0.000316923f, 0.000522517f, 0.000861485f,
+    0.001420349f, 0.002341760f, 0.003860913f, 0.006365583f, 0.010495133f};
+static const float WR_PHI0_1_5[64] = {    // x in [1,5): index 79-(x>>12)
+    0.013903889f, 0.014800644f, 0.015755242f, 0.016771414f, 0.017853133f, 0.019004629f, 0.020230403f, 0.021535250f,
+    0.022924272f, 0.024402903f, 0.025976926f, 0.027652501f, 0.029436184f, 0.031334956f, 0.033356250f, 0.035507982f,
+    0.037798579f, 0.040237016f, 0.042832850f, 0.045596260f, 0.048538086f, 0.051669874f, 0.055003924f, 0.058553339f,
+    0.062332076f, 0.066355011f, 0.070637993f, 0.075197917f, 0.080052790f, 0.085221814f, 0.090725463f, 0.096585578f,
+    0.102825462f, 0.109469985f, 0.116545700f, 0.124080967f, 0.132106091f, 0.140653466f, 0.149757747f, 0.159456024f,
+    0.169788027f, 0.180796343f, 0.192526667f, 0.205028078f, 0.218353351f, 0.232559308f, 0.247707218f, 0.263863255f,
+    0.281099022f, 0.299492155f, 0.319127030f, 0.340095582f, 0.362498271f, 0.386445235f, 0.412057648f, 0.439469363f,
+    0.468828902f, 0.500301872f, 0.534073947f, 0.570354566f, 0.609381573f, 0.651427083f, 0.696805010f, 0.745880827f};
+static const float WR_PHI0_LT1_T[27] = {  // thresholds (as floats, scaled by 2^16 and truncated like SI16())
+    0.707107f, 0.500000f, 0.353553f, 0.250000f, 0.176777f, 0.125000f, 0.088388f, 0.062500f, 0.044194f,
+    0.031250f, 0.022097f, 0.015625f, 0.011049f, 0.007812f, 0.005524f, 0.003906f, 0.002762f, 0.001953f,
+    0.001381f, 0.000977f, 0.000691f, 0.000488f, 0.000345f, 0.000244f, 0.000173f, 0.000122f, 0.000086f};
+static const float WR_PHI0_LT1_V[27] = {  // value when x > T[k] (and x <= T[k-1])
+    0.922449644f, 1.241248638f, 1.573515241f, 1.912825912f, 2.255740095f, 2.600476919f, 2.946130351f,
+    3.292243417f, 3.638586634f, 3.985045009f, 4.331560985f, 4.678105767f, 5.024664952f, 5.371231340f,
+    5.717801329f, 6.064373119f, 6.410945809f, 6.757518949f, 7.104092314f, 7.450665792f, 7.797239326f,
+    8.143812888f, 8.490386464f, 8.836960047f, 9.183533634f, 9.530107222f, 9.876680812f};
+#define WR_PHI0_LUT_ENTRIES 90   // 16 exponent classes below 1.0 + 64 + 10

@@ -1,0 +1,876 @@
+// wenet_rx.hip -- host side of libwenet_rx.so: table construction, device memory, launches and
+// the C ABI declared in include/wenet_rx.h.  Host code only; the kernels are in
+// demod_kernel.hip / ldpc_kernel.hip.
+//
+// Everything that involves glibc's cosf/sinf (Hann window fsk.c:94-111, FFT twiddles
+// kiss_fft.c:356-364, NCO steps fsk.c:758-763, timing oscillator fsk.c:858-873) is evaluated HERE,
+// on the host, with the same libm the reference pipeline would use on this machine, as float
+// recurrences in the reference's order, and uploaded as tables: they are functions of the
+// configuration and of the tone BIN only.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+#include <vector>
+
+#include "../../include/wenet_rx.h"
+#include "wenet_internal.h"
+
+#pragma clang fp contract(off)
+
+extern "C" hipError_t wr_launch_demod(const WrDemodCfg *cfg, const WrChan *d_chans, int nchan, hipStream_t stream);
+extern "C" hipError_t wr_launch_deframe(const WrDeframeChan *d_chans, int nchan, int mode, hipStream_t stream);
+extern "C" hipError_t wr_launch_decode(const WrDecodeArgs *args, hipStream_t stream);
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+#define WR_CHECK(expr, ret)                                                                          \
+    do {                                                                                             \
+        hipError_t _e = (expr);                                                                      \
+        if (_e != hipSuccess) {                                                                      \
+            fprintf(stderr, "libwenet_rx: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(_e),    \
+                    __FILE__, __LINE__);                                                             \
+            return ret;                                                                              \
+        }                                                                                            \
+    } while (0)
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// device buffer helper
+// ------------------------------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    bool reserve(size_t bytes) {
+        if (bytes <= cap) return true;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 4 + 256;
+        if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; fprintf(stderr, "libwenet_rx: hipMalloc(%zu) failed\n", want); return false; }
+        cap = want;
+        return true;
+    }
+    template <typename T> T *as() const { return (T *)p; }
+};
+
+bool device_ready() {
+    static int state = 0;   // 0 unknown, 1 ok, -1 absent
+    if (state == 0) {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+            fprintf(stderr, "libwenet_rx: no HIP device available -- this library has no CPU fallback\n");
+            state = -1;
+        } else state = 1;
+    }
+    return state == 1;
+}
+
+struct cpx { float r, i; };
+inline cpx cmulh(cpx a, cpx b) { cpx c; c.r = a.r * b.r - a.i * b.i; c.i = a.r * b.i + a.i * b.r; return c; }
+inline cpx expj(float phi) { cpx c; c.r = cosf(phi); c.i = sinf(phi); return c; }   // comp_prim.h:95-100
+
+// ------------------------------------------------------------------------------------------------
+// demodulator tables
+// ------------------------------------------------------------------------------------------------
+struct DemodTables {
+    WrDemodCfg cfg;
+    DevBuf blob;            // all tables in one allocation
+    int est_min = 0, est_max = 0, est_space = 0;
+    int tx_f1 = 1200, tx_fs = 400;
+    bool ok = false;
+
+    static int align16(int x) { return (x + 15) & ~15; }
+
+    void set_band(int emin, int emax) {                 // fsk.c:568-570 (int division)
+        est_min = emin; est_max = emax;
+        cfg.f_min = (int)(((long long)est_min * cfg.Ndft) / cfg.Fs);
+        cfg.f_max = (int)(((long long)est_max * cfg.Ndft) / cfg.Fs);
+        cfg.f_zero = (int)(((long long)est_space * cfg.Ndft) / cfg.Fs);
+    }
+
+    bool build(int Fs, int Rs, int P, int M) {
+        memset(&cfg, 0, sizeof(cfg));
+        if (Fs <= 0 || Rs <= 0 || P <= 0) return false;                 // fsk.c:137-141
+        if (Fs % Rs != 0) return false;                                 // fsk.c:143
+        if ((Fs / Rs) % P != 0) return false;                           // fsk.c:145
+        if (M != 2 && M != 4) return false;                             // fsk.c:146
+        const int nsyms = WR_NSYM;
+        cfg.Fs = Fs; cfg.Rs = Rs; cfg.Ts = Fs / Rs; cfg.P = P; cfg.M = M; cfg.Nsym = nsyms;
+        cfg.N = cfg.Ts * nsyms;
+        cfg.Nmem = cfg.N + 2 * cfg.Ts;
+        cfg.Nbits = (M == 2) ? nsyms : nsyms * 2;
+        cfg.nstash = 4 * cfg.Ts;
+        int Ndft = 0;
+        for (int i = 1; i; i <<= 1) if (cfg.N & i) Ndft = i;            // fsk.c:169-171
+        cfg.Ndft = Ndft;
+        if (Ndft < 64 || Ndft / 2 > 2048) { fprintf(stderr, "libwenet_rx: unsupported Ndft %d\n", Ndft); return false; }
+        cfg.q = cfg.Ts / P;
+        cfg.L = cfg.Nmem - cfg.q;
+        cfg.NI = (nsyms + 1) * P;
+        cfg.Lpad = cfg.L + (cfg.L & 1);
+        cfg.P_f = (float)P;
+        cfg.nsym_f = (float)nsyms;
+        cfg.tc = (float)(0.95 * Ndft / Fs);                             // fsk.c:573
+        cfg.one_minus_tc = 1 - cfg.tc;                                  // fsk.c:626 "(1-tc)"
+        est_space = Rs - (Rs / 5);                                      // fsk.c:180
+        int emin = Rs / 4; if (emin < 0) emin = 0;                      // fsk.c:175-176
+        set_band(emin, (Fs / 2) - Rs / 4);                              // fsk.c:178
+        cfg.eye_dec = (int)ceil(((float)P * 2) / 160);                  // fsk.c:1037
+        cfg.neyesamp = (P * 2) / cfg.eye_dec;
+        cfg.eye_traces = 8 / M;
+        cfg.dump_floats = cfg.eye_traces * M * cfg.neyesamp + Ndft / 2 + 2;
+        // FFT plan (kiss_fft.c:308-330): radix 4 first, then 2
+        {
+            int n = Ndft, st = 0;
+            while (n > 1) {
+                const int p = (n % 4 == 0) ? 4 : 2;
+                n /= p;
+                if (st >= WR_MAX_STAGES) return false;
+                cfg.radix[st] = p; cfg.mstage[st] = n; st++;
+            }
+            cfg.nstages = st;
+            cfg.fstride[0] = 1;
+            for (int s = 1; s < st; s++) cfg.fstride[s] = cfg.fstride[s - 1] * cfg.radix[s - 1];
+        }
+        const int NH = Ndft / 2;
+        std::vector<float> hann(Ndft), binf(NH);
+        std::vector<cpx> tw(Ndft), dphi(NH), backoff(3 * NH), phift(cfg.NI);
+        std::vector<int> src(Ndft);
+        {                                                               // fsk.c:94-111
+            cpx d = expj((float)((2 * M_PI) / ((float)Ndft - 1)));
+            cpx r; r.r = .5f; r.i = 0.f;
+            cpx dc = d; dc.i = -dc.i;
+            r = cmulh(dc, r);
+            for (int i = 0; i < Ndft; i++) { r = cmulh(d, r); hann[i] = (float)(.5 - (double)r.r); }
+        }
+        for (int i = 0; i < Ndft; i++) {                                // kiss_fft.c:356-364
+            const double pi = 3.141592653589793238462643383279502884197169399375105820974944;
+            const double phase = -2 * pi * i / Ndft;
+            tw[i].r = (float)cosf((float)phase);
+            tw[i].i = (float)sinf((float)phase);
+        }
+        for (int i = 0; i < Ndft; i++) {                                // leaf <- input index (kf_work recursion)
+            int rem = i, idx = 0, fstride = 1;
+            for (int s = 0; s < cfg.nstages; s++) {
+                const int qd = rem / cfg.mstage[s];
+                rem -= qd * cfg.mstage[s];
+                idx += qd * fstride;
+                fstride *= cfg.radix[s];
+            }
+            src[i] = idx;
+        }
+        for (int b = 0; b < NH; b++) {
+            const float f = (float)(b) * ((float)Fs / (float)Ndft);     // fsk.c:671
+            binf[b] = f;
+            dphi[b] = expj((float)(2 * M_PI * ((f) / (float)(Fs))));    // fsk.c:763 / :788
+            for (int c = 0; c < 3; c++) {                               // fsk.c:758
+                const int nin = cfg.N + (c - 1) * (cfg.Ts / 2);
+                backoff[c * NH + b] = expj((float)(-2 * (cfg.Nmem - nin - (cfg.Ts / P)) * M_PI * ((f) / (float)(Fs))));
+            }
+        }
+        {                                                               // fsk.c:858-873
+            const cpx d = expj((float)(2 * M_PI * ((float)(Rs) / (float)(P * Rs))));
+            cpx ph; ph.r = 1; ph.i = 0;
+            for (int i = 0; i < cfg.NI; i++) { phift[i] = ph; ph = cmulh(ph, d); }
+        }
+        // LDS carve-up
+        int o = 0;
+        cfg.off_X = o;  o = align16(o + (cfg.nstash + cfg.N + cfg.Ts / 2) * 8);
+        cfg.off_FB = o; o = align16(o + Ndft * 8);
+        cfg.off_PH = o; o = align16(o + M * cfg.Lpad * 8);
+        cfg.off_FI = o; o = align16(o + M * cfg.NI * 8);
+        cfg.off_FE = o; o = align16(o + NH * 4);
+        cfg.off_FW = o; o = align16(o + NH * 4);
+        cfg.off_SD = o; o = align16(o + cfg.Nbits * 4);
+        cfg.off_SC = o; o = align16(o + (4 * nsyms + 16) * 4);
+        cfg.lds_bytes = o;
+        if (o > 160 * 1024) { fprintf(stderr, "libwenet_rx: configuration needs %d bytes of LDS (>160 KiB)\n", o); return false; }
+        // state block
+        cfg.st_fft_est = 24;                                            // sizeof(WrChanHdr)=88 -> 24 floats
+        cfg.st_samp_old = cfg.st_fft_est + NH;
+        cfg.st_sd_last = cfg.st_samp_old + 2 * cfg.nstash;
+        cfg.st_floats = cfg.st_sd_last + cfg.Nbits;
+        cfg.st_floats = (cfg.st_floats + 3) & ~3;
+        static_assert(sizeof(WrChanHdr) <= 24 * 4, "state header too large");
+        // upload
+        size_t bytes = 0;
+        auto place = [&](size_t sz) { size_t at = bytes; bytes = (bytes + sz + 255) & ~(size_t)255; return at; };
+        const size_t a_hann = place(Ndft * 4), a_tw = place(Ndft * 8), a_src = place(Ndft * 4), a_dphi = place(NH * 8),
+                     a_back = place(3 * NH * 8), a_pft = place(cfg.NI * 8), a_binf = place(NH * 4);
+        if (!blob.reserve(bytes)) return false;
+        char *base = blob.as<char>();
+        WR_CHECK(hipMemcpy(base + a_hann, hann.data(), Ndft * 4, hipMemcpyHostToDevice), false);
+        WR_CHECK(hipMemcpy(base + a_tw, tw.data(), Ndft * 8, hipMemcpyHostToDevice), false);
+        WR_CHECK(hipMemcpy(base + a_src, src.data(), Ndft * 4, hipMemcpyHostToDevice), false);
+        WR_CHECK(hipMemcpy(base + a_dphi, dphi.data(), NH * 8, hipMemcpyHostToDevice), false);
+        WR_CHECK(hipMemcpy(base + a_back, backoff.data(), 3 * NH * 8, hipMemcpyHostToDevice), false);
+        WR_CHECK(hipMemcpy(base + a_pft, phift.data(), cfg.NI * 8, hipMemcpyHostToDevice), false);
+        WR_CHECK(hipMemcpy(base + a_binf, binf.data(), NH * 4, hipMemcpyHostToDevice), false);
+        cfg.hann = (const float *)(base + a_hann);
+        cfg.tw = (const float2 *)(base + a_tw);
+        cfg.fft_src = (const int *)(base + a_src);
+        cfg.dphi_tab = (const float2 *)(base + a_dphi);
+        cfg.backoff_tab = (const float2 *)(base + a_back);
+        cfg.phi_ft = (const float2 *)(base + a_pft);
+        cfg.bin_freq = (const float *)(base + a_binf);
+        host_binf = binf;
+        ok = true;
+        return true;
+    }
+    std::vector<float> host_binf;
+
+    // initial per-channel state (fsk.c:182-245): phi_c = e^{j0}, everything else zero, nin = N
+    void init_state(std::vector<float> &st) const {
+        st.assign(cfg.st_floats, 0.f);
+        WrChanHdr *h = (WrChanHdr *)st.data();
+        for (int m = 0; m < WR_M_MAX; m++) { h->phi_c[m].x = cosf(0); h->phi_c[m].y = sinf(0); h->f_bin[m] = 0; }
+        h->nin = cfg.N;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// LDPC tables (static Tanner graph + phi0 LUT + scramble code), built once per process
+// ------------------------------------------------------------------------------------------------
+const uint16_t kHRows[WR_NPAR * WR_ROWW] = {
+#include "tables/ldpc_h2064_516_rows.inc"
+};
+const uint8_t kScramble[125] = {
+#include "tables/scramble_v2_bits.inc"
+};
+
+inline int si16(float f) { return (int32_t)(f * (1 << 16)); }           // phi0.c:10
+float phi0_linear_int(int x) {                                          // phi0.c:13-218 on the fixed-point argument
+    if (x >= si16(10.0f)) return 0.0f;
+    if (x >= si16(5.0f)) return WR_PHI0_5_10[19 - (x >> 15)];
+    if (x >= si16(1.0f)) return WR_PHI0_1_5[79 - (x >> 12)];
+    for (int k = 0; k < 27; k++) if (x > si16(WR_PHI0_LT1_T[k])) return WR_PHI0_LT1_V[k];
+    return 10.0f;
+}
+inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+float phi0_lut_eval(const uint32_t *lut, int x) {                       // host twin of phi0_dev
+    if (x >= 655360) return 0.0f;
+    if (x < 1) return 10.0f;
+    int idx;
+    if (x >= 327680) idx = 80 + (19 - (x >> 15));
+    else if (x >= 65536) idx = 16 + (79 - (x >> 12));
+    else idx = 31 - __builtin_clz((unsigned)x);
+    const uint32_t *e = lut + idx * 4;
+    const int u_lo = (int)(e[0] & 0xffffu), u_hi = (int)(e[0] >> 16);
+    uint32_t u = (x >= u_hi) ? e[3] : ((x >= u_lo) ? e[2] : e[1]);
+    float f; memcpy(&f, &u, 4); return f;
+}
+
+struct LdpcTables {
+    DevBuf blob;
+    const uint16_t *d_vedge = nullptr;
+    const uint4 *d_lut = nullptr;
+    const uint8_t *d_scramble = nullptr;
+    bool ok = false;
+
+    bool build() {
+        // variable side of the graph (mpdecode_core.c:286-360): data bit v takes part in the checks
+        // that list it, in ascending check order (= H_cols); socket = its position in that check's row
+        std::vector<uint16_t> vedge(WR_NDATA * 3, 0);
+        std::vector<int> deg(WR_NDATA, 0);
+        for (int c = 0; c < WR_NPAR; c++)
+            for (int j = 0; j < WR_ROWW; j++) {
+                const int v = kHRows[c * WR_ROWW + j];
+                if (v >= WR_NDATA || deg[v] >= 3) { fprintf(stderr, "libwenet_rx: bad code table\n"); return false; }
+                vedge[v * 3 + deg[v]++] = (uint16_t)(j * WR_NPAR + c);   // slot-major edge address
+            }
+        for (int v = 0; v < WR_NDATA; v++) if (deg[v] != 3) { fprintf(stderr, "libwenet_rx: code table: column weight != 3\n"); return false; }
+        // phi0 LUT
+        std::vector<uint32_t> lut(WR_PHI0_LUT_ENTRIES * 4, 0);
+        int thr[27];
+        for (int k = 0; k < 27; k++) thr[k] = si16(WR_PHI0_LT1_T[k]);
+        // below 1.0: "x > T" == "x >= T+1"; per exponent class of x at most two such bounds U fall
+        // inside the class (checked).  entry = {u_lo | u_hi<<16, v0, v1, v2}, value = x>=u_hi ? v2 : x>=u_lo ? v1 : v0
+        for (int e = 0; e < 16; e++) {
+            const int lo = 1 << e, hi = (1 << (e + 1)) - 1;
+            int u[3], nu = 0;
+            for (int k = 26; k >= 0; k--) { const int U = thr[k] + 1; if (U > lo && U <= hi) { if (nu < 3) u[nu] = U; nu++; } }
+            if (nu > 2) { fprintf(stderr, "libwenet_rx: phi0 table: >2 thresholds in one exponent class\n"); return false; }
+            const int u_lo = nu >= 1 ? u[0] : 0xffff, u_hi = nu >= 2 ? u[1] : 0xffff;
+            uint32_t *en = &lut[e * 4];
+            en[0] = (uint32_t)u_lo | ((uint32_t)u_hi << 16);
+            en[1] = f2u(phi0_linear_int(lo));
+            en[2] = nu >= 1 ? f2u(phi0_linear_int(u_lo)) : en[1];      // unused slots repeat their neighbour,
+            en[3] = nu >= 2 ? f2u(phi0_linear_int(u_hi)) : en[2];      // so the 0xffff sentinel is harmless at x=65535
+        }
+        for (int i = 0; i < 64; i++) { uint32_t *en = &lut[(16 + i) * 4]; en[0] = 0; en[1] = en[2] = en[3] = f2u(WR_PHI0_1_5[i]); }
+        for (int i = 0; i < 10; i++) { uint32_t *en = &lut[(80 + i) * 4]; en[0] = 0; en[1] = en[2] = en[3] = f2u(WR_PHI0_5_10[i]); }
+        for (int x = -4; x <= 700000; x++)                              // exhaustive self-check of the table form
+            if (f2u(phi0_lut_eval(lut.data(), x)) != f2u(phi0_linear_int(x))) {
+                fprintf(stderr, "libwenet_rx: phi0 table self-check failed at x=%d\n", x);
+                return false;
+            }
+        size_t a_v = 0, a_l = (WR_NDATA * 3 * 2 + 255) & ~255, a_s = a_l + ((WR_PHI0_LUT_ENTRIES * 16 + 255) & ~255);
+        if (!blob.reserve(a_s + 256)) return false;
+        char *base = blob.as<char>();
+        WR_CHECK(hipMemcpy(base + a_v, vedge.data(), WR_NDATA * 3 * 2, hipMemcpyHostToDevice), false);
+        WR_CHECK(hipMemcpy(base + a_l, lut.data(), WR_PHI0_LUT_ENTRIES * 16, hipMemcpyHostToDevice), false);
+        WR_CHECK(hipMemcpy(base + a_s, kScramble, 125, hipMemcpyHostToDevice), false);
+        d_vedge = (const uint16_t *)(base + a_v);
+        d_lut = (const uint4 *)(base + a_l);
+        d_scramble = (const uint8_t *)(base + a_s);
+        ok = true;
+        return true;
+    }
+};
+
+LdpcTables *ldpc_tables() {
+    static std::mutex mu;
+    static LdpcTables *t = nullptr;
+    std::lock_guard<std::mutex> g(mu);
+    if (!t) {
+        if (!device_ready()) return nullptr;
+        LdpcTables *n = new LdpcTables();
+        if (!n->build()) { delete n; return nullptr; }
+        t = n;
+    }
+    return t;
+}
+
+void fill_decode_tables(WrDecodeArgs &a, const LdpcTables *t) {
+    a.vedge = t->d_vedge; a.phi0_lut = t->d_lut; a.scramble = t->d_scramble;
+}
+
+}  // namespace
+
+// ================================================================================================
+// L1 handle
+// ================================================================================================
+struct wenet_fsk {
+    DemodTables tab;
+    DevBuf d_state, d_chan, d_raw, d_out, d_trace, d_dump;
+    WrChanHdr hdr;                 // host copy after the last launch
+    long long frames_total = 0;
+    long stats_first = -1, stats_period = 0;
+    float snr_est = 0.f;           // fsk->stats->snr_est recursion (fsk.c:1021), host side
+    float f_est_last[4] = {0, 0, 0, 0};
+    std::vector<wenet_modem_stats> stats_out;
+};
+
+static bool fsk_reset_state(wenet_fsk *f) {
+    std::vector<float> st;
+    f->tab.init_state(st);
+    if (!f->d_state.reserve(st.size() * 4)) return false;
+    WR_CHECK(hipMemcpy(f->d_state.p, st.data(), st.size() * 4, hipMemcpyHostToDevice), false);
+    memcpy(&f->hdr, st.data(), sizeof(WrChanHdr));
+    return true;
+}
+
+extern "C" wenet_fsk *wenet_fsk_create_hbr(int Fs, int Rs, int P, int M, int tx_f1, int tx_fs) {
+    if (tx_f1 <= 0 || tx_fs <= 0) return nullptr;                       // fsk.c:139-140
+    if (!device_ready()) return nullptr;
+    wenet_fsk *f = new wenet_fsk();
+    if (!f->tab.build(Fs, Rs, P, M)) { delete f; return nullptr; }
+    f->tab.tx_f1 = tx_f1; f->tab.tx_fs = tx_fs;
+    if (!fsk_reset_state(f) || !f->d_chan.reserve(sizeof(WrChan))) { delete f; return nullptr; }
+    return f;
+}
+
+extern "C" void wenet_fsk_destroy(wenet_fsk *f) { delete f; }
+
+extern "C" void wenet_fsk_set_est_limits(wenet_fsk *f, int fmin, int fmax) {   // fsk.c:522-528
+    if (!f) return;
+    if (fmin < 0) fmin = 0;
+    f->tab.set_band(fmin, fmax);
+}
+
+extern "C" uint32_t wenet_fsk_nin(wenet_fsk *f) { return f ? (uint32_t)f->hdr.nin : 0; }
+
+extern "C" int wenet_fsk_info(wenet_fsk *f, int what) {
+    if (!f) return -1;
+    const WrDemodCfg &c = f->tab.cfg;
+    switch (what) {
+    case 0: return c.Ndft; case 1: return c.N; case 2: return c.Ts; case 3: return c.Nmem; case 4: return c.P;
+    case 5: return c.Nsym; case 6: return c.Nbits; case 7: return c.nstash; case 8: return c.M;
+    case 9: return f->tab.est_min; case 10: return f->tab.est_max; case 11: return f->tab.est_space;
+    case 12: return c.Fs; case 13: return c.Rs;
+    }
+    return -1;
+}
+
+extern "C" void wenet_fsk_enable_stats(wenet_fsk *f, long first, long period) {
+    if (!f) return;
+    f->stats_first = first; f->stats_period = period > 0 ? period : 1;
+    f->tab.cfg.stats = 1;
+}
+
+static const int kBytesPerSample[4] = {2, 4, 2, 8};
+
+extern "C" long wenet_fsk_demod_stream(wenet_fsk *f, int fmt, const void *raw, long nsamples, int soft,
+                                       void *out, long cap_frames, long *consumed, float *trace) {
+    if (!f || fmt < 0 || fmt > 3 || nsamples < 0 || cap_frames < 0) return -1;
+    const WrDemodCfg &c = f->tab.cfg;
+    if (consumed) *consumed = 0;
+    f->stats_out.clear();
+    const long min_nin = c.N - c.Ts / 2;
+    long max_frames = nsamples / min_nin + 1;
+    if (max_frames > cap_frames) max_frames = cap_frames;
+    if (max_frames <= 0 || nsamples < f->hdr.nin) return 0;
+    const size_t raw_bytes = (size_t)nsamples * kBytesPerSample[fmt];
+    const size_t out_elt = soft ? 4 : 1;
+    if (!f->d_raw.reserve(raw_bytes) || !f->d_out.reserve((size_t)max_frames * c.Nbits * out_elt)) return -2;
+    const bool want_trace = trace != nullptr || f->tab.cfg.stats;
+    if (want_trace && !f->d_trace.reserve((size_t)max_frames * WR_TRACE_FLOATS * 4)) return -2;
+    WR_CHECK(hipMemcpy(f->d_raw.p, raw, raw_bytes, hipMemcpyHostToDevice), -3);
+    WrChan ch;
+    memset(&ch, 0, sizeof(ch));
+    ch.raw = f->d_raw.p; ch.nsamples = nsamples; ch.fmt = fmt;
+    ch.state = f->d_state.as<float>();
+    ch.sd_out = soft ? f->d_out.as<float>() : nullptr;
+    ch.bits_out = soft ? nullptr : f->d_out.as<uint8_t>();
+    ch.cap_frames = max_frames;
+    ch.trace = want_trace ? f->d_trace.as<float>() : nullptr;
+    long ndump = 0, dump_first_local = 0;
+    if (f->stats_first >= 0) {
+        // frames are numbered from create; snapshot frames are first, first+period, ...
+        const long long g0 = f->frames_total;
+        long long k = (g0 <= f->stats_first) ? 0 : (g0 - f->stats_first + f->stats_period - 1) / f->stats_period;
+        dump_first_local = (long)(f->stats_first + k * f->stats_period - g0);
+        if (dump_first_local < max_frames) ndump = (max_frames - dump_first_local + f->stats_period - 1) / f->stats_period;
+        if (ndump > 0) {
+            if (!f->d_dump.reserve((size_t)ndump * c.dump_floats * 4)) return -2;
+            ch.dump = f->d_dump.as<float>(); ch.dump_first = dump_first_local; ch.dump_period = f->stats_period; ch.dump_cap = ndump;
+        }
+    }
+    WR_CHECK(hipMemcpy(f->d_chan.p, &ch, sizeof(ch), hipMemcpyHostToDevice), -3);
+    WR_CHECK(wr_launch_demod(&f->tab.cfg, f->d_chan.as<WrChan>(), 1, 0), -4);
+    WR_CHECK(hipMemcpy(&f->hdr, f->d_state.p, sizeof(WrChanHdr), hipMemcpyDeviceToHost), -3);
+    const long frames = (long)f->hdr.frames_call;
+    if (consumed) *consumed = (long)f->hdr.consumed_call;
+    if (frames > 0 && out) WR_CHECK(hipMemcpy(out, f->d_out.p, (size_t)frames * c.Nbits * out_elt, hipMemcpyDeviceToHost), -3);
+    std::vector<float> tr;
+    if (want_trace && frames > 0) {
+        tr.resize((size_t)frames * WR_TRACE_FLOATS);
+        WR_CHECK(hipMemcpy(tr.data(), f->d_trace.p, tr.size() * 4, hipMemcpyDeviceToHost), -3);
+        if (trace) memcpy(trace, tr.data(), tr.size() * 4);
+    }
+    if (f->tab.cfg.stats && frames > 0) {
+        // finish the statistics on the host: EbNodB needs glibc log10f (fsk.c:1009), snr_est is a
+        // per-frame recursion (fsk.c:1021); a NaN frame (mean==std==0 in the trace AND unchanged timing)
+        // leaves them untouched in the reference, which the kernel marks with rx_timing trace = 0 and mean=0
+        std::vector<float> dump;
+        long got = 0;
+        if (ndump > 0) {
+            got = (frames > dump_first_local) ? (frames - dump_first_local + f->stats_period - 1) / f->stats_period : 0;
+            if (got > ndump) got = ndump;
+            if (got > 0) { dump.resize((size_t)got * c.dump_floats); WR_CHECK(hipMemcpy(dump.data(), f->d_dump.p, dump.size() * 4, hipMemcpyDeviceToHost), -3); }
+        }
+        long next_dump = dump_first_local, di = 0;
+        for (long k = 0; k < frames; k++) {
+            const float *t = &tr[(size_t)k * WR_TRACE_FLOATS];
+            const float meanebno = t[WR_TR_MEAN], stdebno = t[WR_TR_STD];
+            const float EbNodB = -6 + (20 * log10f((float)((1e-6 + meanebno) / (1e-6 + stdebno))));
+            f->snr_est = (float)(.5 * f->snr_est + .5 * EbNodB);
+            for (int m = 0; m < 4; m++) f->f_est_last[m] = t[WR_TR_FEST + m];
+            if (di < got && k == next_dump) {
+                wenet_modem_stats s;
+                memset(&s, 0, sizeof(s));
+                const float *d = &dump[(size_t)di * c.dump_floats];
+                const int neye = c.eye_traces * c.M * c.neyesamp;
+                s.snr_est = f->snr_est; s.ppm = t[WR_TR_PPM];
+                for (int m = 0; m < 4; m++) s.f_est[m] = t[WR_TR_FEST + m];
+                s.rx_timing = t[WR_TR_RXT];
+                s.foff = (float)((f->tab.tx_f1 + f->tab.tx_f1 + f->tab.tx_fs) / 2) - (t[WR_TR_FEST] + t[WR_TR_FEST + 1]) / 2;
+                s.neyetr = c.M * c.eye_traces; s.neyesamp = c.neyesamp;
+                float eye_max = 0;                                       // fsk.c:1068-1079
+                for (int e = 0; e < neye; e++) if (fabsf(d[e]) > eye_max) eye_max = fabsf(d[e]);
+                for (int e = 0; e < neye; e++) s.rx_eye[e / c.neyesamp][e % c.neyesamp] = d[e] / eye_max;
+                s.nfft_est = c.Ndft / 2;
+                memcpy(s.fft_est, d + neye, sizeof(float) * (c.Ndft / 2));
+                f->stats_out.push_back(s);
+                di++; next_dump += f->stats_period;
+            }
+        }
+    }
+    f->frames_total += frames;
+    return frames;
+}
+
+extern "C" void wenet_fsk_demod_sd(wenet_fsk *f, float rx_sd[], const wenet_comp in[]) {
+    if (!f) return;
+    long used = 0;
+    (void)wenet_fsk_demod_stream(f, WENET_FMT_CF32, in, (long)f->hdr.nin, 1, rx_sd, 1, &used, nullptr);
+}
+extern "C" void wenet_fsk_demod(wenet_fsk *f, uint8_t rx_bits[], const wenet_comp in[]) {
+    if (!f) return;
+    long used = 0;
+    (void)wenet_fsk_demod_stream(f, WENET_FMT_CF32, in, (long)f->hdr.nin, 0, rx_bits, 1, &used, nullptr);
+}
+
+extern "C" int wenet_fsk_get_stats(wenet_fsk *f, wenet_modem_stats *out, int cap) {
+    if (!f) return 0;
+    int n = (int)f->stats_out.size();
+    if (n > cap) n = cap;
+    for (int i = 0; i < n; i++) out[i] = f->stats_out[i];
+    return n;
+}
+
+// ================================================================================================
+// L2 LDPC API
+// ================================================================================================
+namespace {
+struct DecodeScratch {
+    DevBuf d_in, d_out, d_llr, d_npk, d_bits;
+};
+std::mutex g_dec_mu;
+DecodeScratch g_dec;
+
+// npk dense packets through the decode kernel; kind = WR_DEC_IN_LLR (in = float[npk*2580]) or
+// WR_DEC_IN_SD64 (in = double[npk*n])
+int run_dense(int kind, const void *in, int npk, int n, int mode, int max_iter, int stop_after_llr,
+              std::vector<WrPacketOut> *outs, float *llr_host, uint8_t *bits_host = nullptr) {
+    LdpcTables *t = ldpc_tables();
+    if (!t) return -1;
+    std::lock_guard<std::mutex> g(g_dec_mu);
+    const size_t in_bytes = (size_t)npk * n * (kind == WR_DEC_IN_SD64 ? 8 : 4);
+    if (!g_dec.d_in.reserve(in_bytes) || !g_dec.d_out.reserve((size_t)npk * sizeof(WrPacketOut)) || !g_dec.d_npk.reserve(16)) return -2;
+    if (llr_host && !g_dec.d_llr.reserve((size_t)npk * n * 4)) return -2;
+    if (bits_host && !g_dec.d_bits.reserve((size_t)npk * WR_NCODE)) return -2;
+    WR_CHECK(hipMemcpy(g_dec.d_in.p, in, in_bytes, hipMemcpyHostToDevice), -3);
+    WR_CHECK(hipMemset(g_dec.d_out.p, 0, (size_t)npk * sizeof(WrPacketOut)), -3);
+    WR_CHECK(hipMemcpy(g_dec.d_npk.p, &npk, 4, hipMemcpyHostToDevice), -3);
+    WrDecodeArgs a;
+    memset(&a, 0, sizeof(a));
+    a.input_kind = kind; a.mode = mode; a.max_iter = max_iter; a.stop_after_llr = stop_after_llr;
+    a.nchan = 1; a.max_pk = npk;
+    a.sd64 = (kind == WR_DEC_IN_SD64) ? g_dec.d_in.as<double>() : nullptr;
+    a.n_sd = n;
+    a.llr_in = (kind == WR_DEC_IN_LLR) ? g_dec.d_in.as<float>() : nullptr;
+    a.npk_direct = g_dec.d_npk.as<int>();
+    a.out = g_dec.d_out.as<WrPacketOut>();
+    a.llr_out = llr_host ? g_dec.d_llr.as<float>() : nullptr;
+    a.bits_out = bits_host ? g_dec.d_bits.as<uint8_t>() : nullptr;
+    fill_decode_tables(a, t);
+    WR_CHECK(wr_launch_decode(&a, 0), -4);
+    WR_CHECK(hipDeviceSynchronize(), -4);
+    if (outs) {
+        outs->resize(npk);
+        WR_CHECK(hipMemcpy(outs->data(), g_dec.d_out.p, (size_t)npk * sizeof(WrPacketOut), hipMemcpyDeviceToHost), -3);
+    }
+    if (llr_host) WR_CHECK(hipMemcpy(llr_host, g_dec.d_llr.p, (size_t)npk * n * 4, hipMemcpyDeviceToHost), -3);
+    if (bits_host) WR_CHECK(hipMemcpy(bits_host, g_dec.d_bits.p, (size_t)npk * WR_NCODE, hipMemcpyDeviceToHost), -3);
+    return 0;
+}
+}  // namespace
+
+extern "C" int wenet_ldpc_decode_batch(const float *llr, int npk, int max_iter, uint8_t *bits, int *iters, int *pcc) {
+    if (npk <= 0) return 0;
+    std::vector<WrPacketOut> outs;
+    int rc = run_dense(WR_DEC_IN_LLR, llr, npk, WR_NCODE, 0, max_iter, 0, &outs, nullptr, bits);
+    if (rc < 0) return rc;
+    for (int i = 0; i < npk; i++) {
+        if (iters) iters[i] = outs[i].iter;
+        if (pcc && outs[i].pcc_written) pcc[i] = outs[i].pcc;          // mpdecode_core.c:479 is skipped on the all-zero exit
+    }
+    return 0;
+}
+
+extern "C" int wenet_run_ldpc_decoder(struct wenet_ldpc *ldpc, uint8_t out_char[], float input[], int *parityCheckCount) {
+    if (!ldpc || ldpc->CodeLength != WR_NCODE || ldpc->NumberParityBits != WR_NPAR || ldpc->NumberRowsHcols != WR_NDATA ||
+        ldpc->max_row_weight != WR_ROWW || ldpc->max_col_weight != 3 || ldpc->dec_type != 0)
+        return -1;
+    int iter = 0, pcc_local = parityCheckCount ? *parityCheckCount : 0;
+    int rc = wenet_ldpc_decode_batch(input, 1, ldpc->max_iter, out_char, &iter, &pcc_local);
+    if (rc < 0) return rc;
+    if (parityCheckCount) *parityCheckCount = pcc_local;
+    return iter;
+}
+
+extern "C" void wenet_sd_to_llr(float llr[], double sd[], int n) {
+    if (n <= 0 || n > WR_DEC_THREADS * WR_VARS_PER_THREAD) { fprintf(stderr, "libwenet_rx: wenet_sd_to_llr: n=%d unsupported\n", n); return; }
+    (void)run_dense(WR_DEC_IN_SD64, sd, 1, n, 0, 0, 1, nullptr, llr);
+}
+
+// ================================================================================================
+// L2 deframer handle = the symbol loop of drs232_ldpc.c:176-274 / wenet_ldpc.c:171-258
+// ================================================================================================
+struct wenet_deframer {
+    int mode = 1, max_iter = 10, spp = 3230;
+    std::vector<float> carry;            // symbols from the last resume point on
+    long long carry_base = 0;            // absolute index of carry[0] in the symbol stream
+    unsigned long long hist = 0;         // bit_buffer (zero-initialised, drs232_ldpc.c:172)
+    int collecting = 0;
+    DevBuf d_sd, d_state, d_chan, d_starts, d_out;
+};
+
+extern "C" wenet_deframer *wenet_deframer_create(int framing_mode, int max_iter) {
+    if (framing_mode != 1 && framing_mode != 2) return nullptr;
+    if (!ldpc_tables()) return nullptr;
+    wenet_deframer *d = new wenet_deframer();
+    d->mode = framing_mode; d->max_iter = max_iter;
+    d->spp = 323 * (framing_mode == 1 ? 10 : 8);
+    if (!d->d_state.reserve(sizeof(WrDeframeState)) || !d->d_chan.reserve(sizeof(WrDeframeChan))) { delete d; return nullptr; }
+    return d;
+}
+extern "C" void wenet_deframer_destroy(wenet_deframer *d) { delete d; }
+
+extern "C" long wenet_deframer_push(wenet_deframer *d, const float *symbols, long nsym, uint8_t *pkt_bytes,
+                                    wenet_packet_info *pkt_info, long cap) {
+    if (!d || nsym < 0) return -1;
+    LdpcTables *t = ldpc_tables();
+    if (!t) return -1;
+    if (nsym > 0) d->carry.insert(d->carry.end(), symbols, symbols + nsym);
+    const long long n = (long long)d->carry.size();
+    if (n == 0) return 0;
+    const int max_pk = (int)(n / d->spp + 1);
+    if (!d->d_sd.reserve((size_t)n * 4) || !d->d_starts.reserve((size_t)max_pk * 8) || !d->d_out.reserve((size_t)max_pk * sizeof(WrPacketOut))) return -2;
+    WR_CHECK(hipMemcpy(d->d_sd.p, d->carry.data(), (size_t)n * 4, hipMemcpyHostToDevice), -3);
+    WrDeframeState st;
+    memset(&st, 0, sizeof(st));
+    st.hist = d->hist; st.collecting = d->collecting;
+    WR_CHECK(hipMemcpy(d->d_state.p, &st, sizeof(st), hipMemcpyHostToDevice), -3);
+    WrDeframeChan dc;
+    memset(&dc, 0, sizeof(dc));
+    dc.sd = d->d_sd.as<float>(); dc.nsym = n; dc.nframes_src = nullptr; dc.nbits_per_frame = 0;
+    dc.state = d->d_state.as<WrDeframeState>(); dc.starts = d->d_starts.as<long long>(); dc.cap_packets = max_pk;
+    WR_CHECK(hipMemcpy(d->d_chan.p, &dc, sizeof(dc), hipMemcpyHostToDevice), -3);
+    WR_CHECK(wr_launch_deframe(d->d_chan.as<WrDeframeChan>(), 1, d->mode, 0), -4);
+    WrDecodeArgs a;
+    memset(&a, 0, sizeof(a));
+    a.input_kind = WR_DEC_IN_STREAM; a.mode = d->mode; a.max_iter = d->max_iter; a.nchan = 1; a.max_pk = max_pk;
+    a.dchans = d->d_chan.as<WrDeframeChan>();
+    a.out = d->d_out.as<WrPacketOut>();
+    fill_decode_tables(a, t);
+    WR_CHECK(wr_launch_decode(&a, 0), -4);
+    WR_CHECK(hipMemcpy(&st, d->d_state.p, sizeof(st), hipMemcpyDeviceToHost), -3);   // synchronises
+    long npk = (long)st.npackets;
+    std::vector<WrPacketOut> outs(npk);
+    std::vector<long long> starts(npk);
+    if (npk > 0) {
+        WR_CHECK(hipMemcpy(outs.data(), d->d_out.p, (size_t)npk * sizeof(WrPacketOut), hipMemcpyDeviceToHost), -3);
+        WR_CHECK(hipMemcpy(starts.data(), d->d_starts.p, (size_t)npk * 8, hipMemcpyDeviceToHost), -3);
+    }
+    if (npk > cap) { fprintf(stderr, "libwenet_rx: wenet_deframer_push: %ld packets > cap %ld\n", npk, cap); return -5; }
+    for (long i = 0; i < npk; i++) {
+        if (pkt_bytes) memcpy(pkt_bytes + (size_t)i * 258, outs[i].bytes, 258);
+        if (pkt_info) { pkt_info[i].iter = outs[i].iter; pkt_info[i].crc_ok = outs[i].crc_ok; pkt_info[i].start_symbol = d->carry_base + starts[i]; }
+    }
+    d->hist = st.hist; d->collecting = st.collecting;
+    d->carry.erase(d->carry.begin(), d->carry.begin() + st.resume);
+    d->carry_base += st.resume;
+    return npk;
+}
+
+// ================================================================================================
+// batch receive chain
+// ================================================================================================
+struct wenet_rx {
+    DemodTables tab;
+    int mode = 1, max_iter = 10, spp = 3230;
+    bool want_trace = false, want_llr = false;
+    int nchan = 0, max_pk = 0;
+    std::vector<long long> sd_off, cap_frames;           // per channel: float offset into d_sd, frame capacity
+    DevBuf d_states, d_chans, d_dchans, d_dstates, d_sd, d_starts, d_out, d_trace, d_llr, d_raw;
+    std::vector<float> h_states;
+    std::vector<WrDeframeState> h_dstates;
+    std::vector<WrPacketOut> h_out;
+    std::vector<long long> h_starts;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t stream = nullptr;
+    bool pending = false;
+    ~wenet_rx() { for (auto &e : ev) if (e) (void)hipEventDestroy(e); }
+};
+
+extern "C" wenet_rx *wenet_rx_create(int Fs, int Rs, int P, int M, int framing_mode, int max_iter, int est_lo, int est_hi) {
+    if (framing_mode != 1 && framing_mode != 2) return nullptr;
+    LdpcTables *t = ldpc_tables();
+    if (!t) return nullptr;
+    wenet_rx *rx = new wenet_rx();
+    if (!rx->tab.build(Fs, Rs, P, M)) { delete rx; return nullptr; }
+    if (est_lo > 0 && est_hi > est_lo) rx->tab.set_band(est_lo, est_hi);       // fsk_demod.c:215-218
+    rx->mode = framing_mode; rx->max_iter = max_iter; rx->spp = 323 * (framing_mode == 1 ? 10 : 8);
+    for (auto &e : rx->ev) if (hipEventCreate(&e) != hipSuccess) { delete rx; return nullptr; }
+    return rx;
+}
+extern "C" void wenet_rx_destroy(wenet_rx *rx) { delete rx; }
+extern "C" void wenet_rx_enable_trace(wenet_rx *rx, int on) { if (rx) { rx->want_trace = on != 0; rx->tab.cfg.stats = on ? 1 : 0; } }
+extern "C" void wenet_rx_enable_llr_dump(wenet_rx *rx, int on) { if (rx) rx->want_llr = on != 0; }
+
+extern "C" int wenet_rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const long long *nsamples, int fmt, void *stream_v) {
+    if (!rx || nchan <= 0 || fmt < 0 || fmt > 3) return -1;
+    LdpcTables *t = ldpc_tables();
+    if (!t) return -1;
+    const WrDemodCfg &c = rx->tab.cfg;
+    hipStream_t stream = (hipStream_t)stream_v;
+    rx->stream = stream; rx->nchan = nchan;
+    rx->sd_off.assign(nchan + 1, 0);
+    rx->cap_frames.assign(nchan, 0);
+    const long long min_nin = c.N - c.Ts / 2;
+    long long max_pk = 1;
+    for (int i = 0; i < nchan; i++) {
+        const long long cf = nsamples[i] / min_nin + 1;
+        rx->cap_frames[i] = cf;
+        rx->sd_off[i + 1] = rx->sd_off[i] + cf * c.Nbits;
+        const long long pk = cf * c.Nbits / rx->spp + 1;
+        if (pk > max_pk) max_pk = pk;
+    }
+    rx->max_pk = (int)max_pk;
+    const size_t stb = (size_t)c.st_floats * 4;
+    if (!rx->d_states.reserve(stb * nchan) || !rx->d_chans.reserve(sizeof(WrChan) * nchan) ||
+        !rx->d_dchans.reserve(sizeof(WrDeframeChan) * nchan) || !rx->d_dstates.reserve(sizeof(WrDeframeState) * nchan) ||
+        !rx->d_sd.reserve((size_t)rx->sd_off[nchan] * 4) || !rx->d_starts.reserve((size_t)nchan * max_pk * 8) ||
+        !rx->d_out.reserve((size_t)nchan * max_pk * sizeof(WrPacketOut)))
+        return -2;
+    if (rx->want_trace && !rx->d_trace.reserve((size_t)(rx->sd_off[nchan] / c.Nbits) * WR_TRACE_FLOATS * 4)) return -2;
+    if (rx->want_llr && !rx->d_llr.reserve((size_t)nchan * max_pk * WR_NCODE * 4)) return -2;
+    // fresh modem + deframer state per capture
+    std::vector<float> st0;
+    rx->tab.init_state(st0);
+    rx->h_states.resize((size_t)c.st_floats * nchan);
+    for (int i = 0; i < nchan; i++) memcpy(&rx->h_states[(size_t)i * c.st_floats], st0.data(), stb);
+    WR_CHECK(hipMemcpyAsync(rx->d_states.p, rx->h_states.data(), stb * nchan, hipMemcpyHostToDevice, stream), -3);
+    WR_CHECK(hipMemsetAsync(rx->d_dstates.p, 0, sizeof(WrDeframeState) * nchan, stream), -3);
+    std::vector<WrChan> chans(nchan);
+    std::vector<WrDeframeChan> dch(nchan);
+    for (int i = 0; i < nchan; i++) {
+        WrChan &ch = chans[i];
+        memset(&ch, 0, sizeof(ch));
+        ch.raw = raw[i]; ch.nsamples = nsamples[i]; ch.fmt = fmt;
+        ch.state = rx->d_states.as<float>() + (size_t)i * c.st_floats;
+        ch.sd_out = rx->d_sd.as<float>() + rx->sd_off[i];
+        ch.cap_frames = rx->cap_frames[i];
+        ch.trace = rx->want_trace ? rx->d_trace.as<float>() + (rx->sd_off[i] / c.Nbits) * WR_TRACE_FLOATS : nullptr;
+        WrDeframeChan &d = dch[i];
+        memset(&d, 0, sizeof(d));
+        d.sd = ch.sd_out;
+        d.nframes_src = (const long long *)((const char *)ch.state + offsetof(WrChanHdr, frames_call));
+        d.nbits_per_frame = c.Nbits;
+        d.state = rx->d_dstates.as<WrDeframeState>() + i;
+        d.starts = rx->d_starts.as<long long>() + (size_t)i * max_pk;
+        d.cap_packets = max_pk;
+    }
+    // (pageable H2D copies are staged synchronously by the runtime, so the vectors may go out of scope)
+    WR_CHECK(hipMemcpyAsync(rx->d_chans.p, chans.data(), sizeof(WrChan) * nchan, hipMemcpyHostToDevice, stream), -3);
+    WR_CHECK(hipMemcpyAsync(rx->d_dchans.p, dch.data(), sizeof(WrDeframeChan) * nchan, hipMemcpyHostToDevice, stream), -3);
+    WR_CHECK(hipStreamSynchronize(stream), -3);
+    WrDecodeArgs a;
+    memset(&a, 0, sizeof(a));
+    a.input_kind = WR_DEC_IN_STREAM; a.mode = rx->mode; a.max_iter = rx->max_iter; a.nchan = nchan; a.max_pk = (int)max_pk;
+    a.dchans = rx->d_dchans.as<WrDeframeChan>();
+    a.out = rx->d_out.as<WrPacketOut>();
+    a.llr_out = rx->want_llr ? rx->d_llr.as<float>() : nullptr;
+    fill_decode_tables(a, t);
+    WR_CHECK(hipEventRecord(rx->ev[0], stream), -4);
+    WR_CHECK(wr_launch_demod(&rx->tab.cfg, rx->d_chans.as<WrChan>(), nchan, stream), -4);
+    WR_CHECK(hipEventRecord(rx->ev[1], stream), -4);
+    WR_CHECK(wr_launch_deframe(rx->d_dchans.as<WrDeframeChan>(), nchan, rx->mode, stream), -4);
+    WR_CHECK(hipEventRecord(rx->ev[2], stream), -4);
+    WR_CHECK(wr_launch_decode(&a, stream), -4);
+    WR_CHECK(hipEventRecord(rx->ev[3], stream), -4);
+    rx->pending = true;
+    return 0;
+}
+
+extern "C" int wenet_rx_collect(wenet_rx *rx) {
+    if (!rx || !rx->pending) return -1;
+    const WrDemodCfg &c = rx->tab.cfg;
+    const int nchan = rx->nchan;
+    WR_CHECK(hipEventSynchronize(rx->ev[3]), -4);
+    rx->h_dstates.resize(nchan);
+    WR_CHECK(hipMemcpy(rx->h_states.data(), rx->d_states.p, (size_t)c.st_floats * 4 * nchan, hipMemcpyDeviceToHost), -3);
+    WR_CHECK(hipMemcpy(rx->h_dstates.data(), rx->d_dstates.p, sizeof(WrDeframeState) * nchan, hipMemcpyDeviceToHost), -3);
+    rx->h_out.resize((size_t)nchan * rx->max_pk);
+    rx->h_starts.resize((size_t)nchan * rx->max_pk);
+    // fetch only the packet slots that were filled
+    for (int i = 0; i < nchan; i++) {
+        const long long npk = rx->h_dstates[i].npackets;
+        if (npk <= 0) continue;
+        WR_CHECK(hipMemcpy(&rx->h_out[(size_t)i * rx->max_pk], rx->d_out.as<WrPacketOut>() + (size_t)i * rx->max_pk,
+                           (size_t)npk * sizeof(WrPacketOut), hipMemcpyDeviceToHost), -3);
+        WR_CHECK(hipMemcpy(&rx->h_starts[(size_t)i * rx->max_pk], rx->d_starts.as<long long>() + (size_t)i * rx->max_pk,
+                           (size_t)npk * 8, hipMemcpyDeviceToHost), -3);
+    }
+    rx->pending = false;
+    return 0;
+}
+
+extern "C" int wenet_rx_process(wenet_rx *rx, int nchan, const void *const *raw, const long long *nsamples, int fmt,
+                                int device, void *stream) {
+    if (!rx || nchan <= 0 || fmt < 0 || fmt > 3) return -1;
+    if (device) {
+        int rc = wenet_rx_enqueue(rx, nchan, raw, nsamples, fmt, stream);
+        return rc < 0 ? rc : wenet_rx_collect(rx);
+    }
+    std::vector<size_t> off(nchan + 1, 0);
+    for (int i = 0; i < nchan; i++) off[i + 1] = (off[i] + (size_t)nsamples[i] * kBytesPerSample[fmt] + 255) & ~(size_t)255;
+    if (!rx->d_raw.reserve(off[nchan] + 256)) return -2;
+    std::vector<const void *> dptr(nchan);
+    for (int i = 0; i < nchan; i++) {
+        dptr[i] = rx->d_raw.as<char>() + off[i];
+        WR_CHECK(hipMemcpy((void *)dptr[i], raw[i], (size_t)nsamples[i] * kBytesPerSample[fmt], hipMemcpyHostToDevice), -3);
+    }
+    int rc = wenet_rx_enqueue(rx, nchan, dptr.data(), nsamples, fmt, stream);
+    return rc < 0 ? rc : wenet_rx_collect(rx);
+}
+
+extern "C" long long wenet_rx_frames(wenet_rx *rx, int ch) {
+    if (!rx || ch < 0 || ch >= rx->nchan) return -1;
+    return ((const WrChanHdr *)&rx->h_states[(size_t)ch * rx->tab.cfg.st_floats])->frames_call;
+}
+extern "C" long long wenet_rx_packets(wenet_rx *rx, int ch) {
+    if (!rx || ch < 0 || ch >= rx->nchan || rx->h_dstates.empty()) return -1;
+    return rx->h_dstates[ch].npackets;
+}
+extern "C" long long wenet_rx_get_packets(wenet_rx *rx, int ch, uint8_t *pkt_bytes, wenet_packet_info *info, long long cap) {
+    long long n = wenet_rx_packets(rx, ch);
+    if (n < 0) return n;
+    if (n > cap) n = cap;
+    for (long long i = 0; i < n; i++) {
+        const WrPacketOut &o = rx->h_out[(size_t)ch * rx->max_pk + i];
+        if (pkt_bytes) memcpy(pkt_bytes + (size_t)i * 258, o.bytes, 258);
+        if (info) { info[i].iter = o.iter; info[i].crc_ok = o.crc_ok; info[i].start_symbol = rx->h_starts[(size_t)ch * rx->max_pk + i]; }
+    }
+    return n;
+}
+extern "C" long long wenet_rx_get_soft(wenet_rx *rx, int ch, float *sd, long long cap) {
+    long long fr = wenet_rx_frames(rx, ch);
+    if (fr < 0) return fr;
+    long long n = fr * rx->tab.cfg.Nbits;
+    if (n > cap) n = cap;
+    if (n > 0) WR_CHECK(hipMemcpy(sd, rx->d_sd.as<float>() + rx->sd_off[ch], (size_t)n * 4, hipMemcpyDeviceToHost), -3);
+    return n;
+}
+extern "C" long long wenet_rx_get_trace(wenet_rx *rx, int ch, float *trace, long long cap_frames) {
+    long long fr = wenet_rx_frames(rx, ch);
+    if (fr < 0 || !rx->want_trace) return -1;
+    if (fr > cap_frames) fr = cap_frames;
+    if (fr > 0) WR_CHECK(hipMemcpy(trace, rx->d_trace.as<float>() + (rx->sd_off[ch] / rx->tab.cfg.Nbits) * WR_TRACE_FLOATS,
+                                    (size_t)fr * WR_TRACE_FLOATS * 4, hipMemcpyDeviceToHost), -3);
+    return fr;
+}
+extern "C" long long wenet_rx_get_llrs(wenet_rx *rx, int ch, float *llr, long long cap_packets) {
+    long long n = wenet_rx_packets(rx, ch);
+    if (n < 0 || !rx->want_llr) return -1;
+    if (n > cap_packets) n = cap_packets;
+    if (n > 0) WR_CHECK(hipMemcpy(llr, rx->d_llr.as<float>() + (size_t)ch * rx->max_pk * WR_NCODE, (size_t)n * WR_NCODE * 4, hipMemcpyDeviceToHost), -3);
+    return n;
+}
+extern "C" float wenet_rx_last_ms(wenet_rx *rx, int what) {
+    if (!rx || what < 0 || what > 3) return -1.f;
+    float ms = 0.f;
+    hipError_t e = (what == 3) ? hipEventElapsedTime(&ms, rx->ev[0], rx->ev[3]) : hipEventElapsedTime(&ms, rx->ev[what], rx->ev[what + 1]);
+    return e == hipSuccess ? ms : -1.f;
+}
+
+extern "C" int wenet_rx_device_info(int what) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    if (what == 0) return n;
+    if (n <= 0) return -1;
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, 0) != hipSuccess) return -1;
+    if (what == 1) return p.multiProcessorCount;
+    return -1;
+}
+extern "C" const char *wenet_rx_version(void) { return "wenet_rx 0.1 (gfx950)"; }

@@ -1,0 +1,107 @@
+"""Batch receive chain: many independent IQ captures -> 256-byte packets on one MI355X."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import lib as _lib
+from .fsk import BYTES_PER_SAMPLE, FMT, TRACE_FLOATS
+
+
+class RxBatch:
+    def __init__(self, Fs, Rs, M=2, P=0, framing=1, max_iter=10, est=(0, 0)):
+        self._L = _lib.load()
+        if P == 0:
+            P = Fs // Rs                                  # fsk_demod.c:186-188
+        self._h = self._L.wenet_rx_create(Fs, Rs, P, M, framing, max_iter, est[0], est[1])
+        if not self._h:
+            raise RuntimeError("wenet_rx_create failed (illegal parameters or no GPU)")
+        self.Fs, self.Rs, self.M, self.P, self.framing = Fs, Rs, M, P, framing
+        self.Ts = Fs // Rs
+        self.Nbits = 48 * (1 if M == 2 else 2)
+        self.nchan = 0
+
+    def close(self):
+        if self._h:
+            self._L.wenet_rx_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def enable_trace(self, on=True):
+        self._L.wenet_rx_enable_trace(self._h, 1 if on else 0)
+
+    def enable_llr_dump(self, on=True):
+        self._L.wenet_rx_enable_llr_dump(self._h, 1 if on else 0)
+
+    # ---- host buffers ------------------------------------------------------------------
+    def process(self, captures, fmt):
+        """captures: list of numpy arrays (raw samples in format fmt)."""
+        bufs = [np.ascontiguousarray(c).view(np.uint8).reshape(-1) for c in captures]
+        n = len(bufs)
+        ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
+        ns = (C.c_longlong * n)(*[b.size // BYTES_PER_SAMPLE[fmt] for b in bufs])
+        rc = self._L.wenet_rx_process(self._h, n, ptrs, ns, FMT[fmt], 0, None)
+        if rc < 0:
+            raise RuntimeError(f"wenet_rx_process failed ({rc})")
+        self.nchan = n
+        self._nsamples = [int(x) for x in ns]
+
+    # ---- device buffers (e.g. torch tensors already resident in HBM) ----------------------
+    def enqueue_device(self, dev_ptrs, nsamples, fmt, stream=None):
+        n = len(dev_ptrs)
+        ptrs = (C.c_void_p * n)(*dev_ptrs)
+        ns = (C.c_longlong * n)(*nsamples)
+        rc = self._L.wenet_rx_enqueue(self._h, n, ptrs, ns, FMT[fmt], C.c_void_p(stream) if stream else None)
+        if rc < 0:
+            raise RuntimeError(f"wenet_rx_enqueue failed ({rc})")
+        self.nchan = n
+        self._nsamples = [int(x) for x in nsamples]
+
+    def collect(self):
+        rc = self._L.wenet_rx_collect(self._h)
+        if rc < 0:
+            raise RuntimeError(f"wenet_rx_collect failed ({rc})")
+
+    # ---- results ------------------------------------------------------------------------
+    def frames(self, ch):
+        return int(self._L.wenet_rx_frames(self._h, ch))
+
+    def npackets(self, ch):
+        return int(self._L.wenet_rx_packets(self._h, ch))
+
+    def packets(self, ch):
+        n = self.npackets(ch)
+        pk = np.zeros((max(n, 1), 258), np.uint8)
+        info = (_lib.PacketInfo * max(n, 1))()
+        got = self._L.wenet_rx_get_packets(self._h, ch, pk.ctypes.data, info, n)
+        return dict(n=got, bytes=pk[:got], iter=np.array([info[i].iter for i in range(got)], np.int32),
+                    crc_ok=np.array([bool(info[i].crc_ok) for i in range(got)]),
+                    start=np.array([info[i].start_symbol for i in range(got)], np.int64))
+
+    def valid_payloads(self, ch):
+        """what the reference pipe writes for this capture: the 256-byte payloads of CRC-valid packets."""
+        p = self.packets(ch)
+        return b"".join(bytes(p["bytes"][i][:256]) for i in range(p["n"]) if p["crc_ok"][i])
+
+    def soft(self, ch):
+        n = self.frames(ch) * self.Nbits
+        sd = np.zeros(max(n, 1), np.float32)
+        got = self._L.wenet_rx_get_soft(self._h, ch, sd.ctypes.data, n)
+        return sd[:got]
+
+    def trace(self, ch):
+        n = self.frames(ch)
+        tr = np.zeros((max(n, 1), TRACE_FLOATS), np.float32)
+        got = self._L.wenet_rx_get_trace(self._h, ch, tr.ctypes.data, n)
+        return tr[:max(got, 0)]
+
+    def llrs(self, ch):
+        n = self.npackets(ch)
+        out = np.zeros((max(n, 1), 2580), np.float32)
+        got = self._L.wenet_rx_get_llrs(self._h, ch, out.ctypes.data, n)
+        return out[:max(got, 0)]
+
+    def last_ms(self, what=3):
+        return float(self._L.wenet_rx_last_ms(self._h, what))
