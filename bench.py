@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the Wenet receive hot path on MI355X.
+
+Metric (BASELINE.json): IQ Msamples/s demodulated + LDPC-decoded (and packets/s) at Eb/N0 = 8 dB.
+Workload: BASELINE config 2 made legal: Wenet v2, 2-FSK, Rs 96 000 baud,
+Fs 960 000 sps, cu8 IQ, 10 s per capture, Eb/N0 8 dB -- as a BATCH of independent captures per
+GPU ("many independent IQ captures shard embarrassingly", north_star).  One step = one pass of
+the whole chain (demod -> deframe -> decode, packets copied back to the host) over every capture
+of the rank's batch, with the IQ already resident in HBM.  N GPUs = N ranks, each with its own
+batch (weak scaling, no collective on the data path).
+
+Prints ONE JSON line (see the contract in the task description) with two extra objects:
+  roofline      the demod kernel (dominant) against the 8 TB/s HBM peak, from HIP events around
+                the kernel on its launch stream
+  cpu_baseline  the reference C pipeline (oracle/_ref, built from the unmodified sources) timed
+                on this host on a bounded sample of the same captures; packets must match the GPU's
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_SAMPLE = 2.0 + 256.0 / 27440.0      # cu8 in + packet bytes out
+HBM_PEAK_GBS = 8000.0                              # MI355X_MICROARCH.md: 8 TB/s
+
+
+def cpu_baseline(cfg, caps_host, framing, gpu_payloads, budget_s=20.0):
+    """Reference pipeline `fsk_demod --cu8 -s M Fs Rs - - | {drs232,wenet}_ldpc - -` on host cores."""
+    ref_dir = os.path.join(ROOT, "oracle", "_ref")
+    demod = os.path.join(ref_dir, "fsk_demod")
+    l2 = os.path.join(ref_dir, "drs232_ldpc" if framing == 1 else "wenet_ldpc")
+    kind = "reference"
+    if not (os.path.exists(demod) and os.path.exists(l2)):
+        kind = "port"
+    total_s, total_samples, n_done, same = 0.0, 0, 0, True
+    with tempfile.TemporaryDirectory() as td:
+        for i, raw in enumerate(caps_host):
+            if total_s > budget_s:
+                break
+            if kind == "reference":
+                path = os.path.join(td, "cap.cu8")
+                raw.tofile(path)
+                cmd = f"{demod} --cu8 -s {cfg.M} {cfg.Fs} {cfg.Rs} {path} - 2>/dev/null | {l2} - - 2>/dev/null"
+                t0 = time.perf_counter()
+                out = subprocess.run(cmd, shell=True, stdout=subprocess.PIPE, check=True).stdout
+                dt = time.perf_counter() - t0
+            else:
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                import oracle_lib as ol
+                t0 = time.perf_counter()
+                sd, _ = ol.oracle_demod(raw, "cu8", cfg.Fs, cfg.Rs, cfg.M)
+                d = ol.oracle_deframe(sd, framing)
+                dt = time.perf_counter() - t0
+                out = b"".join(bytes(d["bytes"][k][:256]) for k in range(d["n"]) if d["crc_ok"][k])
+            total_s += dt
+            total_samples += raw.size // 2
+            n_done += 1
+            same = same and (out == gpu_payloads[i])
+    return {"value": round(total_samples / total_s / 1e6, 3), "unit": "Msamples/s",
+            "cores": 2 if kind == "reference" else 1, "kind": kind,
+            "sample": f"{n_done} of the batch's captures ({total_samples} samples), sequential, "
+                      f"2-process pipe, stats off; packets identical to GPU: {same}",
+            "packets_match_gpu": bool(same)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--captures", type=int, default=int(os.environ.get("WENET_BENCH_CAPTURES", "64")),
+                    help="independent captures per GPU")
+    ap.add_argument("--seconds", type=float, default=10.0, help="length of each capture")
+    ap.add_argument("--ebno", type=float, default=8.0)
+    ap.add_argument("--config", default="v2", choices=["v1", "v2", "4fsk"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from wenet_amd import siggen
+    from wenet_amd.rx import RxBatch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    cfg = siggen.CONFIGS[args.config]()
+    nsym = int(args.seconds * cfg.Rs)
+    nsamp = nsym * cfg.Ts
+    B = args.captures
+    # synthetic captures, generated on the GPU: distinct payload streams (up to 8) x independent noise
+    streams = [siggen.air_symbols(cfg, nsym, 2001 + 97 * k + 1000 * rank)[0] for k in range(min(B, 8))]
+    caps = [siggen.make_capture_torch(cfg, streams[i % len(streams)], args.ebno, 7000 + i + 100000 * rank, dev)
+            for i in range(B)]
+    torch.cuda.synchronize()
+    ptrs = [int(c.data_ptr()) for c in caps]
+    ns = [nsamp] * B
+
+    rx = RxBatch(cfg.Fs, cfg.Rs, cfg.M, framing=cfg.mode, max_iter=10)
+
+    def step():
+        rx.enqueue_device(ptrs, ns, "cu8")
+        rx.collect()
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    k_ms = np.zeros(4)
+    for _ in range(args.steps):
+        step()
+        k_ms += [rx.last_ms(i) for i in range(4)]
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    k_ms /= max(args.steps, 1)
+
+    npk_valid = sum(int(rx.packets(c)["crc_ok"].sum()) for c in range(B))
+    npk_all = sum(rx.npackets(c) for c in range(B))
+    total_samples = world * B * nsamp * args.steps
+    value = total_samples / dt / 1e6
+
+    # single-stream latency figure (the ">= 50x real time on one stream" target)
+    single = RxBatch(cfg.Fs, cfg.Rs, cfg.M, framing=cfg.mode, max_iter=10)
+    single.enqueue_device(ptrs[:1], ns[:1], "cu8"); single.collect()
+    t1 = time.perf_counter()
+    single.enqueue_device(ptrs[:1], ns[:1], "cu8"); single.collect()
+    single_s = time.perf_counter() - t1
+
+    if rank == 0:
+        demod_s = k_ms[0] / 1e3
+        achieved = ALGO_BYTES_PER_SAMPLE * B * nsamp / demod_s / 1e9
+        line = {
+            "metric": "IQ Msamples/s demod+LDPC-decoded", "value": round(value, 3), "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{cfg.name} {cfg.M}-FSK Rs={cfg.Rs} Fs={cfg.Fs} cu8 Eb/N0={args.ebno}dB "
+                                   f"{args.seconds:g}s x {B} independent captures per GPU (BASELINE config 2 shape, batched)",
+                       "captures_per_gpu": B, "samples_per_capture": nsamp, "framing": cfg.mode, "ldpc_max_iter": 10},
+            "x_realtime_aggregate": round(value * 1e6 / cfg.Fs, 1),
+            "packets_per_s": round(world * npk_valid * args.steps / dt, 1),
+            "packets_valid_per_step_rank0": npk_valid, "packets_found_per_step_rank0": npk_all,
+            "kernel_ms": {"demod": round(k_ms[0], 3), "deframe": round(k_ms[1], 3), "decode": round(k_ms[2], 3),
+                          "gpu_total": round(k_ms[3], 3)},
+            "single_stream": {"ms": round(single_s * 1e3, 2), "msamples_per_s": round(nsamp / single_s / 1e6, 2),
+                              "x_realtime": round(nsamp / single_s / cfg.Fs, 1),
+                              "gpu_ms": round(single.last_ms(3), 2)},
+            "roofline": {"bound": "hbm", "kernel": "wenet_demod_kernel", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "algorithmic_bytes_per_launch": round(ALGO_BYTES_PER_SAMPLE * B * nsamp),
+                         "avg_launch_ms": round(k_ms[0], 3)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            ncpu = min(B, 8)
+            caps_host = [caps[i].cpu().numpy() for i in range(ncpu)]
+            gpu_payloads = [rx.valid_payloads(i) for i in range(ncpu)]
+            line["cpu_baseline"] = cpu_baseline(cfg, caps_host, cfg.mode, gpu_payloads)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -46,6 +46,40 @@ __device__ __forceinline__ float2 load_sample(const void *raw, int fmt, long lon
     }
 }
 
+// packed-f32 forms (v_pk_mul_f32 / v_pk_add_f32): two independent IEEE operations per instruction,
+// no fusion -- a lone wavefront is instruction-issue bound, so halving the instruction count matters.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f cmul_pk(v2f a, v2f b) {
+    // (a.x*b.x - a.y*b.y, a.x*b.y + a.y*b.x), each product and each sum rounded separately (no FMA):
+    //   t1 = (a.x*b.x, a.y*b.x)   t2 = (a.y*b.y, a.x*b.y)   r = (t1.x - t2.x, t1.y + t2.y)
+    // hipcc needs 5 VALU + 2 nops for this shape; written out it is 3 packed instructions.  The s_nop is the
+    // wait state hipcc itself places between a packed multiply and a packed add that reads its result.
+#ifndef WR_CHAIN_SCALAR
+    v2f r, t1, t2;
+    asm("v_pk_mul_f32 %1, %3, %4 op_sel_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %2, %3, %4 op_sel:[1,1] op_sel_hi:[0,1]\n\t"
+        "s_nop 0\n\t"
+        "v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]"
+        : "=v"(r), "=&v"(t1), "=&v"(t2)
+        : "v"(a), "v"(b));
+#else
+    // scalar f32 VALU: 4 independent multiplies, then the subtract and the add (dependent depth 2).
+    // Written as asm so that the SLP vectoriser does not re-pack it into the slower v_pk_* forms.
+    v2f r;
+    float t1, t2, t3, t4, rx, ry;
+    asm("v_mul_f32 %2, %6, %8\n\t"
+        "v_mul_f32 %3, %7, %9\n\t"
+        "v_mul_f32 %4, %6, %9\n\t"
+        "v_mul_f32 %5, %7, %8\n\t"
+        "v_sub_f32 %0, %2, %3\n\t"
+        "v_add_f32 %1, %4, %5"
+        : "=v"(rx), "=v"(ry), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4)
+        : "v"(a.x), "v"(a.y), "v"(b.x), "v"(b.y));
+    r.x = rx; r.y = ry;
+#endif
+    return r;
+}
+
 struct BestBin { float v; int i; };
 
 __device__ __forceinline__ BestBin better(BestBin a, BestBin b) {
@@ -56,7 +90,11 @@ __device__ __forceinline__ BestBin better(BestBin a, BestBin b) {
 
 }  // namespace
 
-template <int M>
+// PROF: accumulate s_memtime deltas per phase into C.prof (development aid, separate instantiation)
+#define WR_PROF_PHASES 12
+#define PROF_MARK(k) do { if (PROF) { const long long _t = (long long)__builtin_readcyclecounter(); prof[k] += _t - t_last; t_last = _t; } } while (0)
+
+template <int M, bool PROF, bool TLDS>
 __global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const WrChan *chans, int nchan) {
     const int ch = blockIdx.x;
     if (ch >= nchan) return;
@@ -72,6 +110,12 @@ __global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const W
     float  *FW = (float *)(smem + cfg.off_FW);    // [Ndft/2]             peak-search working copy
     float  *SDL = (float *)(smem + cfg.off_SD);   // [Nbits]              last soft decisions (kept across a NaN frame)
     float  *SC = (float *)(smem + cfg.off_SC);    // [4*Nsym + 16]        scratch
+    // configuration tables: LDS copies (TLDS) or the global originals (configurations too big for LDS)
+    const float2 *tw_t   = TLDS ? (const float2 *)(smem + cfg.off_TW) : cfg.tw;
+    const float  *hann_t = TLDS ? (const float *)(smem + cfg.off_HANN) : cfg.hann;
+    const int    *src_t  = TLDS ? (const int *)(smem + cfg.off_SRC) : cfg.fft_src;
+    const float2 *pft_t  = TLDS ? (const float2 *)(smem + cfg.off_PFT) : cfg.phi_ft;
+    const float2 *dphi_t = TLDS ? (const float2 *)(smem + cfg.off_DPHI) : cfg.dphi_tab;
 
     const int Ts = cfg.Ts, N = cfg.N, P = cfg.P, Nmem = cfg.Nmem, nstash = cfg.nstash;
     const int Ndft = cfg.Ndft, NH = cfg.Ndft / 2, L = cfg.L, NI = cfg.NI, q = cfg.q, Lpad = cfg.Lpad;
@@ -85,21 +129,65 @@ __global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const W
     for (int i = lane; i < NH; i += 64) FE[i] = st_fft[i];
     for (int i = lane; i < nstash; i += 64) X[i] = st_old[i];
     for (int i = lane; i < Nbits; i += 64) SDL[i] = st_sd[i];
-    float2 phi_c = (lane < M) ? hdr->phi_c[lane] : make_float2(0.f, 0.f);
+    if (TLDS) {
+        float2 *tw_w = (float2 *)(smem + cfg.off_TW); float *hann_w = (float *)(smem + cfg.off_HANN);
+        int *src_w = (int *)(smem + cfg.off_SRC); float2 *pft_w = (float2 *)(smem + cfg.off_PFT);
+        float2 *dphi_w = (float2 *)(smem + cfg.off_DPHI);
+        for (int i = lane; i < Ndft; i += 64) { tw_w[i] = cfg.tw[i]; hann_w[i] = cfg.hann[i]; src_w[i] = cfg.fft_src[i]; }
+        for (int i = lane; i < NI; i += 64) pft_w[i] = cfg.phi_ft[i];
+        for (int i = lane; i < NH; i += 64) dphi_w[i] = cfg.dphi_tab[i];
+    }
+    float2 phi_c = hdr->phi_c[lane % M];   // meaningful in lanes 0..M-1
     int fbin_prev[M];
 #pragma unroll
-    for (int m = 0; m < M; m++) fbin_prev[m] = hdr->f_bin[m];
+    for (int m = 0; m < M; m++) fbin_prev[m] = __builtin_amdgcn_readfirstlane(hdr->f_bin[m]);
     float norm_rx_timing_st = hdr->norm_rx_timing;
     float ppm = hdr->ppm;
-    int nin = hdr->nin;
+    int nin = __builtin_amdgcn_readfirstlane(hdr->nin);
     __syncthreads();
+
+    long long prof[WR_PROF_PHASES];
+#pragma unroll
+    for (int k = 0; k < WR_PROF_PHASES; k++) prof[k] = 0;
+    long long t_last = PROF ? (long long)__builtin_readcyclecounter() : 0;
+
+    // Input prefetch: while frame k is processed, the longest possible window of frame k+1
+    // (N + Ts/2 samples from off+nin) is already in flight into registers.
+    constexpr int KPRE = 8;
+    const bool use_pre = (N + Ts / 2) <= 64 * KPRE;
+    float2 pre[KPRE];
+#pragma unroll
+    for (int k = 0; k < KPRE; k++) pre[k] = make_float2(0.f, 0.f);
+    if (use_pre) {
+        const long long last = C.nsamples > 0 ? C.nsamples - 1 : 0;
+#pragma unroll
+        for (int k = 0; k < KPRE; k++) {                 // unconditional, index clamped: nothing waits here
+            long long i = lane + 64 * k;
+            i = i < last ? i : last;
+            if (C.nsamples > 0) pre[k] = load_sample(C.raw, C.fmt, i);
+        }
+    }
 
     long long off = 0, frames = 0;
     while (off + nin <= C.nsamples && frames < C.cap_frames) {
         const int nold = Nmem - nin;                                    // fsk.c:698
+        PROF_MARK(11);
         // ---- new samples -> X[nstash ..] ---------------------------------------------------
-        for (int i = lane; i < nin; i += 64) X[nstash + i] = load_sample(C.raw, C.fmt, off + i);
+        if (use_pre) {
+#pragma unroll
+            for (int k = 0; k < KPRE; k++) { const int i = lane + 64 * k; if (i < nin) X[nstash + i] = pre[k]; }
+            const long long off_next = off + nin, last = C.nsamples - 1;
+#pragma unroll
+            for (int k = 0; k < KPRE; k++) {             // clamped index: samples past the end are never used
+                long long i = off_next + lane + 64 * k;
+                i = i < last ? i : last;
+                pre[k] = load_sample(C.raw, C.fmt, i);
+            }
+        } else {
+            for (int i = lane; i < nin; i += 64) X[nstash + i] = load_sample(C.raw, C.fmt, off + i);
+        }
         __syncthreads();
+        PROF_MARK(0);
 
         // ---- tone estimator (fsk.c:540-677) ------------------------------------------------
         const int fft_loops = nin / Ndft;
@@ -108,10 +196,10 @@ __global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const W
             const int fft_samps = samps >= Ndft ? Ndft : samps;        // fsk.c:584
             // window + digit-reversed placement (kf_work leaves, kiss_fft.c:273-278)
             for (int n = lane; n < Ndft; n += 64) {
-                const int idx = cfg.fft_src[n];
+                const int idx = src_t[n];
                 float2 v = make_float2(0.f, 0.f);
                 if (idx < fft_samps) {
-                    const float h = cfg.hann[idx];
+                    const float h = hann_t[idx];
                     const float2 x = X[nstash + idx + Ndft * jl];
                     v = make_float2(h * x.x, h * x.y);
                 }
@@ -125,9 +213,9 @@ __global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const W
                     const int blk = b / m, k = b - blk * m;
                     float2 *F = FB + blk * m * p + k;
                     if (p == 4) {                                      // kf_bfly4 (kiss_fft.c:44-90), forward
-                        const float2 s0 = cmul(F[m], cfg.tw[k * fs]);
-                        const float2 s1 = cmul(F[2 * m], cfg.tw[k * fs * 2]);
-                        const float2 s2 = cmul(F[3 * m], cfg.tw[k * fs * 3]);
+                        const float2 s0 = cmul(F[m], tw_t[k * fs]);
+                        const float2 s1 = cmul(F[2 * m], tw_t[k * fs * 2]);
+                        const float2 s2 = cmul(F[3 * m], tw_t[k * fs * 3]);
                         float2 f0 = F[0];
                         const float2 s5 = make_float2(f0.x - s1.x, f0.y - s1.y);
                         f0 = make_float2(f0.x + s1.x, f0.y + s1.y);
@@ -138,7 +226,7 @@ __global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const W
                         F[m] = make_float2(s5.x + s4.y, s5.y - s4.x);
                         F[3 * m] = make_float2(s5.x - s4.y, s5.y + s4.x);
                     } else {                                           // kf_bfly2 (kiss_fft.c:21-42)
-                        const float2 t = cmul(F[m], cfg.tw[k * fs]);
+                        const float2 t = cmul(F[m], tw_t[k * fs]);
                         const float2 f0 = F[0];
                         F[m] = make_float2(f0.x - t.x, f0.y - t.y);
                         F[0] = make_float2(f0.x + t.x, f0.y + t.y);
@@ -162,6 +250,7 @@ __global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const W
             for (int i = lane; i < NH; i += 64) FW[i] = 0.f;
             __syncthreads();
         }
+        PROF_MARK(1);
         // M peaks: first-maximum argmax, blank +-f_zero, ascending sort (fsk.c:633-667)
         int fbin[M];
 #pragma unroll
@@ -180,7 +269,8 @@ __global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const W
             }
             // all-zero spectrum: best.v stays 0 and lanes disagree on .i only through ties at v==0,
             // where the reference keeps imax=0 (nothing is > 0)
-            const int imax = (best.v > 0.f) ? best.i : 0;
+            // (the butterfly leaves the same winner in every lane; readfirstlane tells the compiler it is uniform)
+            const int imax = __builtin_amdgcn_readfirstlane((best.v > 0.f) ? best.i : 0);
             int lo = imax - cfg.f_zero; lo = lo < 0 ? 0 : lo;
             int hi = imax + cfg.f_zero; hi = hi > NH ? NH : hi;        // only bins < Ndft/2 are ever read again
             __syncthreads();
@@ -201,29 +291,40 @@ __global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const W
             for (int m = 0; m < M; m++) fbin_prev[m] = fbin[m];
         }
 
+        PROF_MARK(2);
         // ---- NCO phasor chain, lanes 0..M-1 (fsk.c:756-764, 781-798, 807-824) ---------------
         if (lane < M) {
+            // lanes 0..M-1 carry one tone each.  Trip counts are wave-uniform (scalar loop control).
             int bp = fbin_prev[0], bc = fbin[0];
 #pragma unroll
             for (int m = 1; m < M; m++) if (lane == m) { bp = fbin_prev[m]; bc = fbin[m]; }
             const int ncase = (nin < N) ? 0 : ((nin > N) ? 2 : 1);
-            float2 phi = cmul(cfg.backoff_tab[ncase * NH + bp], phi_c);   // back the phase off
-            float2 d = cfg.dphi_tab[bp];                                   // step with the PREVIOUS estimate
-            float2 *ph = PH + lane * Lpad;
+            const float2 bo = cfg.backoff_tab[ncase * NH + bp];
+            v2f phi = cmul_pk((v2f){bo.x, bo.y}, (v2f){phi_c.x, phi_c.y});   // back the phase off (fsk.c:758-759)
+            float2 dd = dphi_t[bp];                                          // step with the PREVIOUS estimate
+            v2f d = {dd.x, dd.y};
+            v2f *ph = (v2f *)(PH + lane * Lpad);
             int s = 0;
-            for (; s < nold; s++) { ph[s] = phi; phi = cmul(phi, d); }     // old samples
+            for (; s < nold; s++) { ph[s] = phi; phi = cmul_pk(phi, d); }    // old samples (2..2.5 Ts steps)
             {                                                              // comp_normalize, new estimate
                 const float av = sqrtf(phi.x * phi.x + phi.y * phi.y);
-                phi = make_float2(phi.x / av, phi.y / av);
-                d = cfg.dphi_tab[bc];
+                phi = (v2f){phi.x / av, phi.y / av};
+                dd = dphi_t[bc];
+                d = (v2f){dd.x, dd.y};
             }
-            for (; s < L; s++) { ph[s] = phi; phi = cmul(phi, d); }        // new samples
-            phi_c = phi;                                                   // saved un-normalised (fsk.c:846)
+            // new samples: manual unroll by 8 (inline asm is 'convergent', the loop unroller leaves it alone)
+            for (; s + 8 <= L; s += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; u++) { ph[s + u] = phi; phi = cmul_pk(phi, d); }
+            }
+            for (; s < L; s++) { ph[s] = phi; phi = cmul_pk(phi, d); }
+            phi_c = make_float2(phi.x, phi.y);                             // saved un-normalised (fsk.c:846)
         }
 #pragma unroll
         for (int m = 0; m < M; m++) fbin_prev[m] = fbin[m];                // fsk.c:847
         __syncthreads();
 
+        PROF_MARK(3);
         // ---- down-convert: sample * conj(phasor), in place (fsk.c:791,817) ------------------
         {
             const float2 *src = X + (nstash - nold);                       // fsk.c:775: old tail then new block, contiguous
@@ -240,28 +341,42 @@ __global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const W
         }
         __syncthreads();
 
+        PROF_MARK(4);
         // ---- integrate-and-dump: every output re-sums the Ts circular-buffer slots in slot order
         //      (fsk.c:829-840).  Output i covers samples [i*q, i*q+Ts); sample s sits in slot s % Ts.
+        for (int i = lane; i < NI; i += 64) {
+            const int base = i * q;
+            const int r = base % Ts;
+            int o = (r == 0) ? 0 : Ts - r;                                 // window offset of slot 0
+            v2f acc[M];
 #pragma unroll
-        for (int m = 0; m < M; m++) {
-            const float2 *row = PH + m * Lpad;
-            for (int i = lane; i < NI; i += 64) {
-                const int base = i * q;
-                const int r = base % Ts;
-                float it_r = 0.f, it_i = 0.f;
-                int o = (r == 0) ? 0 : Ts - r;                             // window offset of slot 0
-                for (int j = 0; j < Ts; j++) {
-                    const float2 v = row[base + o];
-                    it_r += v.x;
-                    it_i += v.y;
-                    o++;
-                    if (o == Ts) o = 0;
+            for (int m = 0; m < M; m++) acc[m] = (v2f){0.f, 0.f};
+            for (int j0 = 0; j0 < Ts; j0 += 8) {                           // 8 slots at a time: loads first, then the ordered adds
+                v2f v[M][8];
+                int oo = o;
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int idx = (j0 + u < Ts) ? base + oo : base;      // padding reads a valid address, value unused
+#pragma unroll
+                    for (int m = 0; m < M; m++) v[m][u] = ((const v2f *)PH)[m * Lpad + idx];
+                    oo++;
+                    if (oo == Ts) oo = 0;
                 }
-                FI[m * NI + i] = make_float2(it_r, it_i);
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    if (j0 + u < Ts) {
+#pragma unroll
+                        for (int m = 0; m < M; m++) acc[m] = acc[m] + v[m][u];
+                    }
+                }
+                o = oo;
             }
+#pragma unroll
+            for (int m = 0; m < M; m++) FI[m * NI + i] = make_float2(acc[m].x, acc[m].y);
         }
         __syncthreads();
 
+        PROF_MARK(5);
         // ---- stash the tail of the new block for the next frame (fsk.c:851) ------------------
         for (int i = lane; i < nstash; i += 64) X[i] = X[nstash + nin - nstash + i];
 
@@ -274,24 +389,41 @@ __global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const W
                 const float2 v = FI[m * NI + i];
                 ft1 += (v.x * v.x) + (v.y * v.y);
             }
-            const float2 pf = cfg.phi_ft[i];
+            const float2 pf = pft_t[i];
             TP[i] = make_float2(ft1 * pf.x, ft1 * pf.y);
         }
         __syncthreads();
+        PROF_MARK(6);
         float tcr = 0.f, tci = 0.f;
-        if (lane == 0) {
+        {
+            // sequential float accumulation in index order (fsk.c:870): one packed add per product
+            // (re and im sums are independent chains); every lane runs the uniform loop, lane 0's value
+            // is used.  The next 8 products are loaded (128-bit LDS reads) before the current 8 are added.
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            const v4f *TP4 = (const v4f *)TP;
+            v2f acc = {0.f, 0.f};
+            v4f cur[4], nxt[4];
             int i = 0;
-            for (; i + 8 <= NI; i += 8) {
-                float2 v[8];
+            if (NI >= 8) {
 #pragma unroll
-                for (int u = 0; u < 8; u++) v[u] = TP[i + u];
+                for (int u = 0; u < 4; u++) cur[u] = TP4[u];
+                for (i = 8; i + 8 <= NI; i += 8) {
 #pragma unroll
-                for (int u = 0; u < 8; u++) { tcr = tcr + v[u].x; tci = tci + v[u].y; }
+                    for (int u = 0; u < 4; u++) nxt[u] = TP4[(i >> 1) + u];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { acc = acc + cur[u].xy; acc = acc + cur[u].zw; }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) cur[u] = nxt[u];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) { acc = acc + cur[u].xy; acc = acc + cur[u].zw; }
             }
-            for (; i < NI; i++) { const float2 v = TP[i]; tcr = tcr + v.x; tci = tci + v.y; }
+            for (; i < NI; i++) { const float2 v = TP[i]; acc = acc + (v2f){v.x, v.y}; }
+            tcr = acc.x; tci = acc.y;
         }
-        tcr = __shfl(tcr, 0, 64);
-        tci = __shfl(tci, 0, 64);
+        tcr = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(tcr)));   // lane 0's sums, as wave-uniform values
+        tci = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(tci)));
+        PROF_MARK(7);
 
         int nin_next = nin;
         float tr_mean = 0.f, tr_std = 0.f, tr_rxt = 0.f;
@@ -310,6 +442,7 @@ __global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const W
             if (norm_rx_timing > 0.25f) nin_next = N + Ts / 2;
             else if (norm_rx_timing < -0.25f) nin_next = N - Ts / 2;
             else nin_next = N;
+            nin_next = __builtin_amdgcn_readfirstlane(nin_next);
 
             // ---- resample, decide, soft decisions (fsk.c:913-993) ---------------------------
             const int low_sample = (int)floorf(rx_timing);
@@ -391,6 +524,7 @@ __global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const W
             }
         }
         __syncthreads();
+        PROF_MARK(8);
         // ---- emit the frame's outputs (fsk_demod.c:403-407): a NaN frame re-emits the previous buffer
         if (C.sd_out) {
             float *so = C.sd_out + frames * Nbits;
@@ -411,6 +545,11 @@ __global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const W
         nin = nin_next;
         frames++;
         __syncthreads();
+        PROF_MARK(9);
+    }
+    if (PROF && C.prof && lane == 0) {
+#pragma unroll
+        for (int k = 0; k < WR_PROF_PHASES; k++) C.prof[k] = prof[k];
     }
 
     // ---- save carried state ---------------------------------------------------------------
@@ -431,15 +570,22 @@ __global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const W
 }
 
 // explicit instantiations + launcher
-extern "C" hipError_t wr_launch_demod(const WrDemodCfg *cfg, const WrChan *d_chans, int nchan, hipStream_t stream) {
+extern "C" hipError_t wr_launch_demod_ex(const WrDemodCfg *cfg, const WrChan *d_chans, int nchan, hipStream_t stream, int prof) {
     if (nchan <= 0) return hipSuccess;
     dim3 grid(nchan), block(64);
-    if (cfg->M == 2) {
-        (void)hipFuncSetAttribute((const void *)wenet_demod_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, cfg->lds_bytes);
-        hipLaunchKernelGGL(wenet_demod_kernel<2>, grid, block, cfg->lds_bytes, stream, *cfg, d_chans, nchan);
-    } else {
-        (void)hipFuncSetAttribute((const void *)wenet_demod_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, cfg->lds_bytes);
-        hipLaunchKernelGGL(wenet_demod_kernel<4>, grid, block, cfg->lds_bytes, stream, *cfg, d_chans, nchan);
-    }
+#define WR_LAUNCH(MM, PP, TT)                                                                                            \
+    do {                                                                                                                   \
+        (void)hipFuncSetAttribute((const void *)wenet_demod_kernel<MM, PP, TT>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  cfg->lds_bytes);                                                                          \
+        hipLaunchKernelGGL((wenet_demod_kernel<MM, PP, TT>), grid, block, cfg->lds_bytes, stream, *cfg, d_chans, nchan);   \
+    } while (0)
+#define WR_LAUNCH_T(MM, PP) do { if (cfg->tables_in_lds) WR_LAUNCH(MM, PP, true); else WR_LAUNCH(MM, PP, false); } while (0)
+    if (cfg->M == 2) { if (prof) WR_LAUNCH_T(2, true); else WR_LAUNCH_T(2, false); }
+    else             { if (prof) WR_LAUNCH_T(4, true); else WR_LAUNCH_T(4, false); }
+#undef WR_LAUNCH_T
+#undef WR_LAUNCH
     return hipGetLastError();
+}
+extern "C" hipError_t wr_launch_demod(const WrDemodCfg *cfg, const WrChan *d_chans, int nchan, hipStream_t stream) {
+    return wr_launch_demod_ex(cfg, d_chans, nchan, stream, 0);
 }

@@ -47,6 +47,7 @@ struct WrDemodCfg {
     const float  *bin_freq;             // [Ndft/2] (float)bin*((float)Fs/(float)Ndft) (fsk.c:671)
     // LDS carve-up (bytes)
     int off_X, off_FB, off_PH, off_FI, off_FE, off_FW, off_SD, off_SC, lds_bytes;
+    int tables_in_lds, off_TW, off_HANN, off_SRC, off_PFT, off_DPHI;
     // per-channel state block layout (floats from the block start)
     int st_fft_est, st_samp_old, st_sd_last, st_floats;
 };
@@ -76,6 +77,7 @@ struct WrChan {
     float      *trace;          // WR_TRACE_FLOATS per frame (or null)
     float      *dump;           // stats snapshots (or null): every dump_period-th frame from dump_first
     long long   dump_first, dump_period, dump_cap;
+    long long  *prof;           // development: per-phase cycle totals (profiling instantiation only)
 };
 
 // ---- deframer ----

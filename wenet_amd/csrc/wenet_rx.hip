@@ -23,6 +23,7 @@
 #pragma clang fp contract(off)
 
 extern "C" hipError_t wr_launch_demod(const WrDemodCfg *cfg, const WrChan *d_chans, int nchan, hipStream_t stream);
+extern "C" hipError_t wr_launch_demod_ex(const WrDemodCfg *cfg, const WrChan *d_chans, int nchan, hipStream_t stream, int prof);
 extern "C" hipError_t wr_launch_deframe(const WrDeframeChan *d_chans, int nchan, int mode, hipStream_t stream);
 extern "C" hipError_t wr_launch_decode(const WrDecodeArgs *args, hipStream_t stream);
 
@@ -190,6 +191,18 @@ struct DemodTables {
         cfg.off_FW = o; o = align16(o + NH * 4);
         cfg.off_SD = o; o = align16(o + cfg.Nbits * 4);
         cfg.off_SC = o; o = align16(o + (4 * nsyms + 16) * 4);
+        {   // LDS copies of the configuration tables when they fit next to the working set
+            int t = o;
+            const int o_tw = t;   t = align16(t + Ndft * 8);
+            const int o_hn = t;   t = align16(t + Ndft * 4);
+            const int o_src = t;  t = align16(t + Ndft * 4);
+            const int o_pft = t;  t = align16(t + cfg.NI * 8);
+            const int o_dph = t;  t = align16(t + NH * 8);
+            if (t <= 64 * 1024) {
+                cfg.tables_in_lds = 1; cfg.off_TW = o_tw; cfg.off_HANN = o_hn; cfg.off_SRC = o_src; cfg.off_PFT = o_pft; cfg.off_DPHI = o_dph;
+                o = t;
+            }
+        }
         cfg.lds_bytes = o;
         if (o > 160 * 1024) { fprintf(stderr, "libwenet_rx: configuration needs %d bytes of LDS (>160 KiB)\n", o); return false; }
         // state block
@@ -671,7 +684,8 @@ struct wenet_rx {
     bool want_trace = false, want_llr = false;
     int nchan = 0, max_pk = 0;
     std::vector<long long> sd_off, cap_frames;           // per channel: float offset into d_sd, frame capacity
-    DevBuf d_states, d_chans, d_dchans, d_dstates, d_sd, d_starts, d_out, d_trace, d_llr, d_raw;
+    DevBuf d_states, d_chans, d_dchans, d_dstates, d_sd, d_starts, d_out, d_trace, d_llr, d_raw, d_prof;
+    bool profile = false;
     std::vector<float> h_states;
     std::vector<WrDeframeState> h_dstates;
     std::vector<WrPacketOut> h_out;
@@ -724,6 +738,8 @@ extern "C" int wenet_rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw,
         return -2;
     if (rx->want_trace && !rx->d_trace.reserve((size_t)(rx->sd_off[nchan] / c.Nbits) * WR_TRACE_FLOATS * 4)) return -2;
     if (rx->want_llr && !rx->d_llr.reserve((size_t)nchan * max_pk * WR_NCODE * 4)) return -2;
+    rx->profile = getenv("WENET_RX_PROFILE") != nullptr;
+    if (rx->profile && !rx->d_prof.reserve((size_t)nchan * 16 * 8)) return -2;
     // fresh modem + deframer state per capture
     std::vector<float> st0;
     rx->tab.init_state(st0);
@@ -741,6 +757,7 @@ extern "C" int wenet_rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw,
         ch.sd_out = rx->d_sd.as<float>() + rx->sd_off[i];
         ch.cap_frames = rx->cap_frames[i];
         ch.trace = rx->want_trace ? rx->d_trace.as<float>() + (rx->sd_off[i] / c.Nbits) * WR_TRACE_FLOATS : nullptr;
+        ch.prof = rx->profile ? rx->d_prof.as<long long>() + (size_t)i * 16 : nullptr;
         WrDeframeChan &d = dch[i];
         memset(&d, 0, sizeof(d));
         d.sd = ch.sd_out;
@@ -762,7 +779,7 @@ extern "C" int wenet_rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw,
     a.llr_out = rx->want_llr ? rx->d_llr.as<float>() : nullptr;
     fill_decode_tables(a, t);
     WR_CHECK(hipEventRecord(rx->ev[0], stream), -4);
-    WR_CHECK(wr_launch_demod(&rx->tab.cfg, rx->d_chans.as<WrChan>(), nchan, stream), -4);
+    WR_CHECK(wr_launch_demod_ex(&rx->tab.cfg, rx->d_chans.as<WrChan>(), nchan, stream, rx->profile ? 1 : 0), -4);
     WR_CHECK(hipEventRecord(rx->ev[1], stream), -4);
     WR_CHECK(wr_launch_deframe(rx->d_dchans.as<WrDeframeChan>(), nchan, rx->mode, stream), -4);
     WR_CHECK(hipEventRecord(rx->ev[2], stream), -4);
@@ -861,6 +878,14 @@ extern "C" float wenet_rx_last_ms(wenet_rx *rx, int what) {
     float ms = 0.f;
     hipError_t e = (what == 3) ? hipEventElapsedTime(&ms, rx->ev[0], rx->ev[3]) : hipEventElapsedTime(&ms, rx->ev[what], rx->ev[what + 1]);
     return e == hipSuccess ? ms : -1.f;
+}
+
+// development aid (not in the public header): per-phase cycle totals of channel ch from the last
+// enqueue when WENET_RX_PROFILE was set; returns the number of counters
+extern "C" int wenet_rx_debug_profile(wenet_rx *rx, int ch, long long *out12) {
+    if (!rx || !rx->profile || ch < 0 || ch >= rx->nchan) return 0;
+    if (hipMemcpy(out12, rx->d_prof.as<long long>() + (size_t)ch * 16, 12 * 8, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return 12;
 }
 
 extern "C" int wenet_rx_device_info(int what) {

@@ -211,3 +211,48 @@ def make_capture(cfg: ModemConfig, n_packets: int, ebno_db: float, seed: int,
     else:
         raise ValueError(fmt)
     return raw, payloads
+
+
+# ---------------------------------------------------------------------------------------------
+# GPU-side generation of large batches (benchmarks): same signal model, torch ops on the device.
+# torch is used here only to fill HBM with synthetic captures; it is not part of the receive path.
+# ---------------------------------------------------------------------------------------------
+def air_symbols(cfg: ModemConfig, n_symbols: int, seed: int):
+    """Symbol stream (uint8 tone indices) of back-to-back frames with random payloads."""
+    rng = np.random.default_rng(seed)
+    spf = cfg.symbols_per_frame
+    nfr = n_symbols // spf + 1
+    payloads = [rng.integers(0, 256, PAYLOAD_BYTES, dtype=np.uint8).tobytes() for _ in range(nfr)]
+    bits = np.concatenate([bytes_to_air_bits(frame_packet(p, cfg.mode), cfg.mode) for p in payloads])
+    if cfg.M == 4:
+        b = bits[: (bits.size // 2) * 2].reshape(-1, 2)
+        sym = ((b[:, 0] << 1) | b[:, 1]).astype(np.uint8)
+    else:
+        sym = bits.astype(np.uint8)
+    return sym[:n_symbols], payloads
+
+
+def make_capture_torch(cfg: ModemConfig, sym: np.ndarray, ebno_db: float, seed: int, device="cuda"):
+    """cu8 capture on the GPU for the given symbol stream; returns a torch.uint8 tensor [2*nsamples]."""
+    import torch
+
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    s = torch.from_numpy(sym.astype(np.int64)).to(device)
+    f = cfg.f_low + cfg.f_space * s.to(torch.float64)
+    f = f.repeat_interleave(cfg.Ts)
+    ph = torch.cumsum(f, 0) * (2.0 * np.pi / cfg.Fs)
+    ph = torch.remainder(ph, 2.0 * np.pi).to(torch.float32)
+    del f
+    bps = 1.0 if cfg.M == 2 else 2.0
+    nv = 1.0 * cfg.Fs / (cfg.Rs * (10.0 ** (ebno_db / 10.0)) * bps)        # var(x) == 1 for a unit phasor
+    sg = float(np.sqrt(nv / 2.0))
+    n = ph.numel()
+    xr = torch.cos(ph) + sg * torch.randn(n, device=device, generator=g)
+    xi = torch.sin(ph) + sg * torch.randn(n, device=device, generator=g)
+    del ph
+    mx = torch.sqrt(torch.max(xr * xr + xi * xi))
+    out = torch.empty(2 * n, dtype=torch.uint8, device=device)
+    out[0::2] = (xr / mx * 127.5 + 128.0).to(torch.uint8)
+    out[1::2] = (xi / mx * 127.5 + 128.0).to(torch.uint8)
+    return out
