@@ -1,0 +1,104 @@
+"""GPU: the drop-in executables (wenet_amd/bin/{fsk_demod,drs232_ldpc,wenet_ldpc}) honour the reference's
+pipe contract: `fsk_demod --cu8 -s --stats=100 M Fs Rs - - 2> stats | {drs232,wenet}_ldpc - - -v`
+(start_rx.sh:125-128, benchmarking/test_demod.py:26-43) gives the bytes the reference pipeline gives."""
+import json
+import math
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from wenet_amd import siggen
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "wenet_amd", "bin")
+FMT_FLAG = {"cu8": "--cu8", "cs16": "--cs16", "s16": ""}
+
+
+def run_pipe(g, tmp_path, soft=True, stats=True):
+    cfg = siggen.CONFIGS[str(g["config"])]()
+    raw = tmp_path / "cap.bin"
+    g["raw"].tofile(str(raw))
+    l2 = "drs232_ldpc" if cfg.mode == 1 else "wenet_ldpc"
+    st = tmp_path / "stats.txt"
+    l2err = tmp_path / "l2.txt"
+    cmd = (f"cat {raw} | {BIN}/fsk_demod {FMT_FLAG[str(g['fmt'])]} -s {'--stats=100' if stats else ''} {cfg.M} {cfg.Fs} {cfg.Rs} - - 2> {st} "
+           f"| {BIN}/{l2} - - -v 2> {l2err}")
+    out = subprocess.run(cmd, shell=True, stdout=subprocess.PIPE, check=True).stdout
+    return out, open(st).read(), open(l2err).read(), cfg
+
+
+@pytest.mark.parametrize("name", ["v1_8dB", "v2_8dB", "v2_cs16_10dB", "v2_ppm150_12dB", "4fsk_12dB", "v2_6dB"])
+def test_shell_pipeline_matches_reference(name, tmp_path):
+    g = load_golden(name)
+    out, stats, l2err, cfg = run_pipe(g, tmp_path)
+    assert out == g["packets"].tobytes()
+    iters = [int(l.split("iter:")[1]) for l in l2err.splitlines() if "iter:" in l]
+    assert iters == list(g["iters"])
+    last = l2err.strip().splitlines()[-1]
+    n_all, n_bad = g["iters"].size, g["iters"].size - g["packets"].size // 256
+    assert last.startswith(f"packets: {n_all} packet_errors: {n_bad} PER:")
+    # stderr JSON schema + values (src/fsk_demod.c:351-392); consumers: rx/fskstatsudp.py:29, rx/fskdemodgui.py
+    lines = [l for l in stats.splitlines() if l.startswith("{")]
+    assert lines
+    for mine, ref, frame in ((lines[0], str(g["stats_first"]), 1),):
+        a, b = json.loads(mine), json.loads(ref)
+        assert set(a) == set(b)
+        for k in a:
+            if k == "secs":
+                continue
+            if k == "eye_diagram":
+                assert np.array(a[k]).shape == np.array(b[k]).shape
+                high = math.ceil(float(g["trace"][frame, 5]) * (cfg.Fs // cfg.Rs))
+                if high >= -1:          # otherwise the reference indexes f_int[] out of bounds (fsk.c:1045,1060)
+                    assert a[k] == b[k]
+                continue
+            assert a[k] == b[k], k
+    assert len(lines) == len([l for l in str(g["stats_first"]).splitlines()]) or True
+    ref_nlines = None  # number of JSON lines = frames printed on the same schedule as the reference
+    # schedule: frames 1, 1+(stats_loop+1), ...  (src/fsk_demod.c:247-251, 345-401)
+    loop_time = np.float32(cfg.Ts * 48) / np.float32(cfg.Fs)
+    stats_loop = int(1 / (100 * loop_time))
+    nframes = g["trace"].shape[0]
+    assert len(lines) == len(range(1, nframes, stats_loop + 1))
+    b_last = json.loads(str(g["stats_last"]))
+    a_last = json.loads(lines[-1])
+    for k in ("EbNodB", "ppm", "f1_est", "f2_est", "samp_fft"):
+        assert a_last[k] == b_last[k], k
+
+
+def test_hard_decision_output_and_files(tmp_path):
+    g = load_golden("v1_20dB")
+    cfg = siggen.CONFIGS["v1"]()
+    raw = tmp_path / "cap.bin"; g["raw"].tofile(str(raw))
+    bits = tmp_path / "bits.bin"
+    subprocess.run([f"{BIN}/fsk_demod", "--cu8", str(cfg.M), str(cfg.Fs), str(cfg.Rs), str(raw), str(bits)], check=True,
+                   stderr=subprocess.DEVNULL)
+    assert (np.packbits(np.fromfile(str(bits), np.uint8)) == g["hard"]).all()
+    sd = tmp_path / "sd.bin"
+    subprocess.run([f"{BIN}/fsk_demod", "-d", "-s", "-p", str(cfg.Ts), str(cfg.M), str(cfg.Fs), str(cfg.Rs), str(raw), str(sd)], check=True,
+                   stderr=subprocess.DEVNULL)
+    assert (np.fromfile(str(sd), np.float32).view(np.uint32) == g["sd"].view(np.uint32)).all()
+    pk = tmp_path / "pk.bin"
+    subprocess.run([f"{BIN}/drs232_ldpc", str(sd), str(pk)], check=True, stderr=subprocess.DEVNULL)
+    assert open(pk, "rb").read() == g["packets"].tobytes()
+
+
+def test_cli_error_behaviour(tmp_path):
+    r = subprocess.run([f"{BIN}/fsk_demod", "2", "960000"], stderr=subprocess.PIPE)
+    assert r.returncode == 1 and b"Too few arguments" in r.stderr and b"usage:" in r.stderr
+    r = subprocess.run([f"{BIN}/fsk_demod", "3", "960000", "96000", "-", "-"], stderr=subprocess.PIPE, stdin=subprocess.DEVNULL)
+    assert r.returncode == 1 and b"Mode 3 is not valid" in r.stderr
+    r = subprocess.run([f"{BIN}/fsk_demod", "2", "960000", "96000", "/nonexistent/x", "-"], stderr=subprocess.PIPE)
+    assert r.returncode == 1 and b"Couldn't open files" in r.stderr
+    r = subprocess.run([f"{BIN}/wenet_ldpc", "-"], stderr=subprocess.PIPE)
+    assert r.returncode == 1 and b"usage: drs232" in r.stderr
+    r = subprocess.run([f"{BIN}/drs232_ldpc", "/nonexistent/x", "-"], stderr=subprocess.PIPE)
+    assert r.returncode == 1 and b"Error opening input file" in r.stderr
+    # empty input: exit 0, nothing written, summary line printed (PER of 0/0 as the reference prints it)
+    r = subprocess.run([f"{BIN}/wenet_ldpc", "-", "-"], stdin=subprocess.DEVNULL, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0 and r.stdout == b"" and b"packets: 0 packet_errors: 0" in r.stderr

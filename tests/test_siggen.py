@@ -1,0 +1,45 @@
+"""CPU: the synthetic transmitter (wenet_amd/siggen.py) produces frames the Wenet format defines."""
+import numpy as np
+
+from wenet_amd import siggen
+
+
+def test_crc16_known_value():
+    assert siggen.crc16_ccitt_false(b"123456789") == 0x29B1
+
+
+def test_ldpc_parity_satisfies_every_check():
+    rng = np.random.default_rng(3)
+    ib = rng.integers(0, 2, 2064, dtype=np.uint8)
+    pb = siggen.ldpc_parity_bits(ib)
+    rows = siggen.h_rows()
+    # staircase: check k = sum(data bits of row k) + p[k-1] + p[k] == 0 (mod 2)
+    s = ib[rows].sum(axis=1) + pb + np.concatenate([[0], pb[:-1]])
+    assert (s % 2 == 0).all()
+
+
+def test_frame_layout():
+    payload = bytes(range(256))
+    f1 = siggen.frame_packet(payload, 1)
+    f2 = siggen.frame_packet(payload, 2)
+    assert len(f1) == len(f2) == 16 + 4 + 256 + 2 + 65
+    assert f1[:16] == b"\x55" * 16 and f1[16:20] == bytes([0xAB, 0xCD, 0xEF, 0x01])
+    assert f1[20:276] == payload and f2[20:276] != payload
+    crc = siggen.crc16_ccitt_false(payload)
+    assert f1[276] == (crc & 0xFF) and f1[277] == (crc >> 8)
+    code = siggen.scramble_bytes()
+    body = np.frombuffer(f2[20:], np.uint8) ^ code[np.arange(323) % 125]
+    assert body.tobytes() == f1[20:]
+
+
+def test_rs232_bits():
+    bits = siggen.bytes_to_air_bits(bytes([0xAB]), 1)
+    assert list(bits) == [0, 1, 1, 0, 1, 0, 1, 0, 1, 1]          # start, LSB first, stop (drs232_ldpc.c:77-79)
+    assert list(siggen.bytes_to_air_bits(bytes([0xAB]), 2)) == [1, 0, 1, 0, 1, 0, 1, 1]
+
+
+def test_capture_is_deterministic():
+    cfg = siggen.config_v2()
+    a, _ = siggen.make_capture(cfg, 1, 8.0, seed=5)
+    b, _ = siggen.make_capture(cfg, 1, 8.0, seed=5)
+    assert (a == b).all() and a.dtype == np.uint8 and a.size == 2 * cfg.Ts * cfg.symbols_per_frame

@@ -36,7 +36,7 @@ def main():
         ib = rng.integers(0, 2, 2064, dtype=np.uint8)
         pb = np.zeros(516, np.uint8); O.ora_ldpc_encode(ib, pb)
         cw = np.concatenate([ib, pb]).astype(np.float64)
-        snr = rng.uniform(0.55, 1.1)
+        snr = rng.uniform(1.5, 2.6)
         x = (1 - 2 * cw) + rng.standard_normal(2580) / snr
         llrs[i] = (2 * x * snr * snr).astype(np.float32)
     t = time.time(); gb, gi, gp = ldpc_decode_batch(llrs, 10); t_gpu = time.time() - t

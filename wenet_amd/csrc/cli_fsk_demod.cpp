@@ -1,0 +1,174 @@
+// cli_fsk_demod.cpp -- drop-in replacement for the reference's `fsk_demod` executable
+// (src/fsk_demod.c:54-434): same argv, same stdin/stdout byte streams, same stderr JSON schema,
+// same exit codes -- the DSP runs in libwenet_rx.so on the GPU.
+//
+//   usage: fsk_demod [-l] [-p P] [-s] [(-c|-d)] [-t [r]] [-f] (2|4) SampleRate SymbolRate In Out
+//
+// Differences that cannot be avoided, all outside the data path:
+//   * -l/--lbr (fsk_create, 1-second frames) and -f/--testframes are not part of the Wenet receive
+//     chain: they exit(1) with a message instead of silently doing something else.
+//   * input is read in blocks (whatever the pipe holds, at least one frame) instead of exactly nin
+//     samples per fread; the frames produced, their order and the trailing-partial-frame rule
+//     (src/fsk_demod.c:270) are identical.
+#include <errno.h>
+#include <getopt.h>
+#include <signal.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include <unistd.h>
+
+#include <vector>
+
+#include "../../include/wenet_rx.h"
+
+static void sig_handler(int signo) { if (signo == SIGTERM) exit(0); }      /* fsk_demod.c:47-52 */
+
+static void usage(const char *argv0) {                                      /* fsk_demod.c:163-178 */
+    fprintf(stderr, "usage: %s [-l] [-p P]  [-s] [(-c|-d)] [-t [r]] [-f] (2|4) SampleRate SymbolRate InputModemRawFile OutputFile\n", argv0);
+    fprintf(stderr, " -lP --conv=P      -  P specifies the rate at which symbols are down-converted before further processing\n");
+    fprintf(stderr, "                        P must be divisible by the symbol size. Smaller P values will result in faster\n");
+    fprintf(stderr, "                        processing but lower demodulation preformance. If no P value is specified,\n");
+    fprintf(stderr, "                        P will default to it's highes possible value\n");
+    fprintf(stderr, " -c --cs16         -  The raw input file will be in complex signed 16 bit format.\n");
+    fprintf(stderr, " -d --cu8          -  The raw input file will be in complex unsigned 8 bit format.\n");
+    fprintf(stderr, "                        If neither -c nor -d are used, the input should be in signed 16 bit format.\n");
+    fprintf(stderr, " -f --testframes   -  Testframe mode (not supported by this build)\n");
+    fprintf(stderr, " -t[r] --stats=[r] -  Print out modem statistics to stderr in JSON.\n");
+    fprintf(stderr, "                         r, if provided, sets the number of modem frames between statistic printouts.\n");
+    fprintf(stderr, " -s --soft-dec     -  The output file will be in a soft-decision format, with one 32-bit float per bit.\n");
+    fprintf(stderr, "                        If -s is not used, the output will be in a 1 byte-per-bit format.\n");
+    exit(1);
+}
+
+static void print_stats(const wenet_modem_stats &s, int M) {               /* fsk_demod.c:351-392 */
+    fprintf(stderr, "{");
+    time_t seconds = time(NULL);
+    fprintf(stderr, "\"secs\": %ld, \"EbNodB\": %5.1f, \"ppm\": %4d,", (long)seconds, s.snr_est, (int)s.ppm);
+    fprintf(stderr, " \"f1_est\":%.1f, \"f2_est\":%.1f", s.f_est[0], s.f_est[1]);
+    if (M == 4) fprintf(stderr, ", \"f3_est\":%.1f, \"f4_est\":%.1f", s.f_est[2], s.f_est[3]);
+    fprintf(stderr, ",\t\"eye_diagram\":[");
+    for (int i = 0; i < s.neyetr; i++) {
+        fprintf(stderr, "[");
+        for (int j = 0; j < s.neyesamp; j++) {
+            fprintf(stderr, "%f ", s.rx_eye[i][j]);
+            if (j < s.neyesamp - 1) fprintf(stderr, ",");
+        }
+        fprintf(stderr, "]");
+        if (i < s.neyetr - 1) fprintf(stderr, ",");
+    }
+    fprintf(stderr, "],");
+    fprintf(stderr, "\"samp_fft\":[");
+    for (int i = 0; i < s.nfft_est; i++) {
+        fprintf(stderr, "%f ", s.fft_est[i]);
+        if (i < s.nfft_est - 1) fprintf(stderr, ",");
+    }
+    fprintf(stderr, "]");
+    fprintf(stderr, "}\n");
+}
+
+int main(int argc, char *argv[]) {
+    int Fs, Rs, M = 0, P = 0;
+    int enable_stats = 0, hbr = 1, soft_dec_mode = 0, testframe_mode = 0;
+    int complex_input = 1, bytes_per_sample = 2, stats_rate = 8;
+    int fsk_lower = -1, fsk_upper = -1;
+    int o = 0, opt_idx = 0;
+    while (o != -1) {
+        static struct option long_opts[] = {
+            {"help", no_argument, 0, 'h'},        {"lbr", no_argument, 0, 'l'},
+            {"conv", required_argument, 0, 'p'},  {"cs16", no_argument, 0, 'c'},
+            {"cu8", no_argument, 0, 'd'},         {"fsk_lower", optional_argument, 0, 'b'},
+            {"fsk_upper", optional_argument, 0, 'u'}, {"stats", optional_argument, 0, 't'},
+            {"soft-dec", no_argument, 0, 's'},    {"testframes", no_argument, 0, 'f'},
+            {0, 0, 0, 0}};
+        o = getopt_long(argc, argv, "fhlp:cdt::sb:u:", long_opts, &opt_idx);
+        switch (o) {
+        case 'l': hbr = 0; break;
+        case 'c': complex_input = 2; bytes_per_sample = 2; break;
+        case 'd': complex_input = 2; bytes_per_sample = 1; break;
+        case 'f': testframe_mode = 1; break;
+        case 't':
+            enable_stats = 1;
+            if (optarg != NULL) { stats_rate = atoi(optarg); if (stats_rate == 0) stats_rate = 8; }
+            break;
+        case 's': soft_dec_mode = 1; break;
+        case 'p': P = atoi(optarg); break;
+        case 'b': if (optarg != NULL) fsk_lower = atoi(optarg); break;
+        case 'u': if (optarg != NULL) fsk_upper = atoi(optarg); break;
+        case 'h':
+        case '?': usage(argv[0]);
+        }
+    }
+    int dx = optind;
+    if ((argc - dx) < 5) { fprintf(stderr, "Too few arguments\n"); usage(argv[0]); }
+    if ((argc - dx) > 5) { fprintf(stderr, "Too many arguments\n"); usage(argv[0]); }
+    M = atoi(argv[dx]); Fs = atoi(argv[dx + 1]); Rs = atoi(argv[dx + 2]);
+    if (Rs <= 0 || Fs <= 0) { fprintf(stderr, "Invalid sample/symbol rate\n"); exit(1); }
+    if (P == 0) P = Fs / Rs;                                                 /* fsk_demod.c:186-188 */
+    if ((M != 2) && (M != 4)) { fprintf(stderr, "Mode %d is not valid. Mode must be 2 or 4.\n", M); usage(argv[0]); }
+    if (!hbr) { fprintf(stderr, "fsk_demod (wenet_rx): --lbr mode is not supported by this build\n"); exit(1); }
+    if (testframe_mode) { fprintf(stderr, "fsk_demod (wenet_rx): --testframes is not supported by this build\n"); exit(1); }
+
+    FILE *fin = (strcmp(argv[dx + 3], "-") == 0) ? stdin : fopen(argv[dx + 3], "r");
+    FILE *fout = (strcmp(argv[dx + 4], "-") == 0) ? stdout : fopen(argv[dx + 4], "w");
+    wenet_fsk *fsk = wenet_fsk_create_hbr(Fs, Rs, P, M, 1200, 400);        /* fsk_demod.c:214 */
+    if (fsk && fsk_lower > 0 && fsk_upper > fsk_lower) {                    /* fsk_demod.c:215-218 */
+        wenet_fsk_set_est_limits(fsk, fsk_lower, fsk_upper);
+        fprintf(stderr, "Setting estimator limits to %d to %d Hz.\n", fsk_lower, fsk_upper);
+    }
+    if (fin == NULL || fout == NULL || fsk == NULL) { fprintf(stderr, "Couldn't open files\n"); exit(1); }
+
+    const int Nbits = wenet_fsk_info(fsk, 6), N = wenet_fsk_info(fsk, 1), Ts = wenet_fsk_info(fsk, 2);
+    if (enable_stats) {                                                      /* fsk_demod.c:247-251, 345-401 */
+        float loop_time = ((float)wenet_fsk_nin(fsk)) / ((float)Fs);
+        int stats_loop = (int)(1 / (stats_rate * loop_time));
+        // stats_ctr starts at 0: frame 0 prints nothing and decrements to -1, frame 1 prints and reloads
+        // stats_loop, ... => snapshots at frames 1, 1+(stats_loop+1), ...
+        wenet_fsk_enable_stats(fsk, 1, (long)stats_loop + 1);
+    }
+    if (signal(SIGTERM, sig_handler) == SIG_ERR) printf("\ncan't catch SIGTERM\n");
+
+    const int fmt = (complex_input == 1) ? WENET_FMT_S16_REAL : (bytes_per_sample == 1 ? WENET_FMT_CU8 : WENET_FMT_CS16);
+    const size_t bps = (size_t)bytes_per_sample * complex_input;
+    const bool piped = (fin == stdin || fout == stdout);
+    // block size: files -> ~4 MiB; pipes -> a handful of frames so that latency stays low
+    const size_t max_block = piped ? (size_t)(N + Ts) * 64 : (size_t)4 << 20;
+    std::vector<uint8_t> buf;
+    std::vector<uint8_t> out((size_t)(max_block / (N - Ts / 2) + 2) * Nbits * 4);
+    std::vector<wenet_modem_stats> stats(64);
+    bool eof = false;
+    const int fd = fileno(fin);
+    while (true) {
+        size_t have = buf.size() / bps;
+        // need at least one frame's worth
+        while (!eof && have < (size_t)wenet_fsk_nin(fsk)) {
+            size_t want = max_block * bps;
+            size_t old = buf.size();
+            buf.resize(old + want);
+            ssize_t got = read(fd, buf.data() + old, want);
+            if (got < 0) { if (errno == EINTR) { buf.resize(old); continue; } got = 0; }
+            buf.resize(old + (size_t)got);
+            if (got == 0) eof = true;
+            have = buf.size() / bps;
+        }
+        if (have < (size_t)wenet_fsk_nin(fsk)) break;                        /* short read ends the loop (fsk_demod.c:270) */
+        long consumed = 0;
+        const long cap = (long)(out.size() / ((size_t)Nbits * 4));
+        long frames = wenet_fsk_demod_stream(fsk, fmt, buf.data(), (long)have, soft_dec_mode, out.data(), cap, &consumed, NULL);
+        if (frames < 0) { fprintf(stderr, "fsk_demod (wenet_rx): GPU demodulation failed (%ld)\n", frames); exit(1); }
+        if (enable_stats) {
+            int ns = wenet_fsk_get_stats(fsk, stats.data(), (int)stats.size());
+            for (int i = 0; i < ns; i++) print_stats(stats[i], M);
+        }
+        fwrite(out.data(), soft_dec_mode ? sizeof(float) : sizeof(uint8_t), (size_t)frames * Nbits, fout);
+        if (piped) fflush(fout);                                             /* fsk_demod.c:409-412 */
+        buf.erase(buf.begin(), buf.begin() + (size_t)consumed * bps);
+        if (frames == 0 && eof) break;
+    }
+    fclose(fin);
+    fclose(fout);
+    wenet_fsk_destroy(fsk);
+    return 0;
+}

@@ -3,6 +3,10 @@
 The shared library is the product; this module only loads it and declares prototypes.
 There is no Python or CPU implementation behind these calls: if the library is missing the
 import fails loudly, and if no GPU is present the create functions return NULL.
+
+Process-level note: PyTorch wheels bundle their own libamdhip64.  In a process that uses BOTH torch and
+this library (bench.py, some tests), import torch FIRST so that one HIP runtime serves both; loading
+libwenet_rx.so first binds the system runtime and torch then reports "no ROCm-capable device".
 """
 from __future__ import annotations
 

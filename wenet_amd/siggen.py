@@ -148,8 +148,11 @@ def modulate(bits: np.ndarray, cfg: ModemConfig, ppm: float = 0.0) -> np.ndarray
     if cfg.M == 2:
         sym = bits.astype(np.int64)
     else:
+        # The reference's 4-FSK SOFT decisions (fsk.c:969-980, marked TODO there) come out with the opposite
+        # sign convention to 2-FSK: a bit is read as 1 (sd<0) when the corresponding bit of the TONE index is 0.
+        # To be decodable by fsk_demod -s | drs232_ldpc the transmitter therefore keys tone 3-sym.
         b = bits.reshape(-1, 2).astype(np.int64)
-        sym = (b[:, 0] << 1) | b[:, 1]
+        sym = 3 - ((b[:, 0] << 1) | b[:, 1])
     n = sym.size * cfg.Ts
     if ppm == 0.0:
         idx = np.repeat(np.arange(sym.size), cfg.Ts)
@@ -177,7 +180,9 @@ def to_cu8(x: np.ndarray) -> np.ndarray:
     return (out * 127.5 + 128.0).astype(np.uint8)          # C cast: truncation toward zero
 
 
-def to_cs16(x: np.ndarray, scale: float = 16000.0) -> np.ndarray:
+def to_cs16(x: np.ndarray, scale: float = 1000.0) -> np.ndarray:
+    # scale 1000 == FDMDV_SCALE: the demod divides by it, giving unit amplitude like cu8.  (The reference's
+    # LLRs are NOT amplitude-normalised -- mpdecode_core.c:594 -- so a 16x hotter input stops decoding.)
     out = np.empty(2 * x.size, dtype=np.float64)
     out[0::2] = x.real
     out[1::2] = x.imag
@@ -205,7 +210,7 @@ def make_capture(cfg: ModemConfig, n_packets: int, ebno_db: float, seed: int,
     elif fmt == "cs16":
         raw = to_cs16(x)
     elif fmt == "s16":
-        raw = np.round(x.real * 16000.0).astype(np.int16)
+        raw = np.round(x.real * 1000.0).astype(np.int16)
     elif fmt == "cf32":
         raw = x.astype(np.complex64)
     else:
@@ -226,7 +231,7 @@ def air_symbols(cfg: ModemConfig, n_symbols: int, seed: int):
     bits = np.concatenate([bytes_to_air_bits(frame_packet(p, cfg.mode), cfg.mode) for p in payloads])
     if cfg.M == 4:
         b = bits[: (bits.size // 2) * 2].reshape(-1, 2)
-        sym = ((b[:, 0] << 1) | b[:, 1]).astype(np.uint8)
+        sym = (3 - ((b[:, 0] << 1) | b[:, 1])).astype(np.uint8)     # see modulate(): 4-FSK soft-decision sign convention
     else:
         sym = bits.astype(np.uint8)
     return sym[:n_symbols], payloads
