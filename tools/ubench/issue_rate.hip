@@ -1,0 +1,76 @@
+// development micro-benchmark: VALU issue interval for one wave and for several waves per SIMD
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <vector>
+#pragma clang fp contract(off)
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+template <int MODE>
+__global__ void k(float *out, long long *cyc, int iters) {
+    float a = threadIdx.x * 1e-3f + 1.0f, b = 1.0001f, c = 0.5f, d = 0.25f, e = 2.f, f = 3.f, g = 4.f, h = 5.f;
+    v2f p = {a, b}, q = {1.0001f, 0.9999f};
+    long long t0 = __builtin_readcyclecounter();
+    for (int i = 0; i < iters; i++) {
+        if (MODE == 0) {          // 8 dependent v_add_f32
+            asm volatile("v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1\n"
+                         "v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1" : "+v"(a) : "v"(b));
+        } else if (MODE == 1) {   // 8 independent v_add_f32
+            asm volatile("v_add_f32 %0, %0, %8\n v_add_f32 %1, %1, %8\n v_add_f32 %2, %2, %8\n v_add_f32 %3, %3, %8\n"
+                         "v_add_f32 %4, %4, %8\n v_add_f32 %5, %5, %8\n v_add_f32 %6, %6, %8\n v_add_f32 %7, %7, %8"
+                         : "+v"(a), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(p.x) : "v"(b));
+        } else if (MODE == 2) {   // 8 dependent v_pk_add_f32
+            asm volatile("v_pk_add_f32 %0, %0, %1\n v_pk_add_f32 %0, %0, %1\n v_pk_add_f32 %0, %0, %1\n v_pk_add_f32 %0, %0, %1\n"
+                         "v_pk_add_f32 %0, %0, %1\n v_pk_add_f32 %0, %0, %1\n v_pk_add_f32 %0, %0, %1\n v_pk_add_f32 %0, %0, %1" : "+v"(p) : "v"(q));
+        } else if (MODE == 3) {   // complex multiply chain, packed (2 mul + nop + add), x4
+            v2f t1, t2;
+            for (int u = 0; u < 4; u++)
+                asm volatile("v_pk_mul_f32 %1, %0, %3 op_sel_hi:[1,0]\n v_pk_mul_f32 %2, %0, %3 op_sel:[1,1] op_sel_hi:[0,1]\n s_nop 0\n"
+                             "v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "+v"(p), "=&v"(t1), "=&v"(t2) : "v"(q));
+        } else if (MODE == 4) {   // complex multiply chain, scalar f32 (4 mul + sub + add), x4
+            float t1, t2, t3, t4;
+            for (int u = 0; u < 4; u++)
+                asm volatile("v_mul_f32 %2, %0, %6\n v_mul_f32 %3, %1, %7\n v_mul_f32 %4, %0, %7\n v_mul_f32 %5, %1, %6\n"
+                             "v_sub_f32 %0, %2, %3\n v_add_f32 %1, %4, %5" : "+v"(a), "+v"(c), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4) : "v"(q.x), "v"(q.y));
+        } else if (MODE == 5) {   // 8 dependent ds_read (LDS latency)
+            __shared__ int lds[256];
+            if (i == 0) { lds[threadIdx.x & 255] = (threadIdx.x * 7 + 1) & 255; __syncthreads(); }
+            int idx = threadIdx.x & 255;
+            for (int u = 0; u < 8; u++) idx = lds[idx];
+            a += idx;
+        } else if (MODE == 6) {   // packed cmul without the nop
+            v2f t1, t2;
+            for (int u = 0; u < 4; u++)
+                asm volatile("v_pk_mul_f32 %1, %0, %3 op_sel_hi:[1,0]\n v_pk_mul_f32 %2, %0, %3 op_sel:[1,1] op_sel_hi:[0,1]\n"
+                             "v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "+v"(p), "=&v"(t1), "=&v"(t2) : "v"(q));
+        }
+    }
+    long long t1 = __builtin_readcyclecounter();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a + c + d + e + f + g + h + p.x + p.y;
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+template <int MODE> void run(const char *name, int ops_per_iter) {
+    float *out; long long *cyc;
+    hipMalloc(&out, 4 * 1024 * 1024); hipMalloc(&cyc, 8 * 4096);
+    const int iters = 20000;
+    for (int waves : {1, 2, 4, 8, 16}) {       // waves per block (block = one CU here: 1 block)
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        hipLaunchKernelGGL(k<MODE>, dim3(1), dim3(64 * waves), 0, 0, out, cyc, 100);
+        hipEventRecord(e0); hipLaunchKernelGGL(k<MODE>, dim3(1), dim3(64 * waves), 0, 0, out, cyc, iters); hipEventRecord(e1);
+        hipDeviceSynchronize();
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
+        printf("%-28s waves/CU %2d: %6.2f ticks/op (wave0)  %7.2f ns/op/wave  aggregate %7.1f Mops/s\n", name, waves,
+               (double)c / iters / ops_per_iter, ms * 1e6 / iters / ops_per_iter, (double)waves * iters * ops_per_iter / (ms * 1e3));
+    }
+}
+int main() {
+    run<0>("dep v_add_f32", 8);
+    run<1>("indep v_add_f32", 8);
+    run<2>("dep v_pk_add_f32", 8);
+    run<3>("cmul packed+nop (per step)", 4);
+    run<6>("cmul packed no nop", 4);
+    run<4>("cmul scalar (per step)", 4);
+    run<5>("dep ds_read_b32", 8);
+    return 0;
+}

@@ -29,6 +29,13 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b) {   // comp_prim.h:57
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait
+// for the global loads of the NEXT frame's samples that are deliberately left in flight (and for the
+// soft-decision stores of the previous frame).
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // one sample of the channel's raw input -> COMP (fsk_demod.c:273-296)
 __device__ __forceinline__ float2 load_sample(const void *raw, int fmt, long long idx) {
     if (fmt == WR_FMT_CU8) {
@@ -78,6 +85,46 @@ __device__ __forceinline__ v2f cmul_pk(v2f a, v2f b) {
     r.x = rx; r.y = ry;
 #endif
     return r;
+}
+
+// raw (unconverted) sample fetch + later conversion: keeps the global loads of the next frame in flight
+// (a load whose first use is the int->float conversion would be waited for on the spot)
+#define WR_GLOBAL __attribute__((address_space(1)))
+__device__ __forceinline__ uint2 load_raw(const void *raw, int fmt, long long idx) {
+    uint2 r = make_uint2(0u, 0u);
+    if (fmt == WR_FMT_CU8 || fmt == WR_FMT_S16_REAL) r.x = ((const WR_GLOBAL unsigned short *)(uintptr_t)raw)[idx];
+    else if (fmt == WR_FMT_CS16) r.x = ((const WR_GLOBAL unsigned int *)(uintptr_t)raw)[idx];
+    else { const unsigned long long v = ((const WR_GLOBAL unsigned long long *)(uintptr_t)raw)[idx]; r.x = (unsigned)v; r.y = (unsigned)(v >> 32); }
+    return r;
+}
+// KPRE raw samples per lane (sample index base + lane + 64k, clamped to `last`): the format switch is
+// hoisted so that each arm is KPRE back-to-back loads with nothing waiting on them
+template <int KPRE>
+__device__ __forceinline__ void prefetch_raw(uint2 (&pre)[KPRE], const void *raw, int fmt, long long base, long long last, int lane) {
+    long long idx[KPRE];
+#pragma unroll
+    for (int k = 0; k < KPRE; k++) { const long long i = base + lane + 64 * k; idx[k] = i < last ? i : last; }
+    if (fmt == WR_FMT_CU8 || fmt == WR_FMT_S16_REAL) {
+        const WR_GLOBAL unsigned short *p = (const WR_GLOBAL unsigned short *)(uintptr_t)raw;
+#pragma unroll
+        for (int k = 0; k < KPRE; k++) pre[k].x = p[idx[k]];
+    } else if (fmt == WR_FMT_CS16) {
+        const WR_GLOBAL unsigned int *p = (const WR_GLOBAL unsigned int *)(uintptr_t)raw;
+#pragma unroll
+        for (int k = 0; k < KPRE; k++) pre[k].x = p[idx[k]];
+    } else {
+        const WR_GLOBAL unsigned long long *p = (const WR_GLOBAL unsigned long long *)(uintptr_t)raw;
+#pragma unroll
+        for (int k = 0; k < KPRE; k++) { const unsigned long long v = p[idx[k]]; pre[k].x = (unsigned)v; pre[k].y = (unsigned)(v >> 32); }
+    }
+}
+__device__ __forceinline__ float2 convert_raw(uint2 r, int fmt) {       // fsk_demod.c:273-296
+    if (fmt == WR_FMT_CU8)
+        return make_float2(((float)(r.x & 0xffu) - 127.0f) / 128.0f, ((float)((r.x >> 8) & 0xffu) - 127.0f) / 128.0f);
+    if (fmt == WR_FMT_CS16)
+        return make_float2((float)(short)(r.x & 0xffffu) / 1000.0f, (float)(short)(r.x >> 16) / 1000.0f);
+    if (fmt == WR_FMT_S16_REAL) return make_float2((float)(short)(r.x & 0xffffu) / 1000.0f, 0.0f);
+    return make_float2(__uint_as_float(r.x), __uint_as_float(r.y));
 }
 
 struct BestBin { float v; int i; };
@@ -155,17 +202,11 @@ __global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const W
     // (N + Ts/2 samples from off+nin) is already in flight into registers.
     constexpr int KPRE = 8;
     const bool use_pre = (N + Ts / 2) <= 64 * KPRE;
-    float2 pre[KPRE];
+    uint2 pre[KPRE];
 #pragma unroll
-    for (int k = 0; k < KPRE; k++) pre[k] = make_float2(0.f, 0.f);
+    for (int k = 0; k < KPRE; k++) pre[k] = make_uint2(0u, 0u);
     if (use_pre) {
-        const long long last = C.nsamples > 0 ? C.nsamples - 1 : 0;
-#pragma unroll
-        for (int k = 0; k < KPRE; k++) {                 // unconditional, index clamped: nothing waits here
-            long long i = lane + 64 * k;
-            i = i < last ? i : last;
-            if (C.nsamples > 0) pre[k] = load_sample(C.raw, C.fmt, i);
-        }
+        if (C.nsamples > 0) prefetch_raw<KPRE>(pre, C.raw, C.fmt, 0, C.nsamples - 1, lane);
     }
 
     long long off = 0, frames = 0;
@@ -175,18 +216,12 @@ __global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const W
         // ---- new samples -> X[nstash ..] ---------------------------------------------------
         if (use_pre) {
 #pragma unroll
-            for (int k = 0; k < KPRE; k++) { const int i = lane + 64 * k; if (i < nin) X[nstash + i] = pre[k]; }
-            const long long off_next = off + nin, last = C.nsamples - 1;
-#pragma unroll
-            for (int k = 0; k < KPRE; k++) {             // clamped index: samples past the end are never used
-                long long i = off_next + lane + 64 * k;
-                i = i < last ? i : last;
-                pre[k] = load_sample(C.raw, C.fmt, i);
-            }
+            for (int k = 0; k < KPRE; k++) { const int i = lane + 64 * k; if (i < nin) X[nstash + i] = convert_raw(pre[k], C.fmt); }
+            prefetch_raw<KPRE>(pre, C.raw, C.fmt, off + nin, C.nsamples - 1, lane);   // clamped: samples past the end are never used
         } else {
             for (int i = lane; i < nin; i += 64) X[nstash + i] = load_sample(C.raw, C.fmt, off + i);
         }
-        __syncthreads();
+        lds_barrier();
         PROF_MARK(0);
 
         // ---- tone estimator (fsk.c:540-677) ------------------------------------------------
@@ -205,7 +240,7 @@ __global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const W
                 }
                 FB[n] = v;
             }
-            __syncthreads();
+            lds_barrier();
             for (int s = cfg.nstages - 1; s >= 0; s--) {               // innermost butterflies first
                 const int m = cfg.mstage[s], p = cfg.radix[s], fs = cfg.fstride[s];
                 const int nb = Ndft / p;
@@ -232,7 +267,7 @@ __global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const W
                         F[0] = make_float2(f0.x + t.x, f0.y + t.y);
                     }
                 }
-                __syncthreads();
+                lds_barrier();
             }
             // |X|^2, band limits, IIR (fsk.c:612-628)
             for (int i = lane; i < NH; i += 64) {
@@ -244,11 +279,11 @@ __global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const W
                 FE[i] = e;
                 FW[i] = e;
             }
-            __syncthreads();
+            lds_barrier();
         }
         if (fft_loops == 0) {          // not reachable for hbr geometries (nin >= Ndft); defined behaviour anyway
             for (int i = lane; i < NH; i += 64) FW[i] = 0.f;
-            __syncthreads();
+            lds_barrier();
         }
         PROF_MARK(1);
         // M peaks: first-maximum argmax, blank +-f_zero, ascending sort (fsk.c:633-667)
@@ -273,9 +308,9 @@ __global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const W
             const int imax = __builtin_amdgcn_readfirstlane((best.v > 0.f) ? best.i : 0);
             int lo = imax - cfg.f_zero; lo = lo < 0 ? 0 : lo;
             int hi = imax + cfg.f_zero; hi = hi > NH ? NH : hi;        // only bins < Ndft/2 are ever read again
-            __syncthreads();
+            lds_barrier();
             for (int j = lo + lane; j < hi; j += 64) FW[j] = 0.f;
-            __syncthreads();
+            lds_barrier();
             fbin[k] = imax;
         }
 #pragma unroll
@@ -322,7 +357,7 @@ __global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const W
         }
 #pragma unroll
         for (int m = 0; m < M; m++) fbin_prev[m] = fbin[m];                // fsk.c:847
-        __syncthreads();
+        lds_barrier();
 
         PROF_MARK(3);
         // ---- down-convert: sample * conj(phasor), in place (fsk.c:791,817) ------------------
@@ -339,7 +374,7 @@ __global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const W
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
 
         PROF_MARK(4);
         // ---- integrate-and-dump: every output re-sums the Ts circular-buffer slots in slot order
@@ -374,7 +409,7 @@ __global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const W
 #pragma unroll
             for (int m = 0; m < M; m++) FI[m * NI + i] = make_float2(acc[m].x, acc[m].y);
         }
-        __syncthreads();
+        lds_barrier();
 
         PROF_MARK(5);
         // ---- stash the tail of the new block for the next frame (fsk.c:851) ------------------
@@ -392,7 +427,7 @@ __global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const W
             const float2 pf = pft_t[i];
             TP[i] = make_float2(ft1 * pf.x, ft1 * pf.y);
         }
-        __syncthreads();
+        lds_barrier();
         PROF_MARK(6);
         float tcr = 0.f, tci = 0.f;
         {
@@ -488,7 +523,7 @@ __global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const W
             }
             if (cfg.stats) {                                               // Eb/N0 accumulators (fsk.c:984-1007)
                 if (lane < WR_NSYM) { SC[lane] = mymax; SC[WR_NSYM + lane] = sqrtf(mymax); }
-                __syncthreads();
+                lds_barrier();
                 if (lane == 0) {
                     float stdebno = 0.f, meanebno = 0.f;
                     for (int i = 0; i < WR_NSYM; i++) { stdebno += SC[i]; meanebno += SC[WR_NSYM + i]; }
@@ -498,7 +533,7 @@ __global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const W
                     SC[2 * WR_NSYM] = meanebno;
                     SC[2 * WR_NSYM + 1] = stdebno;
                 }
-                __syncthreads();
+                lds_barrier();
                 tr_mean = SC[2 * WR_NSYM];
                 tr_std = SC[2 * WR_NSYM + 1];
             }
@@ -523,7 +558,7 @@ __global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const W
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
         PROF_MARK(8);
         // ---- emit the frame's outputs (fsk_demod.c:403-407): a NaN frame re-emits the previous buffer
         if (C.sd_out) {
@@ -544,7 +579,7 @@ __global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const W
         off += nin;
         nin = nin_next;
         frames++;
-        __syncthreads();
+        lds_barrier();
         PROF_MARK(9);
     }
     if (PROF && C.prof && lane == 0) {
