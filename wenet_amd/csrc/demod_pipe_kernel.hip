@@ -1,0 +1,533 @@
+// demod_pipe_kernel.hip -- pipelined M-FSK demodulator: eight wavefronts (512 threads) per capture.
+//
+// Why: on gfx950 a lone wavefront issues one VALU instruction every ~7.5-9 cycles no matter how much ILP
+// it has (tools/ubench/issue_rate.hip), and the reference's frame loop is one long dependency chain
+//     estimate tones -> NCO phasor chain -> mix/integrate -> timing sum -> nin -> next frame.
+// The chain and the timing sum are float recurrences that must run in reference order (bit-exactness),
+// so the only way to go faster on ONE capture is to overlap the stages of neighbouring frames:
+//
+//     wave 0      C(k+1)   NCO phasor chain of the NEXT frame            (fsk.c:756-764,781-824)
+//     wave 1      E(k+2)   tone estimator two frames ahead                (fsk.c:540-677)
+//     waves 2-7   D(k)     sample staging, down-conversion, integrate-and-dump, timing products
+//     wave 2      T(k)     ordered timing sum, atan2f, nin, resample/decide, soft decisions out (fsk.c:858-993)
+//
+// C(k+1) and E(k+2) need nin(k+1), which only T(k) produces; they run SPECULATIVELY with nin = N (true for
+// >99 % of frames on a locked signal).  Every stage keeps its carried state in small rings (spectrum x3,
+// NCO phase x3, tone bins x4, phasor rows x2, samples in a 4-frame ring), so when T(k) reports nin(k+1) != N
+// the two speculative stages are simply re-run from the untouched state of frame k.  Results are
+// bit-identical to the sequential kernel (demod_kernel.hip) and hence to the reference.
+//
+// Synchronisation: one workgroup barrier per frame; the six D waves meet at LDS-counter barriers so that
+// waves 0/1 are never stalled inside their long serial loops.
+#include "demod_common.h"
+
+#pragma clang fp contract(off)
+
+#define WP_THREADS 512
+#define WP_DSP_THREADS 384          // waves 2..7
+#define WP_KP 2                     // raw samples prefetched per D thread (2*384 >= N+Ts/2 is required)
+
+namespace {
+
+__device__ __forceinline__ void wave_sync() {     // LDS ordering inside ONE wavefront (it runs in lockstep)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+// barrier among the D waves only: monotone LDS counter, one arrival per wave per phase
+__device__ __forceinline__ void dsp_barrier(int *cnt, int target, int lane) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+enum { CT_NIN_NEXT = 0, CT_CNT = 1, CT_FBIN = 4 /* [4 frames][4 tones] */, CT_INTS = 24 };
+
+}  // namespace
+
+template <int M>
+__global__ __launch_bounds__(WP_THREADS) void wenet_demod_pipe_kernel(WrDemodCfg cfg, const WrChan *chans, int nchan) {
+    const int ch = blockIdx.x;
+    if (ch >= nchan) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const WrChan C = chans[ch];
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float2 *XR = (float2 *)(smem + cfg.p_off_XR);     // [ring]        sample ring, index (abs + nstash) & mask
+    float2 *PHb = (float2 *)(smem + cfg.p_off_PH);    // [2][M][Lpad]  phasors -> mixed samples -> timing products
+    float2 *FI = (float2 *)(smem + cfg.p_off_FI);     // [M][NI]
+    float2 *FB = (float2 *)(smem + cfg.p_off_FB);     // [Ndft]
+    float  *FEr = (float *)(smem + cfg.p_off_FE);     // [3][Ndft/2]   smoothed spectrum after frame j in slot j%3
+    float  *FW = (float *)(smem + cfg.p_off_FW);      // [Ndft/2]
+    float  *SDL = (float *)(smem + cfg.p_off_SD);     // [Nbits]
+    float  *SC = (float *)(smem + cfg.p_off_SC);      // scratch (Eb/N0)
+    float2 *PHE = (float2 *)(smem + cfg.p_off_PHE);   // [3][4]        NCO phase at the end of frame j in slot j%3
+    int    *CT = (int *)(smem + cfg.p_off_CT);        // control words
+    const float2 *tw_t = (const float2 *)(smem + cfg.p_off_TW);
+    const float  *hann_t = (const float *)(smem + cfg.p_off_HANN);
+    const int    *src_t = (const int *)(smem + cfg.p_off_SRC);
+    const float2 *pft_t = (const float2 *)(smem + cfg.p_off_PFT);
+    const float2 *dphi_t = (const float2 *)(smem + cfg.p_off_DPHI);
+
+    const int Ts = cfg.Ts, N = cfg.N, P = cfg.P, Nmem = cfg.Nmem, nstash = cfg.nstash;
+    const int Ndft = cfg.Ndft, NH = cfg.Ndft / 2, L = cfg.L, NI = cfg.NI, q = cfg.q, Lpad = cfg.Lpad;
+    const int Nbits = cfg.Nbits, Nmax = N + Ts / 2;
+    const int rmask = cfg.p_ring - 1;
+#define RIDX(a) ((int)(((a) + nstash) & rmask))
+
+    // ---- carried state -> LDS ------------------------------------------------------------------
+    WrChanHdr *hdr = (WrChanHdr *)C.state;
+    float *st_fft = C.state + cfg.st_fft_est;
+    float2 *st_old = (float2 *)(C.state + cfg.st_samp_old);
+    float *st_sd = C.state + cfg.st_sd_last;
+    {
+        float2 *tw_w = (float2 *)(smem + cfg.p_off_TW); float *hann_w = (float *)(smem + cfg.p_off_HANN);
+        int *src_w = (int *)(smem + cfg.p_off_SRC); float2 *pft_w = (float2 *)(smem + cfg.p_off_PFT);
+        float2 *dphi_w = (float2 *)(smem + cfg.p_off_DPHI);
+        for (int i = tid; i < Ndft; i += WP_THREADS) { tw_w[i] = cfg.tw[i]; hann_w[i] = cfg.hann[i]; src_w[i] = cfg.fft_src[i]; }
+        for (int i = tid; i < NI; i += WP_THREADS) pft_w[i] = cfg.phi_ft[i];
+        for (int i = tid; i < NH; i += WP_THREADS) dphi_w[i] = cfg.dphi_tab[i];
+    }
+    for (int i = tid; i < NH; i += WP_THREADS) FEr[2 * NH + i] = st_fft[i];           // "after frame -1" lives in slot 2
+    for (int i = tid; i < Nbits; i += WP_THREADS) SDL[i] = st_sd[i];
+    for (int i = tid; i < nstash; i += WP_THREADS) XR[RIDX((long long)(i - nstash))] = st_old[i];
+    if (tid < M) { PHE[2 * 4 + tid] = hdr->phi_c[tid]; CT[CT_FBIN + 3 * 4 + tid] = hdr->f_bin[tid]; }   // frame -1 -> slots 2 / 3
+    if (tid == 0) { CT[CT_CNT] = 0; CT[CT_NIN_NEXT] = hdr->nin; }
+    int nin = __builtin_amdgcn_readfirstlane(hdr->nin);
+    // first 3*Nmax samples into the ring
+    {
+        const long long last = C.nsamples - 1;
+        for (long long i = tid; i < 3LL * Nmax; i += WP_THREADS)
+            XR[RIDX(i)] = (C.nsamples > 0) ? load_sample(C.raw, C.fmt, i < last ? i : last) : make_float2(0.f, 0.f);
+    }
+    long long filled = 3LL * Nmax;                    // ring holds absolute samples [off - nstash, filled)
+    // T-wave private carried scalars
+    float norm_rx_timing_st = hdr->norm_rx_timing;
+    float ppm = hdr->ppm;
+    lds_barrier();
+
+    // ================================ stage bodies ============================================
+    // E(j): tone estimator of frame j.  One wavefront.  slot_in/out index the spectrum ring.
+    auto estimate = [&](int j, long long off_j, int nin_j) {
+        const float *FEin = FEr + ((j + 2) % 3) * NH;          // after frame j-1
+        float *FEout = FEr + (j % 3) * NH;
+        const int fft_loops = nin_j / Ndft;
+        for (int jl = 0; jl < fft_loops; jl++) {
+            const int samps = nin_j - (jl + 1) * Ndft;                  // fsk.c:583
+            const int fft_samps = samps >= Ndft ? Ndft : samps;         // fsk.c:584
+            for (int n = lane; n < Ndft; n += 64) {
+                const int idx = src_t[n];
+                float2 v = make_float2(0.f, 0.f);
+                if (idx < fft_samps) {
+                    const float h = hann_t[idx];
+                    const float2 x = XR[RIDX(off_j + idx + Ndft * jl)];
+                    v = make_float2(h * x.x, h * x.y);
+                }
+                FB[n] = v;
+            }
+            wave_sync();
+            for (int s = cfg.nstages - 1; s >= 0; s--) {
+                const int m = cfg.mstage[s], p = cfg.radix[s], fs = cfg.fstride[s];
+                const int nb = Ndft / p;
+                for (int b = lane; b < nb; b += 64) {
+                    const int blk = b / m, k = b - blk * m;
+                    float2 *F = FB + blk * m * p + k;
+                    if (p == 4) {                                       // kf_bfly4 (kiss_fft.c:44-90)
+                        const float2 s0 = cmul(F[m], tw_t[k * fs]);
+                        const float2 s1 = cmul(F[2 * m], tw_t[k * fs * 2]);
+                        const float2 s2 = cmul(F[3 * m], tw_t[k * fs * 3]);
+                        float2 f0 = F[0];
+                        const float2 s5 = make_float2(f0.x - s1.x, f0.y - s1.y);
+                        f0 = make_float2(f0.x + s1.x, f0.y + s1.y);
+                        const float2 s3 = make_float2(s0.x + s2.x, s0.y + s2.y);
+                        const float2 s4 = make_float2(s0.x - s2.x, s0.y - s2.y);
+                        F[2 * m] = make_float2(f0.x - s3.x, f0.y - s3.y);
+                        F[0] = make_float2(f0.x + s3.x, f0.y + s3.y);
+                        F[m] = make_float2(s5.x + s4.y, s5.y - s4.x);
+                        F[3 * m] = make_float2(s5.x - s4.y, s5.y + s4.x);
+                    } else {                                            // kf_bfly2 (kiss_fft.c:21-42)
+                        const float2 t = cmul(F[m], tw_t[k * fs]);
+                        const float2 f0 = F[0];
+                        F[m] = make_float2(f0.x - t.x, f0.y - t.y);
+                        F[0] = make_float2(f0.x + t.x, f0.y + t.y);
+                    }
+                }
+                wave_sync();
+            }
+            const float *FEcur = (jl == 0) ? FEin : FEout;
+            for (int i = lane; i < NH; i += 64) {                       // fsk.c:612-628
+                const float2 v = FB[i];
+                float mag = (v.x * v.x) + (v.y * v.y);
+                if (i < cfg.f_min) mag = 0.f;
+                if (cfg.f_max - 1 >= 0 && i >= cfg.f_max - 1) mag = 0.f;
+                const float e = (FEcur[i] * cfg.one_minus_tc) + (sqrtf(mag) * cfg.tc);
+                FEout[i] = e;
+                FW[i] = e;
+            }
+            wave_sync();
+        }
+        if (fft_loops == 0) {
+            for (int i = lane; i < NH; i += 64) { FEout[i] = FEin[i]; FW[i] = 0.f; }
+            wave_sync();
+        }
+        int fbin[M];
+#pragma unroll
+        for (int k = 0; k < M; k++) {                                   // fsk.c:633-654
+            BestBin best; best.v = 0.f; best.i = 0;
+            for (int jj = lane; jj < NH; jj += 64) {
+                const float v = FW[jj];
+                if (v > best.v) { best.v = v; best.i = jj; }
+            }
+#pragma unroll
+            for (int sh = 32; sh >= 1; sh >>= 1) {
+                BestBin o;
+                o.v = __shfl_xor(best.v, sh, 64);
+                o.i = __shfl_xor(best.i, sh, 64);
+                best = better(best, o);
+            }
+            const int imax = __builtin_amdgcn_readfirstlane((best.v > 0.f) ? best.i : 0);
+            int lo = imax - cfg.f_zero; lo = lo < 0 ? 0 : lo;
+            int hi = imax + cfg.f_zero; hi = hi > NH ? NH : hi;
+            wave_sync();
+            for (int jj = lo + lane; jj < hi; jj += 64) FW[jj] = 0.f;
+            wave_sync();
+            fbin[k] = imax;
+        }
+#pragma unroll
+        for (int a = 1; a < M; a++) {
+#pragma unroll
+            for (int b = a; b > 0; b--)
+                if (fbin[b - 1] > fbin[b]) { const int t = fbin[b]; fbin[b] = fbin[b - 1]; fbin[b - 1] = t; }
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int m = 0; m < M; m++) CT[CT_FBIN + (j & 3) * 4 + m] = fbin[m];
+        }
+        wave_sync();
+    };
+
+    // C(j): NCO phasor chain of frame j (one wavefront, lanes 0..M-1 carry one tone each)
+    auto chain = [&](int j, int nin_j) {
+        if (lane < M) {
+            const int nold = Nmem - nin_j;
+            int bc = CT[CT_FBIN + (j & 3) * 4 + lane];
+            int bp = CT[CT_FBIN + ((j + 3) & 3) * 4 + lane];
+            const int bp0 = CT[CT_FBIN + ((j + 3) & 3) * 4 + 0];
+            if (cfg.bin_freq[bp0] < 1.0f) bp = bc;                       // first run (fsk.c:750-753)
+            const int ncase = (nin_j < N) ? 0 : ((nin_j > N) ? 2 : 1);
+            const float2 bo = cfg.backoff_tab[ncase * NH + bp];
+            const float2 pc = PHE[((j + 2) % 3) * 4 + lane];
+            v2f phi = cmul_pk((v2f){bo.x, bo.y}, (v2f){pc.x, pc.y});     // fsk.c:758-759
+            float2 dd = dphi_t[bp];
+            v2f d = {dd.x, dd.y};
+            v2f *ph = (v2f *)(PHb + ((j & 1) * M + lane) * Lpad);
+            int s = 0;
+            for (; s < nold; s++) { ph[s] = phi; phi = cmul_pk(phi, d); }
+            {
+                const float av = sqrtf(phi.x * phi.x + phi.y * phi.y);   // comp_normalize (fsk.c:787)
+                phi = (v2f){phi.x / av, phi.y / av};
+                dd = dphi_t[bc];
+                d = (v2f){dd.x, dd.y};
+            }
+            for (; s + 8 <= L; s += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; u++) { ph[s + u] = phi; phi = cmul_pk(phi, d); }
+            }
+            for (; s < L; s++) { ph[s] = phi; phi = cmul_pk(phi, d); }
+            PHE[(j % 3) * 4 + lane] = make_float2(phi.x, phi.y);        // un-normalised (fsk.c:846)
+        }
+        wave_sync();
+    };
+
+    // ================================ pipeline prologue ========================================
+    long long off = 0, frames = 0;
+    const bool any = (off + nin <= C.nsamples) && (C.cap_frames > 0);
+    if (any) {
+        if (wave == 1) estimate(0, 0, nin);                              // E(0), true nin
+        lds_barrier();
+        if (wave == 0) chain(0, nin);                                    // C(0), true nin
+        if (wave == 1) estimate(1, (long long)nin, N);                   // E(1), speculative
+        lds_barrier();
+    }
+    // D-thread prefetch registers: samples [filled, filled + 2*384)
+    const int t = tid - 128;                                             // D thread index (waves 2..7)
+    uint2 pre[WP_KP];
+#pragma unroll
+    for (int k = 0; k < WP_KP; k++) pre[k] = make_uint2(0u, 0u);
+    if (any && wave >= 2) {
+        const long long last = C.nsamples - 1;
+#pragma unroll
+        for (int k = 0; k < WP_KP; k++) { long long i = filled + t + WP_DSP_THREADS * k; pre[k] = load_raw(C.raw, C.fmt, i < last ? i : last); }
+    }
+    int dsp_phase = 0;
+
+    // ================================ frame loop ===============================================
+    int kf = 0;                                                          // frame index within this launch
+    while (off + nin <= C.nsamples && frames < C.cap_frames) {
+        const int nold = Nmem - nin;
+        if (wave == 0) {
+            chain(kf + 1, N);                                            // C(k+1), speculative nin = N
+        } else if (wave == 1) {
+            estimate(kf + 2, off + nin + N, N);                          // E(k+2), speculative
+        } else {
+            // ---- stage the next nin samples into the ring, issue the following prefetch -------------
+            {
+#pragma unroll
+                for (int k = 0; k < WP_KP; k++) { const int i = t + WP_DSP_THREADS * k; if (i < nin) XR[RIDX(filled + i)] = convert_raw(pre[k], C.fmt); }
+                const long long nf = filled + nin, last = C.nsamples - 1;
+#pragma unroll
+                for (int k = 0; k < WP_KP; k++) { long long i = nf + t + WP_DSP_THREADS * k; pre[k] = load_raw(C.raw, C.fmt, i < last ? i : last); }
+            }
+            // ---- D(k): down-convert in place (fsk.c:791,817) --------------------------------------
+            float2 *PH = PHb + (kf & 1) * M * Lpad;
+            const long long src0 = off - nold;                           // chain step s <-> absolute sample src0 + s
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                float2 *row = PH + m * Lpad;
+                for (int s = t; s < L; s += WP_DSP_THREADS) {
+                    const float2 x = XR[RIDX(src0 + s)];
+                    const float2 p = row[s];
+                    row[s] = cmul(x, make_float2(p.x, -p.y));
+                }
+            }
+            dsp_barrier(&CT[CT_CNT], 6 * (++dsp_phase), lane);
+            // ---- integrate-and-dump, slot order (fsk.c:829-840) -----------------------------------
+            for (int i = t; i < NI; i += WP_DSP_THREADS) {
+                const int base = i * q;
+                const int r = base % Ts;
+                int o = (r == 0) ? 0 : Ts - r;
+                v2f acc[M];
+#pragma unroll
+                for (int m = 0; m < M; m++) acc[m] = (v2f){0.f, 0.f};
+                for (int j0 = 0; j0 < Ts; j0 += 8) {
+                    v2f v[M][8];
+                    int oo = o;
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const int idx = (j0 + u < Ts) ? base + oo : base;
+#pragma unroll
+                        for (int m = 0; m < M; m++) v[m][u] = ((const v2f *)PH)[m * Lpad + idx];
+                        oo++;
+                        if (oo == Ts) oo = 0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        if (j0 + u < Ts) {
+#pragma unroll
+                            for (int m = 0; m < M; m++) acc[m] = acc[m] + v[m][u];
+                        }
+                    }
+                    o = oo;
+                }
+#pragma unroll
+                for (int m = 0; m < M; m++) FI[m * NI + i] = make_float2(acc[m].x, acc[m].y);
+            }
+            dsp_barrier(&CT[CT_CNT], 6 * (++dsp_phase), lane);
+            // ---- timing products (fsk.c:862-870); the mixed samples are dead, reuse their rows ------
+            float2 *TP = PH;
+            for (int i = t; i < NI; i += WP_DSP_THREADS) {
+                float ft1 = 0.f;
+#pragma unroll
+                for (int m = 0; m < M; m++) {
+                    const float2 v = FI[m * NI + i];
+                    ft1 += (v.x * v.x) + (v.y * v.y);
+                }
+                const float2 pf = pft_t[i];
+                TP[i] = make_float2(ft1 * pf.x, ft1 * pf.y);
+            }
+            dsp_barrier(&CT[CT_CNT], 6 * (++dsp_phase), lane);
+
+            if (wave == 2) {
+                // ---- T(k): ordered sum, timing, nin, decisions (fsk.c:870-993) ----------------------
+                float tcr, tci;
+                {
+                    typedef float v4f __attribute__((ext_vector_type(4)));
+                    const v4f *TP4 = (const v4f *)TP;
+                    v2f acc = {0.f, 0.f};
+                    v4f cur[4], nxt[4];
+                    int i = 0;
+                    if (NI >= 8) {
+#pragma unroll
+                        for (int u = 0; u < 4; u++) cur[u] = TP4[u];
+                        for (i = 8; i + 8 <= NI; i += 8) {
+#pragma unroll
+                            for (int u = 0; u < 4; u++) nxt[u] = TP4[(i >> 1) + u];
+#pragma unroll
+                            for (int u = 0; u < 4; u++) { acc = acc + cur[u].xy; acc = acc + cur[u].zw; }
+#pragma unroll
+                            for (int u = 0; u < 4; u++) cur[u] = nxt[u];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; u++) { acc = acc + cur[u].xy; acc = acc + cur[u].zw; }
+                    }
+                    for (; i < NI; i++) { const float2 v = TP[i]; acc = acc + (v2f){v.x, v.y}; }
+                    tcr = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(acc.x)));
+                    tci = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(acc.y)));
+                }
+                int nin_next = nin;
+                float tr_mean = 0.f, tr_std = 0.f, tr_rxt = 0.f;
+                const bool nan_frame = (tcr != tcr) || (tci != tci);     // fsk.c:878-880
+                if (!nan_frame) {
+                    const float at = wg_atan2f(tci, tcr);
+                    const float norm_rx_timing = (float)((double)at / (2 * 3.14159265358979323846));
+                    const float rx_timing = norm_rx_timing * cfg.P_f;
+                    const float d_nrt = norm_rx_timing - norm_rx_timing_st;
+                    norm_rx_timing_st = norm_rx_timing;
+                    if ((double)fabsf(d_nrt) < .2) {
+                        const float appm = (float)(1e6 * (double)d_nrt / (double)cfg.nsym_f);
+                        ppm = (float)(.9 * (double)ppm + .1 * (double)appm);
+                    }
+                    if (norm_rx_timing > 0.25f) nin_next = N + Ts / 2;
+                    else if (norm_rx_timing < -0.25f) nin_next = N - Ts / 2;
+                    else nin_next = N;
+                    nin_next = __builtin_amdgcn_readfirstlane(nin_next);
+                    const int low_sample = (int)floorf(rx_timing);
+                    const float fract = rx_timing - (float)low_sample;
+                    const int high_sample = (int)ceilf(rx_timing);
+                    const float omf = 1 - fract;
+                    tr_rxt = rx_timing;
+                    float mymax = 0.f;
+                    if (lane < WR_NSYM) {
+                        const int st = (lane + 1) * P;
+                        float tmax[M];
+#pragma unroll
+                        for (int m = 0; m < M; m++) {
+                            const float2 a = FI[m * NI + st + low_sample];
+                            const float2 b = FI[m * NI + st + high_sample];
+                            float tr = omf * a.x, ti = omf * a.y;
+                            tr = tr + fract * b.x;
+                            ti = ti + fract * b.y;
+                            tmax[m] = (tr * tr) + (ti * ti);
+                        }
+                        float mx = tmax[0];
+                        int sym = 0;
+#pragma unroll
+                        for (int m = 0; m < M; m++) if (tmax[m] > mx) { mx = tmax[m]; sym = m; }
+                        mymax = mx;
+                        if (C.bits_out) {
+                            uint8_t *bo = C.bits_out + frames * Nbits;
+                            if (M == 2) bo[lane] = (uint8_t)(sym == 1);
+                            else { bo[lane * 2 + 1] = (uint8_t)(sym & 1); bo[lane * 2] = (uint8_t)((sym & 2) >> 1); }
+                        }
+#pragma unroll
+                        for (int m = 0; m < M; m++) tmax[m] = sqrtf(tmax[m]);
+                        if (M == 2) {
+                            SDL[lane] = tmax[0] - tmax[1];
+                        } else {
+                            float s1 = -tmax[0], s0 = -tmax[0];
+                            s1 += tmax[1 % M];  s0 += -tmax[1 % M];
+                            s1 += -tmax[2 % M]; s0 += tmax[2 % M];
+                            s1 += tmax[3 % M];  s0 += tmax[3 % M];
+                            SDL[lane * 2 + 1] = s1;
+                            SDL[lane * 2] = s0;
+                        }
+                    }
+                    if (cfg.stats) {
+                        if (lane < WR_NSYM) { SC[lane] = mymax; SC[WR_NSYM + lane] = sqrtf(mymax); }
+                        wave_sync();
+                        if (lane == 0) {
+                            float stdebno = 0.f, meanebno = 0.f;
+                            for (int i = 0; i < WR_NSYM; i++) { stdebno += SC[i]; meanebno += SC[WR_NSYM + i]; }
+                            meanebno = meanebno / cfg.nsym_f;
+                            stdebno = (stdebno / cfg.nsym_f) - (meanebno * meanebno);
+                            if ((double)stdebno > 0.0) stdebno = (float)sqrt((double)stdebno); else stdebno = 0.0f;
+                            SC[2 * WR_NSYM] = meanebno;
+                            SC[2 * WR_NSYM + 1] = stdebno;
+                        }
+                        wave_sync();
+                        tr_mean = SC[2 * WR_NSYM];
+                        tr_std = SC[2 * WR_NSYM + 1];
+                    }
+                    if (C.dump && frames >= C.dump_first && ((frames - C.dump_first) % C.dump_period) == 0) {
+                        const long long slot = (frames - C.dump_first) / C.dump_period;
+                        if (slot < C.dump_cap) {
+                            float *d = C.dump + slot * cfg.dump_floats;
+                            const float *FEk = FEr + (kf % 3) * NH;
+                            const int neye = cfg.eye_traces * M * cfg.neyesamp;
+                            for (int e = lane; e < neye; e += 64) {
+                                const int j = e % cfg.neyesamp;
+                                const int tm = e / cfg.neyesamp;
+                                const int i = tm / M, m = tm - i * M;
+                                const int ind = 2 * P * i + (high_sample + 1) + j * cfg.eye_dec;
+                                float v = 0.f;
+                                if (ind >= 0 && ind < NI) { const float2 f = FI[m * NI + ind]; v = sqrtf(f.x * f.x + f.y * f.y); }
+                                d[e] = v;
+                            }
+                            for (int i = lane; i < NH; i += 64) d[neye + i] = FEk[i];
+                            if (lane == 0) { d[neye + NH] = (float)high_sample; d[neye + NH + 1] = (float)frames; }
+                        }
+                    }
+                }
+                wave_sync();
+                if (C.sd_out) {
+                    float *so = C.sd_out + frames * Nbits;
+                    for (int i = lane; i < Nbits; i += 64) so[i] = SDL[i];
+                }
+                if (C.trace && lane == 0) {
+                    float *tr = C.trace + frames * WR_TRACE_FLOATS;
+#pragma unroll
+                    for (int m = 0; m < WR_M_MAX; m++) tr[WR_TR_FEST + m] = (m < M) ? cfg.bin_freq[CT[CT_FBIN + (kf & 3) * 4 + (m < M ? m : 0)]] : 0.f;
+                    tr[WR_TR_NIN] = (float)nin_next;
+                    tr[WR_TR_NRT] = norm_rx_timing_st;
+                    tr[WR_TR_PPM] = ppm;
+                    tr[WR_TR_MEAN] = tr_mean;
+                    tr[WR_TR_STD] = tr_std;
+                    tr[WR_TR_RXT] = tr_rxt;
+                }
+                if (lane == 0) CT[CT_NIN_NEXT] = nin_next;
+            }
+        }
+        lds_barrier();
+        // ---- commit frame k; verify the speculation nin(k+1) == N ----------------------------------
+        const int nin_next = __builtin_amdgcn_readfirstlane(CT[CT_NIN_NEXT]);
+        const long long off_next = off + nin;
+        if (wave >= 2) filled += nin;
+        if (nin_next != N) {
+            // E(k+1) and C(k+1) were computed for the wrong window length / nold, E(k+2) at the wrong offset:
+            // re-run them from the state of frame k, which the rings still hold.
+            if (wave == 1) estimate(kf + 1, off_next, nin_next);
+            lds_barrier();
+            if (wave == 0) chain(kf + 1, nin_next);
+            if (wave == 1) estimate(kf + 2, off_next + nin_next, N);
+            lds_barrier();
+        }
+        off = off_next;
+        nin = nin_next;
+        frames++;
+        kf++;
+    }
+
+    // ================================ save carried state =======================================
+    lds_barrier();
+    if (frames > 0) {
+        const int jl = kf - 1;                                           // last committed frame
+        const float *FEk = FEr + (jl % 3) * NH;
+        for (int i = tid; i < NH; i += WP_THREADS) st_fft[i] = FEk[i];
+        for (int i = tid; i < nstash; i += WP_THREADS) st_old[i] = XR[RIDX(off - nstash + i)];
+        for (int i = tid; i < Nbits; i += WP_THREADS) st_sd[i] = SDL[i];
+        if (tid < M) { hdr->phi_c[tid] = PHE[(jl % 3) * 4 + tid]; hdr->f_bin[tid] = CT[CT_FBIN + (jl & 3) * 4 + tid]; }
+    }
+    if (tid == 128) {                                                    // lane 0 of the T wave owns the timing scalars
+        hdr->norm_rx_timing = norm_rx_timing_st;
+        hdr->ppm = ppm;
+        hdr->nin = nin;
+        hdr->frames_total += frames;
+        hdr->frames_call = frames;
+        hdr->consumed_call = off;
+    }
+#undef RIDX
+}
+
+extern "C" hipError_t wr_launch_demod_pipe(const WrDemodCfg *cfg, const WrChan *d_chans, int nchan, hipStream_t stream) {
+    if (nchan <= 0) return hipSuccess;
+    dim3 grid(nchan), block(WP_THREADS);
+    if (cfg->M == 2) {
+        (void)hipFuncSetAttribute((const void *)wenet_demod_pipe_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, cfg->p_lds_bytes);
+        hipLaunchKernelGGL(wenet_demod_pipe_kernel<2>, grid, block, cfg->p_lds_bytes, stream, *cfg, d_chans, nchan);
+    } else {
+        (void)hipFuncSetAttribute((const void *)wenet_demod_pipe_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, cfg->p_lds_bytes);
+        hipLaunchKernelGGL(wenet_demod_pipe_kernel<4>, grid, block, cfg->p_lds_bytes, stream, *cfg, d_chans, nchan);
+    }
+    return hipGetLastError();
+}

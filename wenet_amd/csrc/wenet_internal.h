@@ -48,6 +48,10 @@ struct WrDemodCfg {
     // LDS carve-up (bytes)
     int off_X, off_FB, off_PH, off_FI, off_FE, off_FW, off_SD, off_SC, lds_bytes;
     int tables_in_lds, off_TW, off_HANN, off_SRC, off_PFT, off_DPHI;
+    // LDS carve-up of the pipelined kernel (demod_pipe_kernel.hip); pipe_ok = configuration fits
+    int pipe_ok, p_ring, p_lds_bytes;
+    int p_off_XR, p_off_PH, p_off_FI, p_off_FB, p_off_FE, p_off_FW, p_off_SD, p_off_SC, p_off_PHE, p_off_CT;
+    int p_off_TW, p_off_HANN, p_off_SRC, p_off_PFT, p_off_DPHI;
     // per-channel state block layout (floats from the block start)
     int st_fft_est, st_samp_old, st_sd_last, st_floats;
 };

@@ -23,6 +23,7 @@
 #pragma clang fp contract(off)
 
 extern "C" hipError_t wr_launch_demod(const WrDemodCfg *cfg, const WrChan *d_chans, int nchan, hipStream_t stream);
+extern "C" hipError_t wr_launch_demod_pipe(const WrDemodCfg *cfg, const WrChan *d_chans, int nchan, hipStream_t stream);
 extern "C" hipError_t wr_launch_demod_ex(const WrDemodCfg *cfg, const WrChan *d_chans, int nchan, hipStream_t stream, int prof);
 extern "C" hipError_t wr_launch_deframe(const WrDeframeChan *d_chans, int nchan, int mode, hipStream_t stream);
 extern "C" hipError_t wr_launch_decode(const WrDecodeArgs *args, hipStream_t stream);
@@ -202,6 +203,30 @@ struct DemodTables {
                 cfg.tables_in_lds = 1; cfg.off_TW = o_tw; cfg.off_HANN = o_hn; cfg.off_SRC = o_src; cfg.off_PFT = o_pft; cfg.off_DPHI = o_dph;
                 o = t;
             }
+        }
+        {   // pipelined kernel: 4-frame sample ring, double phasor rows, triple spectrum/phase rings, tables
+            const int Nmax = cfg.N + cfg.Ts / 2;
+            int ring = 1;
+            while (ring < 4 * Nmax + cfg.nstash) ring <<= 1;
+            int t = 0;
+            cfg.p_ring = ring;
+            cfg.p_off_XR = t;   t = align16(t + ring * 8);
+            cfg.p_off_PH = t;   t = align16(t + 2 * M * cfg.Lpad * 8);
+            cfg.p_off_FI = t;   t = align16(t + M * cfg.NI * 8);
+            cfg.p_off_FB = t;   t = align16(t + Ndft * 8);
+            cfg.p_off_FE = t;   t = align16(t + 3 * NH * 4);
+            cfg.p_off_FW = t;   t = align16(t + NH * 4);
+            cfg.p_off_SD = t;   t = align16(t + cfg.Nbits * 4);
+            cfg.p_off_SC = t;   t = align16(t + (4 * nsyms + 16) * 4);
+            cfg.p_off_PHE = t;  t = align16(t + 3 * 4 * 8);
+            cfg.p_off_CT = t;   t = align16(t + 32 * 4);
+            cfg.p_off_TW = t;   t = align16(t + Ndft * 8);
+            cfg.p_off_HANN = t; t = align16(t + Ndft * 4);
+            cfg.p_off_SRC = t;  t = align16(t + Ndft * 4);
+            cfg.p_off_PFT = t;  t = align16(t + cfg.NI * 8);
+            cfg.p_off_DPHI = t; t = align16(t + NH * 8);
+            cfg.p_lds_bytes = t;
+            cfg.pipe_ok = (Nmax <= 2 * 384 && t <= 80 * 1024 && getenv("WENET_RX_NO_PIPE") == nullptr) ? 1 : 0;
         }
         cfg.lds_bytes = o;
         if (o > 160 * 1024) { fprintf(stderr, "libwenet_rx: configuration needs %d bytes of LDS (>160 KiB)\n", o); return false; }
