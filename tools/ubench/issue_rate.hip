@@ -37,6 +37,33 @@ __global__ void k(float *out, long long *cyc, int iters) {
             int idx = threadIdx.x & 255;
             for (int u = 0; u < 8; u++) idx = lds[idx];
             a += idx;
+        } else if (MODE == 7) {   // packed cmul + nop, ds_write_b64 of every phasor (compiler-scheduled store)
+            extern __shared__ v2f ldsb[];
+            v2f t1, t2;
+            v2f *row = ldsb + (threadIdx.x & 63) * 4;     // (only 2 lanes are active in the real kernel)
+            if ((threadIdx.x & 63) < 2) {
+            for (int u = 0; u < 4; u++) {
+                row[u + 8 * (i & 31)] = p;
+                asm volatile("v_pk_mul_f32 %1, %0, %3 op_sel_hi:[1,0]\n v_pk_mul_f32 %2, %0, %3 op_sel:[1,1] op_sel_hi:[0,1]\n s_nop 0\n"
+                             "v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "+v"(p), "=&v"(t1), "=&v"(t2) : "v"(q));
+            } }
+        } else if (MODE == 8) {   // the store sits in the hazard slot instead of the nop (asm ds_write)
+            extern __shared__ v2f ldsb[];
+            v2f t1, t2;
+            unsigned addr = (unsigned)(((threadIdx.x & 63) * 4 + 8 * (i & 31)) * 8);
+            if ((threadIdx.x & 63) < 2) {
+            for (int u = 0; u < 4; u++) {
+                asm volatile("v_pk_mul_f32 %1, %0, %3 op_sel_hi:[1,0]\n v_pk_mul_f32 %2, %0, %3 op_sel:[1,1] op_sel_hi:[0,1]\n ds_write_b64 %4, %0\n"
+                             "v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "+v"(p), "=&v"(t1), "=&v"(t2) : "v"(q), "v"(addr) : "memory");
+                addr += 8;
+            } }
+        } else if (MODE == 9) {   // lanes<2 predicate only, no store (cost of the exec mask itself)
+            v2f t1, t2;
+            if ((threadIdx.x & 63) < 2) {
+            for (int u = 0; u < 4; u++)
+                asm volatile("v_pk_mul_f32 %1, %0, %3 op_sel_hi:[1,0]\n v_pk_mul_f32 %2, %0, %3 op_sel:[1,1] op_sel_hi:[0,1]\n s_nop 0\n"
+                             "v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "+v"(p), "=&v"(t1), "=&v"(t2) : "v"(q));
+            }
         } else if (MODE == 6) {   // packed cmul without the nop
             v2f t1, t2;
             for (int u = 0; u < 4; u++)
@@ -53,10 +80,10 @@ template <int MODE> void run(const char *name, int ops_per_iter) {
     float *out; long long *cyc;
     hipMalloc(&out, 4 * 1024 * 1024); hipMalloc(&cyc, 8 * 4096);
     const int iters = 20000;
-    for (int waves : {1, 2, 4, 8, 16}) {       // waves per block (block = one CU here: 1 block)
+    for (int waves : {1, 4}) {       // waves per block (block = one CU here: 1 block)
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-        hipLaunchKernelGGL(k<MODE>, dim3(1), dim3(64 * waves), 0, 0, out, cyc, 100);
-        hipEventRecord(e0); hipLaunchKernelGGL(k<MODE>, dim3(1), dim3(64 * waves), 0, 0, out, cyc, iters); hipEventRecord(e1);
+        hipLaunchKernelGGL(k<MODE>, dim3(1), dim3(64 * waves), 32768, 0, out, cyc, 100);
+        hipEventRecord(e0); hipLaunchKernelGGL(k<MODE>, dim3(1), dim3(64 * waves), 32768, 0, out, cyc, iters); hipEventRecord(e1);
         hipDeviceSynchronize();
         float ms; hipEventElapsedTime(&ms, e0, e1);
         long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
@@ -71,6 +98,8 @@ int main() {
     run<3>("cmul packed+nop (per step)", 4);
     run<6>("cmul packed no nop", 4);
     run<4>("cmul scalar (per step)", 4);
-    run<5>("dep ds_read_b32", 8);
+    run<9>("cmul packed+nop, 2 lanes", 4);
+    run<7>("cmul + ds_write (compiler)", 4);
+    run<8>("cmul + ds_write in nop slot", 4);
     return 0;
 }

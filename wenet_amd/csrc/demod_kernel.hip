@@ -491,10 +491,10 @@ __global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const W
 }
 
 // explicit instantiations + launcher
-extern "C" hipError_t wr_launch_demod_pipe(const WrDemodCfg *cfg, const WrChan *d_chans, int nchan, hipStream_t stream);
+extern "C" hipError_t wr_launch_demod_pipe(const WrDemodCfg *cfg, const WrChan *d_chans, int nchan, hipStream_t stream, int prof);
 extern "C" hipError_t wr_launch_demod_ex(const WrDemodCfg *cfg, const WrChan *d_chans, int nchan, hipStream_t stream, int prof) {
     if (nchan <= 0) return hipSuccess;
-    if (cfg->pipe_ok && !prof) return wr_launch_demod_pipe(cfg, d_chans, nchan, stream);   // 8 waves per capture, pipelined
+    if (cfg->pipe_ok && prof != 2) return wr_launch_demod_pipe(cfg, d_chans, nchan, stream, prof);   // 8 waves per capture, pipelined
     dim3 grid(nchan), block(64);
 #define WR_LAUNCH(MM, PP, TT)                                                                                            \
     do {                                                                                                                   \

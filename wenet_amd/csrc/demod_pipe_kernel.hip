@@ -19,6 +19,8 @@
 //
 // Synchronisation: one workgroup barrier per frame; the six D waves meet at LDS-counter barriers so that
 // waves 0/1 are never stalled inside their long serial loops.
+#include <type_traits>
+
 #include "demod_common.h"
 
 #pragma clang fp contract(off)
@@ -26,6 +28,8 @@
 #define WP_THREADS 512
 #define WP_DSP_THREADS 384          // waves 2..7
 #define WP_KP 2                     // raw samples prefetched per D thread (2*384 >= N+Ts/2 is required)
+#define WP_CK 8                     // the chain wave stores every WP_CK-th phasor; D threads replay the steps in between
+#define WP_CKROW 80                 // checkpoints per (segment, tone) row; needs >= (Nmem-Ts/P)/WP_CK + 2
 
 namespace {
 
@@ -45,7 +49,7 @@ enum { CT_NIN_NEXT = 0, CT_CNT = 1, CT_FBIN = 4 /* [4 frames][4 tones] */, CT_IN
 
 }  // namespace
 
-template <int M>
+template <int M, bool PROF>
 __global__ __launch_bounds__(WP_THREADS) void wenet_demod_pipe_kernel(WrDemodCfg cfg, const WrChan *chans, int nchan) {
     const int ch = blockIdx.x;
     if (ch >= nchan) return;
@@ -55,7 +59,9 @@ __global__ __launch_bounds__(WP_THREADS) void wenet_demod_pipe_kernel(WrDemodCfg
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float2 *XR = (float2 *)(smem + cfg.p_off_XR);     // [ring]        sample ring, index (abs + nstash) & mask
-    float2 *PHb = (float2 *)(smem + cfg.p_off_PH);    // [2][M][Lpad]  phasors -> mixed samples -> timing products
+    float2 *DCb = (float2 *)(smem + cfg.p_off_PH);    // [M][Lpad]     mixed samples -> timing products
+    float2 *CKb = (float2 *)(smem + cfg.p_off_CK);    // [2 frames][2 segments][M][WP_CKROW] phasor checkpoints
+    float2 *CKD = (float2 *)(smem + cfg.p_off_CKD);   // [2 frames][2 segments][M] NCO step of each segment
     float2 *FI = (float2 *)(smem + cfg.p_off_FI);     // [M][NI]
     float2 *FB = (float2 *)(smem + cfg.p_off_FB);     // [Ndft]
     float  *FEr = (float *)(smem + cfg.p_off_FE);     // [3][Ndft/2]   smoothed spectrum after frame j in slot j%3
@@ -221,20 +227,32 @@ __global__ __launch_bounds__(WP_THREADS) void wenet_demod_pipe_kernel(WrDemodCfg
             v2f phi = cmul_pk((v2f){bo.x, bo.y}, (v2f){pc.x, pc.y});     // fsk.c:758-759
             float2 dd = dphi_t[bp];
             v2f d = {dd.x, dd.y};
-            v2f *ph = (v2f *)(PHb + ((j & 1) * M + lane) * Lpad);
-            int s = 0;
-            for (; s < nold; s++) { ph[s] = phi; phi = cmul_pk(phi, d); }
+            // segment A: nold steps on the old samples with the previous estimate; segment B: L-nold steps on
+            // the new block after comp_normalize with the new estimate.  Only every WP_CK-th phasor is stored.
+            v2f *ckA = (v2f *)(CKb + (((j & 1) * 2 + 0) * M + lane) * WP_CKROW);
+            v2f *ckB = (v2f *)(CKb + (((j & 1) * 2 + 1) * M + lane) * WP_CKROW);
+            CKD[((j & 1) * 2 + 0) * M + lane] = dd;
+            int s = 0, c = 0;
+            for (; s + WP_CK <= nold; s += WP_CK, c++) {
+                ckA[c] = phi;
+#pragma unroll
+                for (int u = 0; u < WP_CK; u++) phi = cmul_pk(phi, d);
+            }
+            if (s < nold) { ckA[c] = phi; for (; s < nold; s++) phi = cmul_pk(phi, d); }
             {
                 const float av = sqrtf(phi.x * phi.x + phi.y * phi.y);   // comp_normalize (fsk.c:787)
                 phi = (v2f){phi.x / av, phi.y / av};
                 dd = dphi_t[bc];
                 d = (v2f){dd.x, dd.y};
             }
-            for (; s + 8 <= L; s += 8) {
+            CKD[((j & 1) * 2 + 1) * M + lane] = dd;
+            c = 0;
+            for (; s + WP_CK <= L; s += WP_CK, c++) {
+                ckB[c] = phi;
 #pragma unroll
-                for (int u = 0; u < 8; u++) { ph[s + u] = phi; phi = cmul_pk(phi, d); }
+                for (int u = 0; u < WP_CK; u++) phi = cmul_pk(phi, d);
             }
-            for (; s < L; s++) { ph[s] = phi; phi = cmul_pk(phi, d); }
+            if (s < L) { ckB[c] = phi; for (; s < L; s++) phi = cmul_pk(phi, d); }
             PHE[(j % 3) * 4 + lane] = make_float2(phi.x, phi.y);        // un-normalised (fsk.c:846)
         }
         wave_sync();
@@ -264,13 +282,20 @@ __global__ __launch_bounds__(WP_THREADS) void wenet_demod_pipe_kernel(WrDemodCfg
 
     // ================================ frame loop ===============================================
     int kf = 0;                                                          // frame index within this launch
+    long long pr_busy = 0, pr_d = 0, pr_iter = 0, pr_redo = 0, pr_t0 = 0;     // PROF: per-role busy ticks
+    long long pr_sub[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pr_tl = 0;
+#define PSUB(k) do { if (PROF) { const long long _t = (long long)__builtin_readcyclecounter(); pr_sub[k] += _t - pr_tl; pr_tl = _t; } } while (0)
     while (off + nin <= C.nsamples && frames < C.cap_frames) {
         const int nold = Nmem - nin;
+        if (PROF) pr_t0 = (long long)__builtin_readcyclecounter();
         if (wave == 0) {
             chain(kf + 1, N);                                            // C(k+1), speculative nin = N
+            if (PROF) pr_busy += (long long)__builtin_readcyclecounter() - pr_t0;
         } else if (wave == 1) {
             estimate(kf + 2, off + nin + N, N);                          // E(k+2), speculative
+            if (PROF) pr_busy += (long long)__builtin_readcyclecounter() - pr_t0;
         } else {
+            if (PROF) pr_tl = pr_t0;
             // ---- stage the next nin samples into the ring, issue the following prefetch -------------
             {
 #pragma unroll
@@ -279,51 +304,79 @@ __global__ __launch_bounds__(WP_THREADS) void wenet_demod_pipe_kernel(WrDemodCfg
 #pragma unroll
                 for (int k = 0; k < WP_KP; k++) { long long i = nf + t + WP_DSP_THREADS * k; pre[k] = load_raw(C.raw, C.fmt, i < last ? i : last); }
             }
+            PSUB(0);
             // ---- D(k): down-convert in place (fsk.c:791,817) --------------------------------------
-            float2 *PH = PHb + (kf & 1) * M * Lpad;
+            float2 *PH = DCb;
             const long long src0 = off - nold;                           // chain step s <-> absolute sample src0 + s
+            {
+                // one D thread per (tone, checkpoint): replay the <= WP_CK chain steps that follow the checkpoint
+                // (the same cmul_pk sequence the chain wave ran) and mix each sample with its conjugate phasor
+                const int nA = (nold + WP_CK - 1) / WP_CK, nB = (L - nold + WP_CK - 1) / WP_CK;
+                const int per_tone = nA + nB;
+                for (int w = t; w < M * per_tone; w += WP_DSP_THREADS) {
+                    const int m = w / per_tone, c = w - m * per_tone;
+                    const bool segB = c >= nA;
+                    const int cc = segB ? c - nA : c;
+                    const int s0 = segB ? nold + cc * WP_CK : cc * WP_CK;
+                    const int send = segB ? L : nold;
+                    const int cnt = (send - s0) < WP_CK ? (send - s0) : WP_CK;
+                    const float2 dd = CKD[((kf & 1) * 2 + (segB ? 1 : 0)) * M + m];
+                    const v2f d = {dd.x, dd.y};
+                    v2f phi = ((const v2f *)(CKb + (((kf & 1) * 2 + (segB ? 1 : 0)) * M + m) * WP_CKROW))[cc];
+                    float2 *row = PH + m * Lpad + s0;
+                    float2 x[WP_CK];
 #pragma unroll
-            for (int m = 0; m < M; m++) {
-                float2 *row = PH + m * Lpad;
-                for (int s = t; s < L; s += WP_DSP_THREADS) {
-                    const float2 x = XR[RIDX(src0 + s)];
-                    const float2 p = row[s];
-                    row[s] = cmul(x, make_float2(p.x, -p.y));
-                }
-            }
-            dsp_barrier(&CT[CT_CNT], 6 * (++dsp_phase), lane);
-            // ---- integrate-and-dump, slot order (fsk.c:829-840) -----------------------------------
-            for (int i = t; i < NI; i += WP_DSP_THREADS) {
-                const int base = i * q;
-                const int r = base % Ts;
-                int o = (r == 0) ? 0 : Ts - r;
-                v2f acc[M];
+                    for (int u = 0; u < WP_CK; u++) x[u] = XR[RIDX(src0 + s0 + (u < cnt ? u : 0))];
 #pragma unroll
-                for (int m = 0; m < M; m++) acc[m] = (v2f){0.f, 0.f};
-                for (int j0 = 0; j0 < Ts; j0 += 8) {
-                    v2f v[M][8];
-                    int oo = o;
-#pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        const int idx = (j0 + u < Ts) ? base + oo : base;
-#pragma unroll
-                        for (int m = 0; m < M; m++) v[m][u] = ((const v2f *)PH)[m * Lpad + idx];
-                        oo++;
-                        if (oo == Ts) oo = 0;
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        if (j0 + u < Ts) {
-#pragma unroll
-                            for (int m = 0; m < M; m++) acc[m] = acc[m] + v[m][u];
+                    for (int u = 0; u < WP_CK; u++) {
+                        if (u < cnt) {
+                            row[u] = cmul(x[u], make_float2(phi.x, -phi.y));
+                            phi = cmul_pk(phi, d);
                         }
                     }
-                    o = oo;
                 }
-#pragma unroll
-                for (int m = 0; m < M; m++) FI[m * NI + i] = make_float2(acc[m].x, acc[m].y);
             }
+            PSUB(1);
             dsp_barrier(&CT[CT_CNT], 6 * (++dsp_phase), lane);
+            PSUB(2);
+            // ---- integrate-and-dump, slot order (fsk.c:829-840) -----------------------------------
+            {
+                // one row per (tone, output): sum the Ts circular-buffer slots in slot order, loads first
+                auto integrate_row = [&](int m, int i, auto TSC) {
+                    constexpr int TS = decltype(TSC)::value;             // 0 = runtime Ts
+                    const int ts = TS ? TS : Ts;
+                    const int base = i * q;
+                    const int r = base % ts;
+                    int o = (r == 0) ? 0 : ts - r;
+                    const v2f *row = (const v2f *)PH + m * Lpad + base;
+                    v2f acc = {0.f, 0.f};
+                    if (TS) {
+                        v2f v[TS ? TS : 1];
+#pragma unroll
+                        for (int u = 0; u < TS; u++) { v[u] = row[o]; o++; if (o == ts) o = 0; }
+#pragma unroll
+                        for (int u = 0; u < TS; u++) acc = acc + v[u];
+                    } else {
+                        for (int j0 = 0; j0 < ts; j0 += 8) {
+                            v2f v[8];
+#pragma unroll
+                            for (int u = 0; u < 8; u++) { v[u] = row[(j0 + u < ts) ? o : 0]; if (j0 + u < ts) { o++; if (o == ts) o = 0; } }
+#pragma unroll
+                            for (int u = 0; u < 8; u++) if (j0 + u < ts) acc = acc + v[u];
+                        }
+                    }
+                    FI[m * NI + i] = make_float2(acc.x, acc.y);
+                };
+                for (int w = t; w < M * NI; w += WP_DSP_THREADS) {
+                    const int m = w / NI, i = w - m * NI;
+                    if (Ts == 10) integrate_row(m, i, std::integral_constant<int, 10>());
+                    else if (Ts == 8) integrate_row(m, i, std::integral_constant<int, 8>());
+                    else integrate_row(m, i, std::integral_constant<int, 0>());
+                }
+            }
+            PSUB(3);
+            dsp_barrier(&CT[CT_CNT], 6 * (++dsp_phase), lane);
+            PSUB(4);
             // ---- timing products (fsk.c:862-870); the mixed samples are dead, reuse their rows ------
             float2 *TP = PH;
             for (int i = t; i < NI; i += WP_DSP_THREADS) {
@@ -336,7 +389,10 @@ __global__ __launch_bounds__(WP_THREADS) void wenet_demod_pipe_kernel(WrDemodCfg
                 const float2 pf = pft_t[i];
                 TP[i] = make_float2(ft1 * pf.x, ft1 * pf.y);
             }
+            PSUB(5);
             dsp_barrier(&CT[CT_CNT], 6 * (++dsp_phase), lane);
+            PSUB(6);
+            if (PROF) pr_d += (long long)__builtin_readcyclecounter() - pr_t0;
 
             if (wave == 2) {
                 // ---- T(k): ordered sum, timing, nin, decisions (fsk.c:870-993) ----------------------
@@ -365,6 +421,7 @@ __global__ __launch_bounds__(WP_THREADS) void wenet_demod_pipe_kernel(WrDemodCfg
                     tcr = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(acc.x)));
                     tci = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(acc.y)));
                 }
+                PSUB(7);
                 int nin_next = nin;
                 float tr_mean = 0.f, tr_std = 0.f, tr_rxt = 0.f;
                 const bool nan_frame = (tcr != tcr) || (tci != tci);     // fsk.c:878-880
@@ -460,6 +517,7 @@ __global__ __launch_bounds__(WP_THREADS) void wenet_demod_pipe_kernel(WrDemodCfg
                     }
                 }
                 wave_sync();
+                PSUB(8);
                 if (C.sd_out) {
                     float *so = C.sd_out + frames * Nbits;
                     for (int i = lane; i < Nbits; i += 64) so[i] = SDL[i];
@@ -476,13 +534,17 @@ __global__ __launch_bounds__(WP_THREADS) void wenet_demod_pipe_kernel(WrDemodCfg
                     tr[WR_TR_RXT] = tr_rxt;
                 }
                 if (lane == 0) CT[CT_NIN_NEXT] = nin_next;
+                PSUB(9);
             }
+            if (PROF) pr_busy += (long long)__builtin_readcyclecounter() - pr_t0;
         }
         lds_barrier();
+        if (PROF) pr_iter += (long long)__builtin_readcyclecounter() - pr_t0;
         // ---- commit frame k; verify the speculation nin(k+1) == N ----------------------------------
         const int nin_next = __builtin_amdgcn_readfirstlane(CT[CT_NIN_NEXT]);
         const long long off_next = off + nin;
         if (wave >= 2) filled += nin;
+        if (PROF && nin_next != N) pr_redo++;
         if (nin_next != N) {
             // E(k+1) and C(k+1) were computed for the wrong window length / nold, E(k+2) at the wrong offset:
             // re-run them from the state of frame k, which the rings still hold.
@@ -498,6 +560,14 @@ __global__ __launch_bounds__(WP_THREADS) void wenet_demod_pipe_kernel(WrDemodCfg
         kf++;
     }
 
+    if (PROF && C.prof && lane == 0) {
+        // [0] chain busy  [1] estimator busy  [2] T-wave busy (D+T)  [3] D part (to the last D barrier)
+        // [4] iteration total  [5] mispredictions  [6] frames
+        if (wave == 0) C.prof[0] = pr_busy;
+        if (wave == 1) C.prof[1] = pr_busy;
+        if (wave == 2) { C.prof[2] = pr_busy; C.prof[3] = pr_d; C.prof[4] = pr_iter; C.prof[5] = pr_redo; C.prof[6] = frames;
+                         if (C.prof2) for (int k = 0; k < 10; k++) C.prof2[k] = pr_sub[k]; }
+    }
     // ================================ save carried state =======================================
     lds_barrier();
     if (frames > 0) {
@@ -519,15 +589,17 @@ __global__ __launch_bounds__(WP_THREADS) void wenet_demod_pipe_kernel(WrDemodCfg
 #undef RIDX
 }
 
-extern "C" hipError_t wr_launch_demod_pipe(const WrDemodCfg *cfg, const WrChan *d_chans, int nchan, hipStream_t stream) {
+extern "C" hipError_t wr_launch_demod_pipe(const WrDemodCfg *cfg, const WrChan *d_chans, int nchan, hipStream_t stream, int prof) {
     if (nchan <= 0) return hipSuccess;
     dim3 grid(nchan), block(WP_THREADS);
-    if (cfg->M == 2) {
-        (void)hipFuncSetAttribute((const void *)wenet_demod_pipe_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, cfg->p_lds_bytes);
-        hipLaunchKernelGGL(wenet_demod_pipe_kernel<2>, grid, block, cfg->p_lds_bytes, stream, *cfg, d_chans, nchan);
-    } else {
-        (void)hipFuncSetAttribute((const void *)wenet_demod_pipe_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, cfg->p_lds_bytes);
-        hipLaunchKernelGGL(wenet_demod_pipe_kernel<4>, grid, block, cfg->p_lds_bytes, stream, *cfg, d_chans, nchan);
-    }
+#define WP_LAUNCH(MM, PP)                                                                                                    \
+    do {                                                                                                                     \
+        (void)hipFuncSetAttribute((const void *)wenet_demod_pipe_kernel<MM, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  cfg->p_lds_bytes);                                                                          \
+        hipLaunchKernelGGL((wenet_demod_pipe_kernel<MM, PP>), grid, block, cfg->p_lds_bytes, stream, *cfg, d_chans, nchan);   \
+    } while (0)
+    if (cfg->M == 2) { if (prof) WP_LAUNCH(2, true); else WP_LAUNCH(2, false); }
+    else             { if (prof) WP_LAUNCH(4, true); else WP_LAUNCH(4, false); }
+#undef WP_LAUNCH
     return hipGetLastError();
 }

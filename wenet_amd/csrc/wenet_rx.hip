@@ -23,7 +23,7 @@
 #pragma clang fp contract(off)
 
 extern "C" hipError_t wr_launch_demod(const WrDemodCfg *cfg, const WrChan *d_chans, int nchan, hipStream_t stream);
-extern "C" hipError_t wr_launch_demod_pipe(const WrDemodCfg *cfg, const WrChan *d_chans, int nchan, hipStream_t stream);
+extern "C" hipError_t wr_launch_demod_pipe(const WrDemodCfg *cfg, const WrChan *d_chans, int nchan, hipStream_t stream, int prof);
 extern "C" hipError_t wr_launch_demod_ex(const WrDemodCfg *cfg, const WrChan *d_chans, int nchan, hipStream_t stream, int prof);
 extern "C" hipError_t wr_launch_deframe(const WrDeframeChan *d_chans, int nchan, int mode, hipStream_t stream);
 extern "C" hipError_t wr_launch_decode(const WrDecodeArgs *args, hipStream_t stream);
@@ -211,7 +211,9 @@ struct DemodTables {
             int t = 0;
             cfg.p_ring = ring;
             cfg.p_off_XR = t;   t = align16(t + ring * 8);
-            cfg.p_off_PH = t;   t = align16(t + 2 * M * cfg.Lpad * 8);
+            cfg.p_off_PH = t;   t = align16(t + M * cfg.Lpad * 8);
+            cfg.p_off_CK = t;   t = align16(t + 2 * 2 * M * 80 * 8);      // WP_CKROW = 80
+            cfg.p_off_CKD = t;  t = align16(t + 2 * 2 * M * 8);
             cfg.p_off_FI = t;   t = align16(t + M * cfg.NI * 8);
             cfg.p_off_FB = t;   t = align16(t + Ndft * 8);
             cfg.p_off_FE = t;   t = align16(t + 3 * NH * 4);
@@ -226,7 +228,7 @@ struct DemodTables {
             cfg.p_off_PFT = t;  t = align16(t + cfg.NI * 8);
             cfg.p_off_DPHI = t; t = align16(t + NH * 8);
             cfg.p_lds_bytes = t;
-            cfg.pipe_ok = (Nmax <= 2 * 384 && t <= 80 * 1024 && getenv("WENET_RX_NO_PIPE") == nullptr) ? 1 : 0;
+            cfg.pipe_ok = (Nmax <= 2 * 384 && cfg.L / 8 + 2 <= 80 && t <= 80 * 1024 && getenv("WENET_RX_NO_PIPE") == nullptr) ? 1 : 0;
         }
         cfg.lds_bytes = o;
         if (o > 160 * 1024) { fprintf(stderr, "libwenet_rx: configuration needs %d bytes of LDS (>160 KiB)\n", o); return false; }
@@ -764,7 +766,7 @@ extern "C" int wenet_rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw,
     if (rx->want_trace && !rx->d_trace.reserve((size_t)(rx->sd_off[nchan] / c.Nbits) * WR_TRACE_FLOATS * 4)) return -2;
     if (rx->want_llr && !rx->d_llr.reserve((size_t)nchan * max_pk * WR_NCODE * 4)) return -2;
     rx->profile = getenv("WENET_RX_PROFILE") != nullptr;
-    if (rx->profile && !rx->d_prof.reserve((size_t)nchan * 16 * 8)) return -2;
+    if (rx->profile && !rx->d_prof.reserve((size_t)nchan * 32 * 8)) return -2;
     // fresh modem + deframer state per capture
     std::vector<float> st0;
     rx->tab.init_state(st0);
@@ -782,7 +784,8 @@ extern "C" int wenet_rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw,
         ch.sd_out = rx->d_sd.as<float>() + rx->sd_off[i];
         ch.cap_frames = rx->cap_frames[i];
         ch.trace = rx->want_trace ? rx->d_trace.as<float>() + (rx->sd_off[i] / c.Nbits) * WR_TRACE_FLOATS : nullptr;
-        ch.prof = rx->profile ? rx->d_prof.as<long long>() + (size_t)i * 16 : nullptr;
+        ch.prof = rx->profile ? rx->d_prof.as<long long>() + (size_t)i * 32 : nullptr;
+        ch.prof2 = rx->profile ? rx->d_prof.as<long long>() + (size_t)i * 32 + 16 : nullptr;
         WrDeframeChan &d = dch[i];
         memset(&d, 0, sizeof(d));
         d.sd = ch.sd_out;
@@ -804,7 +807,7 @@ extern "C" int wenet_rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw,
     a.llr_out = rx->want_llr ? rx->d_llr.as<float>() : nullptr;
     fill_decode_tables(a, t);
     WR_CHECK(hipEventRecord(rx->ev[0], stream), -4);
-    WR_CHECK(wr_launch_demod_ex(&rx->tab.cfg, rx->d_chans.as<WrChan>(), nchan, stream, rx->profile ? 1 : 0), -4);
+    WR_CHECK(wr_launch_demod_ex(&rx->tab.cfg, rx->d_chans.as<WrChan>(), nchan, stream, rx->profile ? (getenv("WENET_RX_PROFILE")[0] == '2' ? 2 : 1) : 0), -4);
     WR_CHECK(hipEventRecord(rx->ev[1], stream), -4);
     WR_CHECK(wr_launch_deframe(rx->d_dchans.as<WrDeframeChan>(), nchan, rx->mode, stream), -4);
     WR_CHECK(hipEventRecord(rx->ev[2], stream), -4);
@@ -909,8 +912,8 @@ extern "C" float wenet_rx_last_ms(wenet_rx *rx, int what) {
 // enqueue when WENET_RX_PROFILE was set; returns the number of counters
 extern "C" int wenet_rx_debug_profile(wenet_rx *rx, int ch, long long *out12) {
     if (!rx || !rx->profile || ch < 0 || ch >= rx->nchan) return 0;
-    if (hipMemcpy(out12, rx->d_prof.as<long long>() + (size_t)ch * 16, 12 * 8, hipMemcpyDeviceToHost) != hipSuccess) return 0;
-    return 12;
+    if (hipMemcpy(out12, rx->d_prof.as<long long>() + (size_t)ch * 32, 26 * 8, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return 26;
 }
 
 extern "C" int wenet_rx_device_info(int what) {
