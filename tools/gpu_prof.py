@@ -26,7 +26,7 @@ p = np.zeros(26, np.int64)
 L.wenet_rx_debug_profile(rx._h, 0, p.ctypes.data)
 fr = rx.frames(0)
 if os.environ["WENET_RX_PROFILE"] == "1":
-    n7 = ["chain busy", "estimator busy", "T-wave busy (D+T)", "D part", "iteration total", "mispredictions", "frames"]
+    n7 = ["chain busy", "estimator busy", "T busy", "D busy (wave 3)", "iteration total", "mispredictions", "frames"]
     print(f"{name} B={B} frames={fr} demod_ms={rx.last_ms(0):.2f} us/frame={rx.last_ms(0)*1e3/fr:.2f} (pipelined kernel)")
     for n, v in zip(n7, p):
         print(f"  {n:20s} {v/fr:10.1f} per frame")

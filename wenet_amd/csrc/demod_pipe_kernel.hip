@@ -6,19 +6,20 @@
 // The chain and the timing sum are float recurrences that must run in reference order (bit-exactness),
 // so the only way to go faster on ONE capture is to overlap the stages of neighbouring frames:
 //
-//     wave 0      C(k+1)   NCO phasor chain of the NEXT frame            (fsk.c:756-764,781-824)
-//     wave 1      E(k+2)   tone estimator two frames ahead                (fsk.c:540-677)
-//     waves 2-7   D(k)     sample staging, down-conversion, integrate-and-dump, timing products
+//     wave 1      E(k+3)   tone estimator three frames ahead             (fsk.c:540-677)
+//     wave 0      C(k+2)   NCO phasor chain two frames ahead (checkpoints) (fsk.c:756-764,781-824)
+//     waves 3-7   D(k+1)   sample staging, chain replay + down-conversion, integrate-and-dump, timing products
 //     wave 2      T(k)     ordered timing sum, atan2f, nin, resample/decide, soft decisions out (fsk.c:858-993)
 //
-// C(k+1) and E(k+2) need nin(k+1), which only T(k) produces; they run SPECULATIVELY with nin = N (true for
-// >99 % of frames on a locked signal).  Every stage keeps its carried state in small rings (spectrum x3,
-// NCO phase x3, tone bins x4, phasor rows x2, samples in a 4-frame ring), so when T(k) reports nin(k+1) != N
-// the two speculative stages are simply re-run from the untouched state of frame k.  Results are
-// bit-identical to the sequential kernel (demod_kernel.hip) and hence to the reference.
+// E, C and D of later frames need nin(k+1), which only T(k) produces; they run SPECULATIVELY with nin = N
+// (true for >99 % of frames on a locked signal).  Every stage keeps its carried state in small rings
+// (spectrum x4, NCO phase x3, tone bins x4, checkpoints x2, integrator outputs / timing products x2, samples in a
+// 5-frame ring), so when T(k) reports nin(k+1) != N the speculative stages are simply re-run from the
+// untouched state of frame k.  Results are bit-identical to the sequential kernel (demod_kernel.hip) and
+// hence to the reference.
 //
-// Synchronisation: one workgroup barrier per frame; the six D waves meet at LDS-counter barriers so that
-// waves 0/1 are never stalled inside their long serial loops.
+// Synchronisation: one workgroup barrier per frame; the five D waves meet at LDS-counter barriers so that
+// the other waves are never stalled inside their long serial loops.
 #include <type_traits>
 
 #include "demod_common.h"
@@ -26,8 +27,9 @@
 #pragma clang fp contract(off)
 
 #define WP_THREADS 512
-#define WP_DSP_THREADS 384          // waves 2..7
-#define WP_KP 2                     // raw samples prefetched per D thread (2*384 >= N+Ts/2 is required)
+#define WP_DSP_THREADS 320          // waves 3..7
+#define WP_KP 2                     // raw samples prefetched per D thread (2*320 >= N+Ts/2 is required)
+#define WP_DSP_WAVES 5
 #define WP_CK 8                     // the chain wave stores every WP_CK-th phasor; D threads replay the steps in between
 #define WP_CKROW 80                 // checkpoints per (segment, tone) row; needs >= (Nmem-Ts/P)/WP_CK + 2
 
@@ -62,9 +64,10 @@ __global__ __launch_bounds__(WP_THREADS) void wenet_demod_pipe_kernel(WrDemodCfg
     float2 *DCb = (float2 *)(smem + cfg.p_off_PH);    // [M][Lpad]     mixed samples -> timing products
     float2 *CKb = (float2 *)(smem + cfg.p_off_CK);    // [2 frames][2 segments][M][WP_CKROW] phasor checkpoints
     float2 *CKD = (float2 *)(smem + cfg.p_off_CKD);   // [2 frames][2 segments][M] NCO step of each segment
-    float2 *FI = (float2 *)(smem + cfg.p_off_FI);     // [M][NI]
+    float2 *FIb = (float2 *)(smem + cfg.p_off_FI);    // [2][M][NI]    integrator outputs of frame j in slot j&1
+    float2 *TPb = (float2 *)(smem + cfg.p_off_TP);    // [2][NI]       timing products of frame j in slot j&1
     float2 *FB = (float2 *)(smem + cfg.p_off_FB);     // [Ndft]
-    float  *FEr = (float *)(smem + cfg.p_off_FE);     // [3][Ndft/2]   smoothed spectrum after frame j in slot j%3
+    float  *FEr = (float *)(smem + cfg.p_off_FE);     // [4][Ndft/2]   smoothed spectrum after frame j in slot j&3
     float  *FW = (float *)(smem + cfg.p_off_FW);      // [Ndft/2]
     float  *SDL = (float *)(smem + cfg.p_off_SD);     // [Nbits]
     float  *SC = (float *)(smem + cfg.p_off_SC);      // scratch (Eb/N0)
@@ -95,29 +98,26 @@ __global__ __launch_bounds__(WP_THREADS) void wenet_demod_pipe_kernel(WrDemodCfg
         for (int i = tid; i < NI; i += WP_THREADS) pft_w[i] = cfg.phi_ft[i];
         for (int i = tid; i < NH; i += WP_THREADS) dphi_w[i] = cfg.dphi_tab[i];
     }
-    for (int i = tid; i < NH; i += WP_THREADS) FEr[2 * NH + i] = st_fft[i];           // "after frame -1" lives in slot 2
+    for (int i = tid; i < NH; i += WP_THREADS) FEr[3 * NH + i] = st_fft[i];           // "after frame -1" lives in slot 3
     for (int i = tid; i < Nbits; i += WP_THREADS) SDL[i] = st_sd[i];
     for (int i = tid; i < nstash; i += WP_THREADS) XR[RIDX((long long)(i - nstash))] = st_old[i];
     if (tid < M) { PHE[2 * 4 + tid] = hdr->phi_c[tid]; CT[CT_FBIN + 3 * 4 + tid] = hdr->f_bin[tid]; }   // frame -1 -> slots 2 / 3
     if (tid == 0) { CT[CT_CNT] = 0; CT[CT_NIN_NEXT] = hdr->nin; }
     int nin = __builtin_amdgcn_readfirstlane(hdr->nin);
-    // first 3*Nmax samples into the ring
+    // first 4*Nmax samples into the ring
     {
         const long long last = C.nsamples - 1;
-        for (long long i = tid; i < 3LL * Nmax; i += WP_THREADS)
+        for (long long i = tid; i < 4LL * Nmax; i += WP_THREADS)
             XR[RIDX(i)] = (C.nsamples > 0) ? load_sample(C.raw, C.fmt, i < last ? i : last) : make_float2(0.f, 0.f);
     }
-    long long filled = 3LL * Nmax;                    // ring holds absolute samples [off - nstash, filled)
-    // T-wave private carried scalars
-    float norm_rx_timing_st = hdr->norm_rx_timing;
-    float ppm = hdr->ppm;
+    long long filled = 4LL * Nmax;                    // ring holds absolute samples [off - nstash, filled)
     lds_barrier();
 
     // ================================ stage bodies ============================================
     // E(j): tone estimator of frame j.  One wavefront.  slot_in/out index the spectrum ring.
     auto estimate = [&](int j, long long off_j, int nin_j) {
-        const float *FEin = FEr + ((j + 2) % 3) * NH;          // after frame j-1
-        float *FEout = FEr + (j % 3) * NH;
+        const float *FEin = FEr + ((j + 3) & 3) * NH;          // after frame j-1
+        float *FEout = FEr + (j & 3) * NH;
         const int fft_loops = nin_j / Ndft;
         for (int jl = 0; jl < fft_loops; jl++) {
             const int samps = nin_j - (jl + 1) * Ndft;                  // fsk.c:583
@@ -258,321 +258,324 @@ __global__ __launch_bounds__(WP_THREADS) void wenet_demod_pipe_kernel(WrDemodCfg
         wave_sync();
     };
 
+    // D(j): mix + integrate + timing products of frame j.  Waves 3..7 (t = D thread index).
+    const int t = tid - 192;
+    int dsp_phase = 0;
+    auto dstage = [&](int j, long long off_j, int nin_j) {
+        const int nold = Nmem - nin_j;
+        float2 *PH = DCb;
+        float2 *FI = FIb + (j & 1) * M * NI;
+        float2 *TP = TPb + (j & 1) * NI;
+        const long long src0 = off_j - nold;                             // chain step s <-> absolute sample src0 + s
+        {
+            // one D thread per (tone, checkpoint): replay the <= WP_CK chain steps that follow the checkpoint
+            // (the same cmul_pk sequence the chain wave ran) and mix each sample with its conjugate phasor
+            const int nA = (nold + WP_CK - 1) / WP_CK, nB = (L - nold + WP_CK - 1) / WP_CK;
+            const int per_tone = nA + nB;
+            for (int w = t; w < M * per_tone; w += WP_DSP_THREADS) {
+                const int m = w / per_tone, c = w - m * per_tone;
+                const bool segB = c >= nA;
+                const int cc = segB ? c - nA : c;
+                const int s0 = segB ? nold + cc * WP_CK : cc * WP_CK;
+                const int send = segB ? L : nold;
+                const int cnt = (send - s0) < WP_CK ? (send - s0) : WP_CK;
+                const float2 dd = CKD[((j & 1) * 2 + (segB ? 1 : 0)) * M + m];
+                const v2f d = {dd.x, dd.y};
+                v2f phi = ((const v2f *)(CKb + (((j & 1) * 2 + (segB ? 1 : 0)) * M + m) * WP_CKROW))[cc];
+                float2 *row = PH + m * Lpad + s0;
+                float2 x[WP_CK];
+#pragma unroll
+                for (int u = 0; u < WP_CK; u++) x[u] = XR[RIDX(src0 + s0 + (u < cnt ? u : 0))];
+#pragma unroll
+                for (int u = 0; u < WP_CK; u++) {
+                    if (u < cnt) {
+                        row[u] = cmul(x[u], make_float2(phi.x, -phi.y));
+                        phi = cmul_pk(phi, d);
+                    }
+                }
+            }
+        }
+        dsp_barrier(&CT[CT_CNT], WP_DSP_WAVES * (++dsp_phase), lane);
+        {
+            // one row per (tone, output): sum the Ts circular-buffer slots in slot order (fsk.c:829-840), loads first
+            auto integrate_row = [&](int m, int i, auto TSC) {
+                constexpr int TS = decltype(TSC)::value;                 // 0 = runtime Ts
+                const int ts = TS ? TS : Ts;
+                const int base = i * q;
+                const int r = base % ts;
+                int o = (r == 0) ? 0 : ts - r;
+                const v2f *row = (const v2f *)PH + m * Lpad + base;
+                v2f acc = {0.f, 0.f};
+                if (TS) {
+                    v2f v[TS ? TS : 1];
+#pragma unroll
+                    for (int u = 0; u < TS; u++) { v[u] = row[o]; o++; if (o == ts) o = 0; }
+#pragma unroll
+                    for (int u = 0; u < TS; u++) acc = acc + v[u];
+                } else {
+                    for (int j0 = 0; j0 < ts; j0 += 8) {
+                        v2f v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) { v[u] = row[(j0 + u < ts) ? o : 0]; if (j0 + u < ts) { o++; if (o == ts) o = 0; } }
+#pragma unroll
+                        for (int u = 0; u < 8; u++) if (j0 + u < ts) acc = acc + v[u];
+                    }
+                }
+                FI[m * NI + i] = make_float2(acc.x, acc.y);
+            };
+            for (int w = t; w < M * NI; w += WP_DSP_THREADS) {
+                const int m = w / NI, i = w - m * NI;
+                if (Ts == 10) integrate_row(m, i, std::integral_constant<int, 10>());
+                else if (Ts == 8) integrate_row(m, i, std::integral_constant<int, 8>());
+                else integrate_row(m, i, std::integral_constant<int, 0>());
+            }
+        }
+        dsp_barrier(&CT[CT_CNT], WP_DSP_WAVES * (++dsp_phase), lane);
+        for (int i = t; i < NI; i += WP_DSP_THREADS) {                   // timing products (fsk.c:862-870)
+            float ft1 = 0.f;
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                const float2 v = FI[m * NI + i];
+                ft1 += (v.x * v.x) + (v.y * v.y);
+            }
+            const float2 pf = pft_t[i];
+            TP[i] = make_float2(ft1 * pf.x, ft1 * pf.y);
+        }
+        wave_sync();
+    };
+
+    // T(k): ordered sum, timing, nin, decisions (fsk.c:870-993).  Wave 2.  kf = frame index in this launch.
+    float norm_rx_timing_st = hdr->norm_rx_timing;                       // T-wave private carried scalars
+    float ppm = hdr->ppm;
+    auto tstage = [&](int kf, long long frames, int nin_cur) {
+        const float2 *FI = FIb + (kf & 1) * M * NI;
+        const float2 *TP = TPb + (kf & 1) * NI;
+        float tcr, tci;
+        {
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            const v4f *TP4 = (const v4f *)TP;
+            v2f acc = {0.f, 0.f};
+            v4f cur[4], nxt[4];
+            int i = 0;
+            if (NI >= 8) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) cur[u] = TP4[u];
+                for (i = 8; i + 8 <= NI; i += 8) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) nxt[u] = TP4[(i >> 1) + u];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { acc = acc + cur[u].xy; acc = acc + cur[u].zw; }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) cur[u] = nxt[u];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) { acc = acc + cur[u].xy; acc = acc + cur[u].zw; }
+            }
+            for (; i < NI; i++) { const float2 v = TP[i]; acc = acc + (v2f){v.x, v.y}; }
+            tcr = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(acc.x)));
+            tci = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(acc.y)));
+        }
+        int nin_next = nin_cur;
+        float tr_mean = 0.f, tr_std = 0.f, tr_rxt = 0.f;
+        const bool nan_frame = (tcr != tcr) || (tci != tci);             // fsk.c:878-880
+        if (!nan_frame) {
+            const float at = wg_atan2f(tci, tcr);
+            const float norm_rx_timing = (float)((double)at / (2 * 3.14159265358979323846));
+            const float rx_timing = norm_rx_timing * cfg.P_f;
+            const float d_nrt = norm_rx_timing - norm_rx_timing_st;
+            norm_rx_timing_st = norm_rx_timing;
+            if ((double)fabsf(d_nrt) < .2) {
+                const float appm = (float)(1e6 * (double)d_nrt / (double)cfg.nsym_f);
+                ppm = (float)(.9 * (double)ppm + .1 * (double)appm);
+            }
+            if (norm_rx_timing > 0.25f) nin_next = N + Ts / 2;
+            else if (norm_rx_timing < -0.25f) nin_next = N - Ts / 2;
+            else nin_next = N;
+            nin_next = __builtin_amdgcn_readfirstlane(nin_next);
+            if (lane == 0) CT[CT_NIN_NEXT] = nin_next;                   // published early; read after the frame barrier
+            const int low_sample = (int)floorf(rx_timing);
+            const float fract = rx_timing - (float)low_sample;
+            const int high_sample = (int)ceilf(rx_timing);
+            const float omf = 1 - fract;
+            tr_rxt = rx_timing;
+            float mymax = 0.f;
+            if (lane < WR_NSYM) {
+                const int st = (lane + 1) * P;
+                float tmax[M];
+#pragma unroll
+                for (int m = 0; m < M; m++) {
+                    const float2 a = FI[m * NI + st + low_sample];
+                    const float2 b = FI[m * NI + st + high_sample];
+                    float tr = omf * a.x, ti = omf * a.y;
+                    tr = tr + fract * b.x;
+                    ti = ti + fract * b.y;
+                    tmax[m] = (tr * tr) + (ti * ti);
+                }
+                float mx = tmax[0];
+                int sym = 0;
+#pragma unroll
+                for (int m = 0; m < M; m++) if (tmax[m] > mx) { mx = tmax[m]; sym = m; }
+                mymax = mx;
+                if (C.bits_out) {
+                    uint8_t *bo = C.bits_out + frames * Nbits;
+                    if (M == 2) bo[lane] = (uint8_t)(sym == 1);
+                    else { bo[lane * 2 + 1] = (uint8_t)(sym & 1); bo[lane * 2] = (uint8_t)((sym & 2) >> 1); }
+                }
+#pragma unroll
+                for (int m = 0; m < M; m++) tmax[m] = sqrtf(tmax[m]);
+                if (M == 2) {
+                    SDL[lane] = tmax[0] - tmax[1];
+                } else {
+                    float s1 = -tmax[0], s0 = -tmax[0];
+                    s1 += tmax[1 % M];  s0 += -tmax[1 % M];
+                    s1 += -tmax[2 % M]; s0 += tmax[2 % M];
+                    s1 += tmax[3 % M];  s0 += tmax[3 % M];
+                    SDL[lane * 2 + 1] = s1;
+                    SDL[lane * 2] = s0;
+                }
+            }
+            if (cfg.stats) {
+                if (lane < WR_NSYM) { SC[lane] = mymax; SC[WR_NSYM + lane] = sqrtf(mymax); }
+                wave_sync();
+                if (lane == 0) {
+                    float stdebno = 0.f, meanebno = 0.f;
+                    for (int i = 0; i < WR_NSYM; i++) { stdebno += SC[i]; meanebno += SC[WR_NSYM + i]; }
+                    meanebno = meanebno / cfg.nsym_f;
+                    stdebno = (stdebno / cfg.nsym_f) - (meanebno * meanebno);
+                    if ((double)stdebno > 0.0) stdebno = (float)sqrt((double)stdebno); else stdebno = 0.0f;
+                    SC[2 * WR_NSYM] = meanebno;
+                    SC[2 * WR_NSYM + 1] = stdebno;
+                }
+                wave_sync();
+                tr_mean = SC[2 * WR_NSYM];
+                tr_std = SC[2 * WR_NSYM + 1];
+            }
+            if (C.dump && frames >= C.dump_first && ((frames - C.dump_first) % C.dump_period) == 0) {
+                const long long slot = (frames - C.dump_first) / C.dump_period;
+                if (slot < C.dump_cap) {
+                    float *d = C.dump + slot * cfg.dump_floats;
+                    const float *FEk = FEr + (kf & 3) * NH;
+                    const int neye = cfg.eye_traces * M * cfg.neyesamp;
+                    for (int e = lane; e < neye; e += 64) {
+                        const int j = e % cfg.neyesamp;
+                        const int tm = e / cfg.neyesamp;
+                        const int i = tm / M, m = tm - i * M;
+                        const int ind = 2 * P * i + (high_sample + 1) + j * cfg.eye_dec;
+                        float v = 0.f;
+                        if (ind >= 0 && ind < NI) { const float2 f = FI[m * NI + ind]; v = sqrtf(f.x * f.x + f.y * f.y); }
+                        d[e] = v;
+                    }
+                    for (int i = lane; i < NH; i += 64) d[neye + i] = FEk[i];
+                    if (lane == 0) { d[neye + NH] = (float)high_sample; d[neye + NH + 1] = (float)frames; }
+                }
+            }
+        } else if (lane == 0) {
+            CT[CT_NIN_NEXT] = nin_next;
+        }
+        wave_sync();
+        if (C.sd_out) {
+            float *so = C.sd_out + frames * Nbits;
+            for (int i = lane; i < Nbits; i += 64) so[i] = SDL[i];
+        }
+        if (C.trace && lane == 0) {
+            float *tr = C.trace + frames * WR_TRACE_FLOATS;
+#pragma unroll
+            for (int m = 0; m < WR_M_MAX; m++) tr[WR_TR_FEST + m] = (m < M) ? cfg.bin_freq[CT[CT_FBIN + (kf & 3) * 4 + (m < M ? m : 0)]] : 0.f;
+            tr[WR_TR_NIN] = (float)nin_next;
+            tr[WR_TR_NRT] = norm_rx_timing_st;
+            tr[WR_TR_PPM] = ppm;
+            tr[WR_TR_MEAN] = tr_mean;
+            tr[WR_TR_STD] = tr_std;
+            tr[WR_TR_RXT] = tr_rxt;
+        }
+    };
+
     // ================================ pipeline prologue ========================================
+    //   E(0) | C(0),E(1) | D(0),C(1),E(2)         (frame 0 with the true nin, later frames speculative)
     long long off = 0, frames = 0;
     const bool any = (off + nin <= C.nsamples) && (C.cap_frames > 0);
     if (any) {
-        if (wave == 1) estimate(0, 0, nin);                              // E(0), true nin
+        if (wave == 1) estimate(0, 0, nin);
         lds_barrier();
-        if (wave == 0) chain(0, nin);                                    // C(0), true nin
-        if (wave == 1) estimate(1, (long long)nin, N);                   // E(1), speculative
+        if (wave == 0) chain(0, nin);
+        if (wave == 1) estimate(1, (long long)nin, N);
+        lds_barrier();
+        if (wave == 0) chain(1, N);
+        if (wave == 1) estimate(2, (long long)nin + N, N);
+        if (wave >= 3) dstage(0, 0, nin);
         lds_barrier();
     }
-    // D-thread prefetch registers: samples [filled, filled + 2*384)
-    const int t = tid - 128;                                             // D thread index (waves 2..7)
+    // D-thread prefetch registers: samples [filled, filled + 2*320)
     uint2 pre[WP_KP];
 #pragma unroll
     for (int k = 0; k < WP_KP; k++) pre[k] = make_uint2(0u, 0u);
-    if (any && wave >= 2) {
+    if (any && wave >= 3) {
         const long long last = C.nsamples - 1;
 #pragma unroll
         for (int k = 0; k < WP_KP; k++) { long long i = filled + t + WP_DSP_THREADS * k; pre[k] = load_raw(C.raw, C.fmt, i < last ? i : last); }
     }
-    int dsp_phase = 0;
 
     // ================================ frame loop ===============================================
     int kf = 0;                                                          // frame index within this launch
-    long long pr_busy = 0, pr_d = 0, pr_iter = 0, pr_redo = 0, pr_t0 = 0;     // PROF: per-role busy ticks
-    long long pr_sub[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pr_tl = 0;
-#define PSUB(k) do { if (PROF) { const long long _t = (long long)__builtin_readcyclecounter(); pr_sub[k] += _t - pr_tl; pr_tl = _t; } } while (0)
+    long long pr_busy = 0, pr_iter = 0, pr_redo = 0, pr_t0 = 0;          // PROF: per-role busy ticks
     while (off + nin <= C.nsamples && frames < C.cap_frames) {
-        const int nold = Nmem - nin;
         if (PROF) pr_t0 = (long long)__builtin_readcyclecounter();
+        const long long off1 = off + nin;                                // true start of frame k+1
         if (wave == 0) {
-            chain(kf + 1, N);                                            // C(k+1), speculative nin = N
-            if (PROF) pr_busy += (long long)__builtin_readcyclecounter() - pr_t0;
+            chain(kf + 2, N);                                            // C(k+2), speculative
         } else if (wave == 1) {
-            estimate(kf + 2, off + nin + N, N);                          // E(k+2), speculative
-            if (PROF) pr_busy += (long long)__builtin_readcyclecounter() - pr_t0;
+            estimate(kf + 3, off1 + 2LL * N, N);                         // E(k+3), speculative
+        } else if (wave == 2) {
+            tstage(kf, frames, nin);                                     // T(k)
         } else {
-            if (PROF) pr_tl = pr_t0;
-            // ---- stage the next nin samples into the ring, issue the following prefetch -------------
-            {
+            // stage the next nin samples into the ring, issue the following prefetch
 #pragma unroll
-                for (int k = 0; k < WP_KP; k++) { const int i = t + WP_DSP_THREADS * k; if (i < nin) XR[RIDX(filled + i)] = convert_raw(pre[k], C.fmt); }
+            for (int k = 0; k < WP_KP; k++) { const int i = t + WP_DSP_THREADS * k; if (i < nin) XR[RIDX(filled + i)] = convert_raw(pre[k], C.fmt); }
+            {
                 const long long nf = filled + nin, last = C.nsamples - 1;
 #pragma unroll
                 for (int k = 0; k < WP_KP; k++) { long long i = nf + t + WP_DSP_THREADS * k; pre[k] = load_raw(C.raw, C.fmt, i < last ? i : last); }
             }
-            PSUB(0);
-            // ---- D(k): down-convert in place (fsk.c:791,817) --------------------------------------
-            float2 *PH = DCb;
-            const long long src0 = off - nold;                           // chain step s <-> absolute sample src0 + s
-            {
-                // one D thread per (tone, checkpoint): replay the <= WP_CK chain steps that follow the checkpoint
-                // (the same cmul_pk sequence the chain wave ran) and mix each sample with its conjugate phasor
-                const int nA = (nold + WP_CK - 1) / WP_CK, nB = (L - nold + WP_CK - 1) / WP_CK;
-                const int per_tone = nA + nB;
-                for (int w = t; w < M * per_tone; w += WP_DSP_THREADS) {
-                    const int m = w / per_tone, c = w - m * per_tone;
-                    const bool segB = c >= nA;
-                    const int cc = segB ? c - nA : c;
-                    const int s0 = segB ? nold + cc * WP_CK : cc * WP_CK;
-                    const int send = segB ? L : nold;
-                    const int cnt = (send - s0) < WP_CK ? (send - s0) : WP_CK;
-                    const float2 dd = CKD[((kf & 1) * 2 + (segB ? 1 : 0)) * M + m];
-                    const v2f d = {dd.x, dd.y};
-                    v2f phi = ((const v2f *)(CKb + (((kf & 1) * 2 + (segB ? 1 : 0)) * M + m) * WP_CKROW))[cc];
-                    float2 *row = PH + m * Lpad + s0;
-                    float2 x[WP_CK];
-#pragma unroll
-                    for (int u = 0; u < WP_CK; u++) x[u] = XR[RIDX(src0 + s0 + (u < cnt ? u : 0))];
-#pragma unroll
-                    for (int u = 0; u < WP_CK; u++) {
-                        if (u < cnt) {
-                            row[u] = cmul(x[u], make_float2(phi.x, -phi.y));
-                            phi = cmul_pk(phi, d);
-                        }
-                    }
-                }
-            }
-            PSUB(1);
-            dsp_barrier(&CT[CT_CNT], 6 * (++dsp_phase), lane);
-            PSUB(2);
-            // ---- integrate-and-dump, slot order (fsk.c:829-840) -----------------------------------
-            {
-                // one row per (tone, output): sum the Ts circular-buffer slots in slot order, loads first
-                auto integrate_row = [&](int m, int i, auto TSC) {
-                    constexpr int TS = decltype(TSC)::value;             // 0 = runtime Ts
-                    const int ts = TS ? TS : Ts;
-                    const int base = i * q;
-                    const int r = base % ts;
-                    int o = (r == 0) ? 0 : ts - r;
-                    const v2f *row = (const v2f *)PH + m * Lpad + base;
-                    v2f acc = {0.f, 0.f};
-                    if (TS) {
-                        v2f v[TS ? TS : 1];
-#pragma unroll
-                        for (int u = 0; u < TS; u++) { v[u] = row[o]; o++; if (o == ts) o = 0; }
-#pragma unroll
-                        for (int u = 0; u < TS; u++) acc = acc + v[u];
-                    } else {
-                        for (int j0 = 0; j0 < ts; j0 += 8) {
-                            v2f v[8];
-#pragma unroll
-                            for (int u = 0; u < 8; u++) { v[u] = row[(j0 + u < ts) ? o : 0]; if (j0 + u < ts) { o++; if (o == ts) o = 0; } }
-#pragma unroll
-                            for (int u = 0; u < 8; u++) if (j0 + u < ts) acc = acc + v[u];
-                        }
-                    }
-                    FI[m * NI + i] = make_float2(acc.x, acc.y);
-                };
-                for (int w = t; w < M * NI; w += WP_DSP_THREADS) {
-                    const int m = w / NI, i = w - m * NI;
-                    if (Ts == 10) integrate_row(m, i, std::integral_constant<int, 10>());
-                    else if (Ts == 8) integrate_row(m, i, std::integral_constant<int, 8>());
-                    else integrate_row(m, i, std::integral_constant<int, 0>());
-                }
-            }
-            PSUB(3);
-            dsp_barrier(&CT[CT_CNT], 6 * (++dsp_phase), lane);
-            PSUB(4);
-            // ---- timing products (fsk.c:862-870); the mixed samples are dead, reuse their rows ------
-            float2 *TP = PH;
-            for (int i = t; i < NI; i += WP_DSP_THREADS) {
-                float ft1 = 0.f;
-#pragma unroll
-                for (int m = 0; m < M; m++) {
-                    const float2 v = FI[m * NI + i];
-                    ft1 += (v.x * v.x) + (v.y * v.y);
-                }
-                const float2 pf = pft_t[i];
-                TP[i] = make_float2(ft1 * pf.x, ft1 * pf.y);
-            }
-            PSUB(5);
-            dsp_barrier(&CT[CT_CNT], 6 * (++dsp_phase), lane);
-            PSUB(6);
-            if (PROF) pr_d += (long long)__builtin_readcyclecounter() - pr_t0;
-
-            if (wave == 2) {
-                // ---- T(k): ordered sum, timing, nin, decisions (fsk.c:870-993) ----------------------
-                float tcr, tci;
-                {
-                    typedef float v4f __attribute__((ext_vector_type(4)));
-                    const v4f *TP4 = (const v4f *)TP;
-                    v2f acc = {0.f, 0.f};
-                    v4f cur[4], nxt[4];
-                    int i = 0;
-                    if (NI >= 8) {
-#pragma unroll
-                        for (int u = 0; u < 4; u++) cur[u] = TP4[u];
-                        for (i = 8; i + 8 <= NI; i += 8) {
-#pragma unroll
-                            for (int u = 0; u < 4; u++) nxt[u] = TP4[(i >> 1) + u];
-#pragma unroll
-                            for (int u = 0; u < 4; u++) { acc = acc + cur[u].xy; acc = acc + cur[u].zw; }
-#pragma unroll
-                            for (int u = 0; u < 4; u++) cur[u] = nxt[u];
-                        }
-#pragma unroll
-                        for (int u = 0; u < 4; u++) { acc = acc + cur[u].xy; acc = acc + cur[u].zw; }
-                    }
-                    for (; i < NI; i++) { const float2 v = TP[i]; acc = acc + (v2f){v.x, v.y}; }
-                    tcr = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(acc.x)));
-                    tci = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(acc.y)));
-                }
-                PSUB(7);
-                int nin_next = nin;
-                float tr_mean = 0.f, tr_std = 0.f, tr_rxt = 0.f;
-                const bool nan_frame = (tcr != tcr) || (tci != tci);     // fsk.c:878-880
-                if (!nan_frame) {
-                    const float at = wg_atan2f(tci, tcr);
-                    const float norm_rx_timing = (float)((double)at / (2 * 3.14159265358979323846));
-                    const float rx_timing = norm_rx_timing * cfg.P_f;
-                    const float d_nrt = norm_rx_timing - norm_rx_timing_st;
-                    norm_rx_timing_st = norm_rx_timing;
-                    if ((double)fabsf(d_nrt) < .2) {
-                        const float appm = (float)(1e6 * (double)d_nrt / (double)cfg.nsym_f);
-                        ppm = (float)(.9 * (double)ppm + .1 * (double)appm);
-                    }
-                    if (norm_rx_timing > 0.25f) nin_next = N + Ts / 2;
-                    else if (norm_rx_timing < -0.25f) nin_next = N - Ts / 2;
-                    else nin_next = N;
-                    nin_next = __builtin_amdgcn_readfirstlane(nin_next);
-                    const int low_sample = (int)floorf(rx_timing);
-                    const float fract = rx_timing - (float)low_sample;
-                    const int high_sample = (int)ceilf(rx_timing);
-                    const float omf = 1 - fract;
-                    tr_rxt = rx_timing;
-                    float mymax = 0.f;
-                    if (lane < WR_NSYM) {
-                        const int st = (lane + 1) * P;
-                        float tmax[M];
-#pragma unroll
-                        for (int m = 0; m < M; m++) {
-                            const float2 a = FI[m * NI + st + low_sample];
-                            const float2 b = FI[m * NI + st + high_sample];
-                            float tr = omf * a.x, ti = omf * a.y;
-                            tr = tr + fract * b.x;
-                            ti = ti + fract * b.y;
-                            tmax[m] = (tr * tr) + (ti * ti);
-                        }
-                        float mx = tmax[0];
-                        int sym = 0;
-#pragma unroll
-                        for (int m = 0; m < M; m++) if (tmax[m] > mx) { mx = tmax[m]; sym = m; }
-                        mymax = mx;
-                        if (C.bits_out) {
-                            uint8_t *bo = C.bits_out + frames * Nbits;
-                            if (M == 2) bo[lane] = (uint8_t)(sym == 1);
-                            else { bo[lane * 2 + 1] = (uint8_t)(sym & 1); bo[lane * 2] = (uint8_t)((sym & 2) >> 1); }
-                        }
-#pragma unroll
-                        for (int m = 0; m < M; m++) tmax[m] = sqrtf(tmax[m]);
-                        if (M == 2) {
-                            SDL[lane] = tmax[0] - tmax[1];
-                        } else {
-                            float s1 = -tmax[0], s0 = -tmax[0];
-                            s1 += tmax[1 % M];  s0 += -tmax[1 % M];
-                            s1 += -tmax[2 % M]; s0 += tmax[2 % M];
-                            s1 += tmax[3 % M];  s0 += tmax[3 % M];
-                            SDL[lane * 2 + 1] = s1;
-                            SDL[lane * 2] = s0;
-                        }
-                    }
-                    if (cfg.stats) {
-                        if (lane < WR_NSYM) { SC[lane] = mymax; SC[WR_NSYM + lane] = sqrtf(mymax); }
-                        wave_sync();
-                        if (lane == 0) {
-                            float stdebno = 0.f, meanebno = 0.f;
-                            for (int i = 0; i < WR_NSYM; i++) { stdebno += SC[i]; meanebno += SC[WR_NSYM + i]; }
-                            meanebno = meanebno / cfg.nsym_f;
-                            stdebno = (stdebno / cfg.nsym_f) - (meanebno * meanebno);
-                            if ((double)stdebno > 0.0) stdebno = (float)sqrt((double)stdebno); else stdebno = 0.0f;
-                            SC[2 * WR_NSYM] = meanebno;
-                            SC[2 * WR_NSYM + 1] = stdebno;
-                        }
-                        wave_sync();
-                        tr_mean = SC[2 * WR_NSYM];
-                        tr_std = SC[2 * WR_NSYM + 1];
-                    }
-                    if (C.dump && frames >= C.dump_first && ((frames - C.dump_first) % C.dump_period) == 0) {
-                        const long long slot = (frames - C.dump_first) / C.dump_period;
-                        if (slot < C.dump_cap) {
-                            float *d = C.dump + slot * cfg.dump_floats;
-                            const float *FEk = FEr + (kf % 3) * NH;
-                            const int neye = cfg.eye_traces * M * cfg.neyesamp;
-                            for (int e = lane; e < neye; e += 64) {
-                                const int j = e % cfg.neyesamp;
-                                const int tm = e / cfg.neyesamp;
-                                const int i = tm / M, m = tm - i * M;
-                                const int ind = 2 * P * i + (high_sample + 1) + j * cfg.eye_dec;
-                                float v = 0.f;
-                                if (ind >= 0 && ind < NI) { const float2 f = FI[m * NI + ind]; v = sqrtf(f.x * f.x + f.y * f.y); }
-                                d[e] = v;
-                            }
-                            for (int i = lane; i < NH; i += 64) d[neye + i] = FEk[i];
-                            if (lane == 0) { d[neye + NH] = (float)high_sample; d[neye + NH + 1] = (float)frames; }
-                        }
-                    }
-                }
-                wave_sync();
-                PSUB(8);
-                if (C.sd_out) {
-                    float *so = C.sd_out + frames * Nbits;
-                    for (int i = lane; i < Nbits; i += 64) so[i] = SDL[i];
-                }
-                if (C.trace && lane == 0) {
-                    float *tr = C.trace + frames * WR_TRACE_FLOATS;
-#pragma unroll
-                    for (int m = 0; m < WR_M_MAX; m++) tr[WR_TR_FEST + m] = (m < M) ? cfg.bin_freq[CT[CT_FBIN + (kf & 3) * 4 + (m < M ? m : 0)]] : 0.f;
-                    tr[WR_TR_NIN] = (float)nin_next;
-                    tr[WR_TR_NRT] = norm_rx_timing_st;
-                    tr[WR_TR_PPM] = ppm;
-                    tr[WR_TR_MEAN] = tr_mean;
-                    tr[WR_TR_STD] = tr_std;
-                    tr[WR_TR_RXT] = tr_rxt;
-                }
-                if (lane == 0) CT[CT_NIN_NEXT] = nin_next;
-                PSUB(9);
-            }
-            if (PROF) pr_busy += (long long)__builtin_readcyclecounter() - pr_t0;
+            dstage(kf + 1, off1, N);                                     // D(k+1), speculative
         }
+        if (PROF) pr_busy += (long long)__builtin_readcyclecounter() - pr_t0;
         lds_barrier();
         if (PROF) pr_iter += (long long)__builtin_readcyclecounter() - pr_t0;
         // ---- commit frame k; verify the speculation nin(k+1) == N ----------------------------------
         const int nin_next = __builtin_amdgcn_readfirstlane(CT[CT_NIN_NEXT]);
-        const long long off_next = off + nin;
-        if (wave >= 2) filled += nin;
-        if (PROF && nin_next != N) pr_redo++;
+        if (wave >= 3) filled += nin;
         if (nin_next != N) {
-            // E(k+1) and C(k+1) were computed for the wrong window length / nold, E(k+2) at the wrong offset:
-            // re-run them from the state of frame k, which the rings still hold.
-            if (wave == 1) estimate(kf + 1, off_next, nin_next);
+            // Everything computed ahead assumed nin(k+1) == N (window length, nold, sample offsets).  Re-run it
+            // from the state of frame k, which the rings still hold:  E(k+1) | C(k+1),E(k+2) | D(k+1),C(k+2),E(k+3)
+            if (PROF) pr_redo++;
+            if (wave == 1) estimate(kf + 1, off1, nin_next);
             lds_barrier();
             if (wave == 0) chain(kf + 1, nin_next);
-            if (wave == 1) estimate(kf + 2, off_next + nin_next, N);
+            if (wave == 1) estimate(kf + 2, off1 + nin_next, N);
+            lds_barrier();
+            if (wave == 0) chain(kf + 2, N);
+            if (wave == 1) estimate(kf + 3, off1 + nin_next + N, N);
+            if (wave >= 3) dstage(kf + 1, off1, nin_next);
             lds_barrier();
         }
-        off = off_next;
+        off = off1;
         nin = nin_next;
         frames++;
         kf++;
     }
-
     if (PROF && C.prof && lane == 0) {
-        // [0] chain busy  [1] estimator busy  [2] T-wave busy (D+T)  [3] D part (to the last D barrier)
-        // [4] iteration total  [5] mispredictions  [6] frames
+        // [0] chain busy  [1] estimator busy  [2] T busy  [3] D busy (wave 3)  [4] iteration total  [5] mispredictions  [6] frames
         if (wave == 0) C.prof[0] = pr_busy;
         if (wave == 1) C.prof[1] = pr_busy;
-        if (wave == 2) { C.prof[2] = pr_busy; C.prof[3] = pr_d; C.prof[4] = pr_iter; C.prof[5] = pr_redo; C.prof[6] = frames;
-                         if (C.prof2) for (int k = 0; k < 10; k++) C.prof2[k] = pr_sub[k]; }
+        if (wave == 2) { C.prof[2] = pr_busy; C.prof[4] = pr_iter; C.prof[5] = pr_redo; C.prof[6] = frames; }
+        if (wave == 3) C.prof[3] = pr_busy;
     }
+
     // ================================ save carried state =======================================
     lds_barrier();
     if (frames > 0) {
         const int jl = kf - 1;                                           // last committed frame
-        const float *FEk = FEr + (jl % 3) * NH;
+        const float *FEk = FEr + (jl & 3) * NH;
         for (int i = tid; i < NH; i += WP_THREADS) st_fft[i] = FEk[i];
         for (int i = tid; i < nstash; i += WP_THREADS) st_old[i] = XR[RIDX(off - nstash + i)];
         for (int i = tid; i < Nbits; i += WP_THREADS) st_sd[i] = SDL[i];

@@ -204,7 +204,7 @@ struct DemodTables {
                 o = t;
             }
         }
-        {   // pipelined kernel: 4-frame sample ring, double phasor rows, triple spectrum/phase rings, tables
+        {   // pipelined kernel: sample ring (>= 4 frames + tail), checkpoint/integrator/product double buffers, state rings, tables
             const int Nmax = cfg.N + cfg.Ts / 2;
             int ring = 1;
             while (ring < 4 * Nmax + cfg.nstash) ring <<= 1;
@@ -214,9 +214,10 @@ struct DemodTables {
             cfg.p_off_PH = t;   t = align16(t + M * cfg.Lpad * 8);
             cfg.p_off_CK = t;   t = align16(t + 2 * 2 * M * 80 * 8);      // WP_CKROW = 80
             cfg.p_off_CKD = t;  t = align16(t + 2 * 2 * M * 8);
-            cfg.p_off_FI = t;   t = align16(t + M * cfg.NI * 8);
+            cfg.p_off_FI = t;   t = align16(t + 2 * M * cfg.NI * 8);
+            cfg.p_off_TP = t;   t = align16(t + 2 * cfg.NI * 8);
             cfg.p_off_FB = t;   t = align16(t + Ndft * 8);
-            cfg.p_off_FE = t;   t = align16(t + 3 * NH * 4);
+            cfg.p_off_FE = t;   t = align16(t + 4 * NH * 4);
             cfg.p_off_FW = t;   t = align16(t + NH * 4);
             cfg.p_off_SD = t;   t = align16(t + cfg.Nbits * 4);
             cfg.p_off_SC = t;   t = align16(t + (4 * nsyms + 16) * 4);
@@ -228,7 +229,7 @@ struct DemodTables {
             cfg.p_off_PFT = t;  t = align16(t + cfg.NI * 8);
             cfg.p_off_DPHI = t; t = align16(t + NH * 8);
             cfg.p_lds_bytes = t;
-            cfg.pipe_ok = (Nmax <= 2 * 384 && cfg.L / 8 + 2 <= 80 && t <= 80 * 1024 && getenv("WENET_RX_NO_PIPE") == nullptr) ? 1 : 0;
+            cfg.pipe_ok = (Nmax <= 2 * 320 && cfg.L / 8 + 2 <= 80 && t <= 80 * 1024 && getenv("WENET_RX_NO_PIPE") == nullptr) ? 1 : 0;
         }
         cfg.lds_bytes = o;
         if (o > 160 * 1024) { fprintf(stderr, "libwenet_rx: configuration needs %d bytes of LDS (>160 KiB)\n", o); return false; }
