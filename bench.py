@@ -76,7 +76,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--captures", type=int, default=int(os.environ.get("WENET_BENCH_CAPTURES", "64")),
+    ap.add_argument("--captures", type=int, default=int(os.environ.get("WENET_BENCH_CAPTURES", "512")),
                     help="independent captures per GPU")
     ap.add_argument("--seconds", type=float, default=10.0, help="length of each capture")
     ap.add_argument("--ebno", type=float, default=8.0)
@@ -95,9 +95,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1)))
+    ndev = max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local_rank % ndev)
+    dev = torch.device("cuda", local_rank % ndev)
 
     cfg = siggen.CONFIGS[args.config]()
     nsym = int(args.seconds * cfg.Rs)
@@ -169,7 +170,7 @@ def main():
             "single_stream": {"ms": round(single_s * 1e3, 2), "msamples_per_s": round(nsamp / single_s / 1e6, 2),
                               "x_realtime": round(nsamp / single_s / cfg.Fs, 1),
                               "gpu_ms": round(single.last_ms(3), 2)},
-            "roofline": {"bound": "hbm", "kernel": "wenet_demod_kernel", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "wenet_demod_pipe_kernel", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
                          "algorithmic_bytes_per_launch": round(ALGO_BYTES_PER_SAMPLE * B * nsamp),
                          "avg_launch_ms": round(k_ms[0], 3)},

@@ -135,6 +135,78 @@ __device__ __forceinline__ int var_edge(int v, int k, const uint16_t *vedge_lds)
 
 }  // namespace
 
+// soft symbol i (0..n-1) of a packet as the double the reference feeds to sd_to_llr
+__device__ __forceinline__ double packet_symbol(const WrDecodeArgs &A, const float *sd_stream, long long start, long long slot, int n, int i) {
+    if (A.input_kind == WR_DEC_IN_SD64) return A.sd64[slot * n + i];
+    if (A.mode == 1) {                                  // RS232 strip: out[8b+j] = in[10b + 8 - j] (drs232_ldpc.c:220-225)
+        const int b = i >> 3, j = i & 7;
+        return (double)sd_stream[start + 10 * b + 8 - j];
+    }
+    const int kb = i % 1000;                            // v2: symbol * scramble_code[ind % 1000] (wenet_ldpc.c:207)
+    const int neg = (A.scramble[kb >> 3] >> (7 - (kb & 7))) & 1;
+    return (double)sd_stream[start + i] * (neg ? -1.0 : 1.0);
+}
+
+// sd_to_llr statistics (mpdecode_core.c:575-592): three running double sums whose rounding depends on the
+// order, so each packet is summed sequentially -- by ONE THREAD PER PACKET, thousands of packets side by side
+// (inside the decode workgroup the same chains would idle 575 of 576 threads for ~50 us per packet).
+// Output: estEsN0 per packet slot, with the reference's x87 rounding (x87emu.h).
+__global__ __launch_bounds__(256) void wenet_llr_stats_kernel(WrDecodeArgs A) {
+    const long long slot = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (slot >= (long long)A.nchan * A.max_pk) return;
+    const int ch = (int)(slot / A.max_pk), pk = (int)(slot - (long long)ch * A.max_pk);
+    const float *sd_stream = nullptr;
+    long long start = 0;
+    if (A.input_kind == WR_DEC_IN_STREAM) {
+        const WrDeframeChan D = A.dchans[ch];
+        if (pk >= D.state->npackets) return;
+        sd_stream = D.sd;
+        start = D.starts[pk];
+    } else if (pk >= A.npk_direct[ch]) return;
+    const int n = (A.input_kind == WR_DEC_IN_SD64) ? A.n_sd : WR_NCODE;
+    double sum = 0.0;
+    for (int i = 0; i < n; i++) sum += fabs(packet_symbol(A, sd_stream, start, slot, n, i));
+    const double mean = sum / n;
+    sum = 0.0;
+    double sumsq = 0.0;
+    for (int i = 0; i < n; i++) {
+        const double s = packet_symbol(A, sd_stream, start, slot, n, i);
+        const double sign = (double)((s > 0.0) - (s < 0.0));
+        const double x = s / mean - sign;
+        sum += x;
+        sumsq += x * x;
+    }
+    const double estvar = (n * sumsq - sum * sum) / (n * (n - 1));
+    A.esn0[slot] = wx_est_esn0(estvar);                 // 1.0/(2.0L*estvar + 1E-3), x87 rounding
+}
+
+// CRC-16/CCITT-FALSE gate (drs232_ldpc.c:91-102, 243-254): byte-serial, one thread per packet
+__global__ __launch_bounds__(256) void wenet_crc_kernel(WrDecodeArgs A) {
+    const long long slot = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (slot >= (long long)A.nchan * A.max_pk) return;
+    const int ch = (int)(slot / A.max_pk), pk = (int)(slot - (long long)ch * A.max_pk);
+    const long long npk = (A.input_kind == WR_DEC_IN_STREAM) ? A.dchans[ch].state->npackets : A.npk_direct[ch];
+    if (pk >= npk) return;
+    WrPacketOut *out = &A.out[slot];
+    unsigned crc = 0xFFFFu;
+    const unsigned *w = (const unsigned *)out->bytes;   // 280-byte records: 4-byte aligned
+    unsigned tail = 0;
+    for (int i = 0; i < 65; i++) {
+        const unsigned v = w[i];
+        if (i < 64) {
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                unsigned x = ((crc >> 8) ^ (v >> (8 * b))) & 0xffu;
+                x ^= x >> 4;
+                crc = ((crc << 8) ^ (x << 12) ^ (x << 5) ^ x) & 0xffffu;
+            }
+        } else tail = v;
+    }
+    const unsigned tx = tail & 0xffffu;                 // packet[256] | packet[257] << 8
+    out->crc_ok = (uint8_t)(crc == tx);
+    out->done = 1;
+}
+
 __global__ __launch_bounds__(WR_DEC_THREADS) void wenet_decode_kernel(WrDecodeArgs A) {
     const int pk = blockIdx.x, ch = blockIdx.y;
     const int tid = threadIdx.x;
@@ -157,76 +229,24 @@ __global__ __launch_bounds__(WR_DEC_THREADS) void wenet_decode_kernel(WrDecodeAr
     const int n = (A.input_kind == WR_DEC_IN_SD64) ? A.n_sd : WR_NCODE;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // prologue view: double XS[n] (sd, then x = sd/mean - sign)
-    // decode view  : float msg[14*516] | uint16 vedge[2064*3] | uint4 lut[90] | misc
-    double   *XS   = (double *)smem;
+    // float msg[14*516] | uint16 vedge[2064*3] | uint4 lut[90] | bit/byte staging
     float    *msg  = (float *)smem;
     uint16_t *vedge = (uint16_t *)(smem + 14 * WR_NPAR * 4);                       // 28896
     uint4    *lut  = (uint4 *)(smem + 14 * WR_NPAR * 4 + WR_NDATA * 3 * 2 + 0);    // 28896+12384 = 41280 (16B aligned)
-    double   *bc   = (double *)(smem + 41280 + WR_PHI0_LUT_ENTRIES * 16);          // broadcast scratch (8 doubles)
-    uint8_t  *bitbuf = (uint8_t *)(bc + 8);                                        // [2580] decoded bits, then [258] bytes
+    uint8_t  *bitbuf = (uint8_t *)(smem + 41280 + WR_PHI0_LUT_ENTRIES * 16);       // [2580] decoded bits, then [258] bytes
 
     float llr[WR_VARS_PER_THREAD];
     WrPacketOut *out = A.out ? &A.out[slot] : nullptr;
 
     if (A.input_kind != WR_DEC_IN_LLR) {
-        // ---- gather the packet's soft symbols as doubles --------------------------------------
-        double sdv[WR_VARS_PER_THREAD];
+        // ---- LLRs: llr = (float)(4.0L*estEsN0*sd) with estEsN0 from wenet_llr_stats_kernel (mpdecode_core.c:593-594)
+        const double estEsN0 = A.esn0[slot];
 #pragma unroll
         for (int t = 0; t < WR_VARS_PER_THREAD; t++) {
             const int i = tid + t * WR_DEC_THREADS;
-            double v = 0.0;
-            if (i < n) {
-                if (A.input_kind == WR_DEC_IN_SD64) {
-                    v = A.sd64[(long long)slot * n + i];
-                } else if (A.mode == 1) {                       // RS232: out[8b+j] = in[10b + 8 - j]
-                    const int b = i >> 3, j = i & 7;
-                    v = (double)sd_stream[start + 10 * b + 8 - j];
-                } else {                                        // v2: symbol * scramble_code[ind % 1000]
-                    const int kb = i % 1000;
-                    const int neg = (A.scramble[kb >> 3] >> (7 - (kb & 7))) & 1;
-                    const double code = neg ? -1.0 : 1.0;
-                    v = (double)sd_stream[start + i] * code;
-                }
-                XS[i] = v;
-            }
-            sdv[t] = v;
-        }
-        __syncthreads();
-        // ---- sd_to_llr (mpdecode_core.c:569-595): the three running sums are sequential double
-        //      additions; one lane replays them in order, everything else is parallel.
-        if (tid == 0) {
-            double sum = 0.0;
-            for (int i = 0; i < n; i++) sum += fabs(XS[i]);
-            bc[0] = sum / n;
-        }
-        __syncthreads();
-        const double mean = bc[0];
-#pragma unroll
-        for (int t = 0; t < WR_VARS_PER_THREAD; t++) {
-            const int i = tid + t * WR_DEC_THREADS;
-            if (i < n) {
-                const double s = sdv[t];
-                const double sign = (double)((s > 0.0) - (s < 0.0));
-                XS[i] = s / mean - sign;
-            }
-        }
-        __syncthreads();
-        if (tid == 0) {
-            double sum = 0.0, sumsq = 0.0;
-            for (int i = 0; i < n; i++) { const double x = XS[i]; sum += x; sumsq += x * x; }
-            const double estvar = (n * sumsq - sum * sum) / (n * (n - 1));
-            bc[1] = wx_est_esn0(estvar);                        // 1.0/(2.0L*estvar + 1E-3), x87 rounding
-        }
-        __syncthreads();
-        const double estEsN0 = bc[1];
-#pragma unroll
-        for (int t = 0; t < WR_VARS_PER_THREAD; t++) {
-            const int i = tid + t * WR_DEC_THREADS;
-            llr[t] = (i < n) ? wx_llr(estEsN0, sdv[t]) : 0.f;   // (float)(4.0L*estEsN0*sd)
+            llr[t] = (i < n) ? wx_llr(estEsN0, packet_symbol(A, sd_stream, start, slot, n, i)) : 0.f;
             if (A.llr_out && i < n) A.llr_out[(long long)slot * n + i] = llr[t];
         }
-        __syncthreads();                                        // XS is dead from here on
     } else {
 #pragma unroll
         for (int t = 0; t < WR_VARS_PER_THREAD; t++) {
@@ -343,24 +363,14 @@ __global__ __launch_bounds__(WR_DEC_THREADS) void wenet_decode_kernel(WrDecodeAr
         bytes[tid] = (uint8_t)a;
         if (out) out->bytes[tid] = (uint8_t)a;
     }
-    __syncthreads();
-    if (tid == 0 && out) {
-        unsigned crc = 0xFFFFu;
-        for (int i = 0; i < 256; i++) {
-            unsigned x = ((crc >> 8) ^ bytes[i]) & 0xffu;
-            x ^= x >> 4;
-            crc = ((crc << 8) ^ (x << 12) ^ (x << 5) ^ x) & 0xffffu;
-        }
-        const unsigned tx = (unsigned)bytes[256] | ((unsigned)bytes[257] << 8);
-        out->crc_ok = (uint8_t)(crc == tx);
+    if (tid == 0 && out) {                                  // crc_ok/done are set by wenet_crc_kernel
         out->iter = result;
         out->pcc = pcc;
         out->pcc_written = pcc_written;
-        out->done = 1;
     }
 }
 
-#define WR_DEC_LDS_BYTES (41280 + WR_PHI0_LUT_ENTRIES * 16 + 64 + 2592 + 272)
+#define WR_DEC_LDS_BYTES (41280 + WR_PHI0_LUT_ENTRIES * 16 + 2592 + 272)
 
 extern "C" hipError_t wr_launch_deframe(const WrDeframeChan *d_chans, int nchan, int mode, hipStream_t stream) {
     if (nchan <= 0) return hipSuccess;
@@ -370,10 +380,14 @@ extern "C" hipError_t wr_launch_deframe(const WrDeframeChan *d_chans, int nchan,
 
 extern "C" hipError_t wr_launch_decode(const WrDecodeArgs *args, hipStream_t stream) {
     if (args->nchan <= 0 || args->max_pk <= 0) return hipSuccess;
-    int lds = WR_DEC_LDS_BYTES;
-    const int need_prologue = (args->input_kind == WR_DEC_IN_SD64 ? args->n_sd : WR_NCODE) * 8 + 64;
-    if (args->input_kind != WR_DEC_IN_LLR && need_prologue > lds) lds = need_prologue;
+    const long long slots = (long long)args->nchan * args->max_pk;
+    const unsigned blocks = (unsigned)((slots + 255) / 256);
+    if (args->input_kind != WR_DEC_IN_LLR)
+        hipLaunchKernelGGL(wenet_llr_stats_kernel, dim3(blocks), dim3(256), 0, stream, *args);
+    const int lds = WR_DEC_LDS_BYTES;
     (void)hipFuncSetAttribute((const void *)wenet_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipLaunchKernelGGL(wenet_decode_kernel, dim3(args->max_pk, args->nchan), dim3(WR_DEC_THREADS), lds, stream, *args);
+    if (!args->stop_after_llr && args->out)
+        hipLaunchKernelGGL(wenet_crc_kernel, dim3(blocks), dim3(256), 0, stream, *args);
     return hipGetLastError();
 }

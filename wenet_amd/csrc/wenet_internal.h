@@ -143,6 +143,7 @@ struct WrDecodeArgs {
     WrPacketOut *out;                   // [nchan*max_pk]
     float       *llr_out;               // optional [nchan*max_pk*n]
     uint8_t     *bits_out;              // optional [nchan*max_pk*2580] all decoded bits (run_ldpc_decoder API)
+    double      *esn0;                  // [nchan*max_pk] estEsN0 per packet (wenet_llr_stats_kernel -> decode)
     // tables
     const uint16_t *vedge;              // [2064*3] edge address (slot*516+check) per data bit, socket order
     const uint4    *phi0_lut;           // [90]

@@ -562,7 +562,7 @@ extern "C" int wenet_fsk_get_stats(wenet_fsk *f, wenet_modem_stats *out, int cap
 // ================================================================================================
 namespace {
 struct DecodeScratch {
-    DevBuf d_in, d_out, d_llr, d_npk, d_bits;
+    DevBuf d_in, d_out, d_llr, d_npk, d_bits, d_esn0;
 };
 std::mutex g_dec_mu;
 DecodeScratch g_dec;
@@ -578,6 +578,7 @@ int run_dense(int kind, const void *in, int npk, int n, int mode, int max_iter, 
     if (!g_dec.d_in.reserve(in_bytes) || !g_dec.d_out.reserve((size_t)npk * sizeof(WrPacketOut)) || !g_dec.d_npk.reserve(16)) return -2;
     if (llr_host && !g_dec.d_llr.reserve((size_t)npk * n * 4)) return -2;
     if (bits_host && !g_dec.d_bits.reserve((size_t)npk * WR_NCODE)) return -2;
+    if (!g_dec.d_esn0.reserve((size_t)npk * 8)) return -2;
     WR_CHECK(hipMemcpy(g_dec.d_in.p, in, in_bytes, hipMemcpyHostToDevice), -3);
     WR_CHECK(hipMemset(g_dec.d_out.p, 0, (size_t)npk * sizeof(WrPacketOut)), -3);
     WR_CHECK(hipMemcpy(g_dec.d_npk.p, &npk, 4, hipMemcpyHostToDevice), -3);
@@ -592,6 +593,7 @@ int run_dense(int kind, const void *in, int npk, int n, int mode, int max_iter, 
     a.out = g_dec.d_out.as<WrPacketOut>();
     a.llr_out = llr_host ? g_dec.d_llr.as<float>() : nullptr;
     a.bits_out = bits_host ? g_dec.d_bits.as<uint8_t>() : nullptr;
+    a.esn0 = g_dec.d_esn0.as<double>();
     fill_decode_tables(a, t);
     WR_CHECK(wr_launch_decode(&a, 0), -4);
     WR_CHECK(hipDeviceSynchronize(), -4);
@@ -642,7 +644,7 @@ struct wenet_deframer {
     long long carry_base = 0;            // absolute index of carry[0] in the symbol stream
     unsigned long long hist = 0;         // bit_buffer (zero-initialised, drs232_ldpc.c:172)
     int collecting = 0;
-    DevBuf d_sd, d_state, d_chan, d_starts, d_out;
+    DevBuf d_sd, d_state, d_chan, d_starts, d_out, d_esn0;
 };
 
 extern "C" wenet_deframer *wenet_deframer_create(int framing_mode, int max_iter) {
@@ -665,7 +667,7 @@ extern "C" long wenet_deframer_push(wenet_deframer *d, const float *symbols, lon
     const long long n = (long long)d->carry.size();
     if (n == 0) return 0;
     const int max_pk = (int)(n / d->spp + 1);
-    if (!d->d_sd.reserve((size_t)n * 4) || !d->d_starts.reserve((size_t)max_pk * 8) || !d->d_out.reserve((size_t)max_pk * sizeof(WrPacketOut))) return -2;
+    if (!d->d_sd.reserve((size_t)n * 4) || !d->d_starts.reserve((size_t)max_pk * 8) || !d->d_out.reserve((size_t)max_pk * sizeof(WrPacketOut)) || !d->d_esn0.reserve((size_t)max_pk * 8)) return -2;
     WR_CHECK(hipMemcpy(d->d_sd.p, d->carry.data(), (size_t)n * 4, hipMemcpyHostToDevice), -3);
     WrDeframeState st;
     memset(&st, 0, sizeof(st));
@@ -682,6 +684,7 @@ extern "C" long wenet_deframer_push(wenet_deframer *d, const float *symbols, lon
     a.input_kind = WR_DEC_IN_STREAM; a.mode = d->mode; a.max_iter = d->max_iter; a.nchan = 1; a.max_pk = max_pk;
     a.dchans = d->d_chan.as<WrDeframeChan>();
     a.out = d->d_out.as<WrPacketOut>();
+    a.esn0 = d->d_esn0.as<double>();
     fill_decode_tables(a, t);
     WR_CHECK(wr_launch_decode(&a, 0), -4);
     WR_CHECK(hipMemcpy(&st, d->d_state.p, sizeof(st), hipMemcpyDeviceToHost), -3);   // synchronises
@@ -712,7 +715,7 @@ struct wenet_rx {
     bool want_trace = false, want_llr = false;
     int nchan = 0, max_pk = 0;
     std::vector<long long> sd_off, cap_frames;           // per channel: float offset into d_sd, frame capacity
-    DevBuf d_states, d_chans, d_dchans, d_dstates, d_sd, d_starts, d_out, d_trace, d_llr, d_raw, d_prof;
+    DevBuf d_states, d_chans, d_dchans, d_dstates, d_sd, d_starts, d_out, d_trace, d_llr, d_raw, d_prof, d_esn0;
     bool profile = false;
     std::vector<float> h_states;
     std::vector<WrDeframeState> h_dstates;
@@ -762,7 +765,7 @@ extern "C" int wenet_rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw,
     if (!rx->d_states.reserve(stb * nchan) || !rx->d_chans.reserve(sizeof(WrChan) * nchan) ||
         !rx->d_dchans.reserve(sizeof(WrDeframeChan) * nchan) || !rx->d_dstates.reserve(sizeof(WrDeframeState) * nchan) ||
         !rx->d_sd.reserve((size_t)rx->sd_off[nchan] * 4) || !rx->d_starts.reserve((size_t)nchan * max_pk * 8) ||
-        !rx->d_out.reserve((size_t)nchan * max_pk * sizeof(WrPacketOut)))
+        !rx->d_out.reserve((size_t)nchan * max_pk * sizeof(WrPacketOut)) || !rx->d_esn0.reserve((size_t)nchan * max_pk * 8))
         return -2;
     if (rx->want_trace && !rx->d_trace.reserve((size_t)(rx->sd_off[nchan] / c.Nbits) * WR_TRACE_FLOATS * 4)) return -2;
     if (rx->want_llr && !rx->d_llr.reserve((size_t)nchan * max_pk * WR_NCODE * 4)) return -2;
@@ -805,6 +808,7 @@ extern "C" int wenet_rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw,
     a.input_kind = WR_DEC_IN_STREAM; a.mode = rx->mode; a.max_iter = rx->max_iter; a.nchan = nchan; a.max_pk = (int)max_pk;
     a.dchans = rx->d_dchans.as<WrDeframeChan>();
     a.out = rx->d_out.as<WrPacketOut>();
+    a.esn0 = rx->d_esn0.as<double>();
     a.llr_out = rx->want_llr ? rx->d_llr.as<float>() : nullptr;
     fill_decode_tables(a, t);
     WR_CHECK(hipEventRecord(rx->ev[0], stream), -4);
