@@ -154,6 +154,18 @@ def main():
     if rank == 0:
         demod_s = k_ms[0] / 1e3
         achieved = ALGO_BYTES_PER_SAMPLE * B * nsamp / demod_s / 1e9
+        # HBM traffic of the dominant kernel: bytes per IQ sample from the committed PMC profile of this kernel
+        # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 read correction: profiles/*_pmc_traffic.json),
+        # scaled to this launch -- per-sample traffic does not depend on the batch size.
+        traffic = None
+        try:
+            import glob
+            pj = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))[-1]
+            kern = json.load(open(pj))["kernels"]
+            bps = [v["hbm_bytes_per_iq_sample"] for k, v in kern.items() if "demod_pipe_kernel" in k or "demod_kernel" in k][0]
+            traffic = round(bps * B * nsamp)
+        except Exception:
+            traffic = None
         line = {
             "metric": "IQ Msamples/s demod+LDPC-decoded", "value": round(value, 3), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -171,7 +183,8 @@ def main():
                               "x_realtime": round(nsamp / single_s / cfg.Fs, 1),
                               "gpu_ms": round(single.last_ms(3), 2)},
             "roofline": {"bound": "hbm", "kernel": "wenet_demod_pipe_kernel", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                         "traffic_source": "rocprofv3 PMC profile of this kernel (profiles/), per-sample bytes x samples in launch",
                          "algorithmic_bytes_per_launch": round(ALGO_BYTES_PER_SAMPLE * B * nsamp),
                          "avg_launch_ms": round(k_ms[0], 3)},
         }
