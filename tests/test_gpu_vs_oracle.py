@@ -219,3 +219,67 @@ def test_full_size_properties_10s_8dB():
     ref = ol.oracle_deframe(sd, cfg.mode)
     assert b"".join(bytes(ref["bytes"][i][:256]) for i in range(ref["n"]) if ref["crc_ok"][i]) == out1
     rx.close()
+
+
+@pytest.mark.parametrize("name,ppm", [("v2", 600.0), ("v2", -450.0), ("v1", 300.0), ("v1", -900.0)])
+def test_heavy_clock_error_many_slips(name, ppm):
+    """Large symbol-clock errors: nin != N every few frames, i.e. the pipelined kernel's speculation
+    (nin = N) fails constantly and its rollback path carries the whole capture."""
+    cfg = siggen.CONFIGS[name]()
+    raw, _ = siggen.make_capture(cfg, 3, 12.0, seed=int(abs(ppm)), ppm=ppm)
+    ref, tr = ol.oracle_demod(raw, "cu8", cfg.Fs, cfg.Rs, cfg.M, want_trace=True)
+    assert (tr[:, 4] != cfg.Ts * 48).sum() > 5                      # really many slips
+    f = Fsk(cfg.Fs, cfg.Rs, cfg.Ts, cfg.M)
+    sd, _, gtr = f.demod_stream(raw, "cu8", want_trace=True)
+    assert bits_equal(sd, ref)
+    assert bits_equal(np.ascontiguousarray(gtr[:, 4:7]), np.ascontiguousarray(tr[:, 4:7]))
+    f.close()
+
+
+def test_every_capture_length_around_frame_boundaries():
+    """0..4 frames +- one sample, one launch each and all together as a ragged batch."""
+    cfg = siggen.config_v2()
+    raw, _ = siggen.make_capture(cfg, 1, 10.0, seed=77)
+    N = cfg.Ts * 48
+    lens = [0, 1, N - 1, N, N + 1, 2 * N - 1, 2 * N, 2 * N + 1, 3 * N, 4 * N + 5]
+    caps = [raw[:2 * n] for n in lens]
+    rx = RxBatch(cfg.Fs, cfg.Rs, cfg.M, framing=cfg.mode)
+    rx.process(caps, "cu8")
+    for i, c in enumerate(caps):
+        ref = ol.oracle_demod(c, "cu8", cfg.Fs, cfg.Rs, cfg.M)[0] if c.size else np.zeros(0, np.float32)
+        assert bits_equal(rx.soft(i), ref), lens[i]
+        f = Fsk(cfg.Fs, cfg.Rs, cfg.Ts, cfg.M)
+        sd, used, _ = f.demod_stream(c, "cu8")
+        assert bits_equal(sd, ref) and used <= lens[i]
+        f.close()
+    rx.close()
+
+
+def test_frame_cap_resume():
+    """cap_frames smaller than the data: the launch stops mid-stream with speculative stages in flight; the
+    next call must resume from exactly the committed state."""
+    import ctypes as C
+    from wenet_amd import lib as _lib
+    cfg = siggen.config_v1()
+    raw, _ = siggen.make_capture(cfg, 2, 9.0, seed=5, ppm=250.0)
+    ref, _ = ol.oracle_demod(raw, "cu8", cfg.Fs, cfg.Rs, cfg.M)
+    L = _lib.load()
+    h = L.wenet_fsk_create_hbr(cfg.Fs, cfg.Rs, cfg.Ts, cfg.M, 1200, 400)
+    buf = np.ascontiguousarray(raw)
+    out = []
+    pos = 0
+    caps = [1, 2, 3, 5, 7, 11, 13]
+    k = 0
+    while True:
+        chunk = buf[2 * pos:]
+        o = np.zeros(48 * 16, np.float32)
+        used = C.c_long(0)
+        n = L.wenet_fsk_demod_stream(h, 2, chunk.ctypes.data, chunk.size // 2, 1, o.ctypes.data, caps[k % len(caps)], C.byref(used), None)
+        assert n >= 0
+        if n == 0:
+            break
+        out.append(o[:n * 48].copy())
+        pos += used.value
+        k += 1
+    L.wenet_fsk_destroy(h)
+    assert bits_equal(np.concatenate(out), ref)
