@@ -32,7 +32,7 @@ ALGO_BYTES_PER_SAMPLE = 2.0 + 256.0 / 27440.0      # cu8 in + packet bytes out (
 HBM_PEAK_GBS = 8000.0                              # MI355X_MICROARCH.md: 8 TB/s
 
 
-def cpu_baseline(cfg, caps_host, framing, gpu_payloads, budget_s=20.0):
+def cpu_baseline(cfg, caps_host, framing, gpu_payloads, budget_s=15.0):
     """Reference pipeline `fsk_demod --cu8 -s M Fs Rs - - | {drs232,wenet}_ldpc - -` on host cores."""
     ref_dir = os.path.join(ROOT, "oracle", "_ref")
     demod = os.path.join(ref_dir, "fsk_demod")
@@ -189,7 +189,7 @@ def main():
                          "avg_launch_ms": round(k_ms[0], 3)},
         }
         if world == 1 and not args.no_cpu_baseline:
-            ncpu = min(B, 8)
+            ncpu = min(B, 24)
             caps_host = [caps[i].cpu().numpy() for i in range(ncpu)]
             gpu_payloads = [rx.valid_payloads(i) for i in range(ncpu)]
             line["cpu_baseline"] = cpu_baseline(cfg, caps_host, cfg.mode, gpu_payloads)
