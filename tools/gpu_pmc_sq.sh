@@ -1,0 +1,15 @@
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_sq -o s -- python $GRAFT_REPO_ROOT/bench.py --captures 512 --steps 1 --warmup 0 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/pmc_sq.log 2>&1
+python - <<'PY'
+import csv, glob, os
+root = os.environ["GRAFT_REPO_ROOT"] + "/gpurun_out"
+for f in glob.glob(f"{root}/pmc_sq/*counter_collection.csv"):
+    rows = list(csv.DictReader(open(f)))
+    acc = {}
+    for r in rows:
+        k = r.get("Kernel_Name", "")[:32]
+        if "wenet" not in k: continue
+        acc.setdefault((k, r["Counter_Name"]), []).append(float(r["Counter_Value"]))
+    for (k, c), v in sorted(acc.items()):
+        print(k, c, "n=%d" % len(v), "max=%.4g" % max(v))
+PY

@@ -719,12 +719,22 @@ struct wenet_rx {
     bool profile = false;
     std::vector<float> h_states;
     std::vector<WrDeframeState> h_dstates;
-    std::vector<WrPacketOut> h_out;
-    std::vector<long long> h_starts;
+    // results land in ONE pinned host block with two async copies (states | deframer states, then packet slots | starts)
+    void *h_pin = nullptr; size_t h_pin_cap = 0;
+    WrPacketOut *h_out = nullptr;
+    long long *h_starts = nullptr;
+    bool pin_reserve(size_t bytes) {
+        if (bytes <= h_pin_cap) return true;
+        if (h_pin) (void)hipHostFree(h_pin);
+        h_pin = nullptr; h_pin_cap = 0;
+        if (hipHostMalloc(&h_pin, bytes + bytes / 4, hipHostMallocDefault) != hipSuccess) { h_pin = nullptr; return false; }
+        h_pin_cap = bytes + bytes / 4;
+        return true;
+    }
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t stream = nullptr;
     bool pending = false;
-    ~wenet_rx() { for (auto &e : ev) if (e) (void)hipEventDestroy(e); }
+    ~wenet_rx() { for (auto &e : ev) if (e) (void)hipEventDestroy(e); if (h_pin) (void)hipHostFree(h_pin); }
 };
 
 extern "C" wenet_rx *wenet_rx_create(int Fs, int Rs, int P, int M, int framing_mode, int max_iter, int est_lo, int est_hi) {
@@ -830,17 +840,16 @@ extern "C" int wenet_rx_collect(wenet_rx *rx) {
     rx->h_dstates.resize(nchan);
     WR_CHECK(hipMemcpy(rx->h_states.data(), rx->d_states.p, (size_t)c.st_floats * 4 * nchan, hipMemcpyDeviceToHost), -3);
     WR_CHECK(hipMemcpy(rx->h_dstates.data(), rx->d_dstates.p, sizeof(WrDeframeState) * nchan, hipMemcpyDeviceToHost), -3);
-    rx->h_out.resize((size_t)nchan * rx->max_pk);
-    rx->h_starts.resize((size_t)nchan * rx->max_pk);
-    // fetch only the packet slots that were filled
-    for (int i = 0; i < nchan; i++) {
-        const long long npk = rx->h_dstates[i].npackets;
-        if (npk <= 0) continue;
-        WR_CHECK(hipMemcpy(&rx->h_out[(size_t)i * rx->max_pk], rx->d_out.as<WrPacketOut>() + (size_t)i * rx->max_pk,
-                           (size_t)npk * sizeof(WrPacketOut), hipMemcpyDeviceToHost), -3);
-        WR_CHECK(hipMemcpy(&rx->h_starts[(size_t)i * rx->max_pk], rx->d_starts.as<long long>() + (size_t)i * rx->max_pk,
-                           (size_t)npk * 8, hipMemcpyDeviceToHost), -3);
-    }
+    // packet slots + start offsets: one contiguous device->pinned-host copy each (per-capture copies of only the
+    // filled slots cost ~1000 small transfers for 512 captures)
+    const size_t n_slots = (size_t)nchan * rx->max_pk;
+    const size_t out_bytes = n_slots * sizeof(WrPacketOut), st_bytes = n_slots * 8;
+    if (!rx->pin_reserve(out_bytes + st_bytes + 64)) return -2;
+    rx->h_out = (WrPacketOut *)rx->h_pin;
+    rx->h_starts = (long long *)((char *)rx->h_pin + ((out_bytes + 63) & ~(size_t)63));
+    WR_CHECK(hipMemcpyAsync(rx->h_out, rx->d_out.p, out_bytes, hipMemcpyDeviceToHost, rx->stream), -3);
+    WR_CHECK(hipMemcpyAsync(rx->h_starts, rx->d_starts.p, st_bytes, hipMemcpyDeviceToHost, rx->stream), -3);
+    WR_CHECK(hipStreamSynchronize(rx->stream), -3);
     rx->pending = false;
     return 0;
 }
