@@ -22,6 +22,10 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+__device__ __forceinline__ void wave_sync() {     // LDS ordering inside ONE wavefront (it runs in lockstep)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 // one sample of the channel's raw input -> COMP (fsk_demod.c:273-296)
 __device__ __forceinline__ float2 load_sample(const void *raw, int fmt, long long idx) {
     if (fmt == WR_FMT_CU8) {
@@ -86,10 +90,10 @@ __device__ __forceinline__ uint2 load_raw(const void *raw, int fmt, long long id
 // KPRE raw samples per lane (sample index base + lane + 64k, clamped to `last`): the format switch is
 // hoisted so that each arm is KPRE back-to-back loads with nothing waiting on them
 template <int KPRE>
-__device__ __forceinline__ void prefetch_raw(uint2 (&pre)[KPRE], const void *raw, int fmt, long long base, long long last, int lane) {
+__device__ __forceinline__ void prefetch_raw(uint2 (&pre)[KPRE], const void *raw, int fmt, long long base, long long last, int tid, int nt) {
     long long idx[KPRE];
 #pragma unroll
-    for (int k = 0; k < KPRE; k++) { const long long i = base + lane + 64 * k; idx[k] = i < last ? i : last; }
+    for (int k = 0; k < KPRE; k++) { const long long i = base + tid + nt * k; idx[k] = i < last ? i : last; }
     if (fmt == WR_FMT_CU8 || fmt == WR_FMT_S16_REAL) {
         const WR_GLOBAL unsigned short *p = (const WR_GLOBAL unsigned short *)(uintptr_t)raw;
 #pragma unroll

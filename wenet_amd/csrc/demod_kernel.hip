@@ -27,11 +27,14 @@
 #define WR_PROF_PHASES 12
 #define PROF_MARK(k) do { if (PROF) { const long long _t = (long long)__builtin_readcyclecounter(); prof[k] += _t - t_last; t_last = _t; } } while (0)
 
-template <int M, bool PROF, bool TLDS>
-__global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const WrChan *chans, int nchan) {
+// NT = threads per capture: 64 (one wavefront) or 512 (eight: the order-free stages are spread over all of them,
+// the ordered recurrences run on wavefront 0) -- used for configurations too large for the pipelined kernel.
+template <int M, bool PROF, bool TLDS, int NT>
+__global__ __launch_bounds__(NT) void wenet_demod_kernel(WrDemodCfg cfg, const WrChan *chans, int nchan) {
     const int ch = blockIdx.x;
     if (ch >= nchan) return;
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const WrChan C = chans[ch];
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -59,16 +62,16 @@ __global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const W
     float *st_fft = C.state + cfg.st_fft_est;
     float2 *st_old = (float2 *)(C.state + cfg.st_samp_old);
     float *st_sd = C.state + cfg.st_sd_last;
-    for (int i = lane; i < NH; i += 64) FE[i] = st_fft[i];
-    for (int i = lane; i < nstash; i += 64) X[i] = st_old[i];
-    for (int i = lane; i < Nbits; i += 64) SDL[i] = st_sd[i];
+    for (int i = tid; i < NH; i += NT) FE[i] = st_fft[i];
+    for (int i = tid; i < nstash; i += NT) X[i] = st_old[i];
+    for (int i = tid; i < Nbits; i += NT) SDL[i] = st_sd[i];
     if (TLDS) {
         float2 *tw_w = (float2 *)(smem + cfg.off_TW); float *hann_w = (float *)(smem + cfg.off_HANN);
         int *src_w = (int *)(smem + cfg.off_SRC); float2 *pft_w = (float2 *)(smem + cfg.off_PFT);
         float2 *dphi_w = (float2 *)(smem + cfg.off_DPHI);
-        for (int i = lane; i < Ndft; i += 64) { tw_w[i] = cfg.tw[i]; hann_w[i] = cfg.hann[i]; src_w[i] = cfg.fft_src[i]; }
-        for (int i = lane; i < NI; i += 64) pft_w[i] = cfg.phi_ft[i];
-        for (int i = lane; i < NH; i += 64) dphi_w[i] = cfg.dphi_tab[i];
+        for (int i = tid; i < Ndft; i += NT) { tw_w[i] = cfg.tw[i]; hann_w[i] = cfg.hann[i]; src_w[i] = cfg.fft_src[i]; }
+        for (int i = tid; i < NI; i += NT) pft_w[i] = cfg.phi_ft[i];
+        for (int i = tid; i < NH; i += NT) dphi_w[i] = cfg.dphi_tab[i];
     }
     float2 phi_c = hdr->phi_c[lane % M];   // meaningful in lanes 0..M-1
     int fbin_prev[M];
@@ -87,12 +90,12 @@ __global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const W
     // Input prefetch: while frame k is processed, the longest possible window of frame k+1
     // (N + Ts/2 samples from off+nin) is already in flight into registers.
     constexpr int KPRE = 8;
-    const bool use_pre = (N + Ts / 2) <= 64 * KPRE;
+    const bool use_pre = (N + Ts / 2) <= NT * KPRE;
     uint2 pre[KPRE];
 #pragma unroll
     for (int k = 0; k < KPRE; k++) pre[k] = make_uint2(0u, 0u);
     if (use_pre) {
-        if (C.nsamples > 0) prefetch_raw<KPRE>(pre, C.raw, C.fmt, 0, C.nsamples - 1, lane);
+        if (C.nsamples > 0) prefetch_raw<KPRE>(pre, C.raw, C.fmt, 0, C.nsamples - 1, tid, NT);
     }
 
     long long off = 0, frames = 0;
@@ -102,10 +105,10 @@ __global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const W
         // ---- new samples -> X[nstash ..] ---------------------------------------------------
         if (use_pre) {
 #pragma unroll
-            for (int k = 0; k < KPRE; k++) { const int i = lane + 64 * k; if (i < nin) X[nstash + i] = convert_raw(pre[k], C.fmt); }
-            prefetch_raw<KPRE>(pre, C.raw, C.fmt, off + nin, C.nsamples - 1, lane);   // clamped: samples past the end are never used
+            for (int k = 0; k < KPRE; k++) { const int i = tid + NT * k; if (i < nin) X[nstash + i] = convert_raw(pre[k], C.fmt); }
+            prefetch_raw<KPRE>(pre, C.raw, C.fmt, off + nin, C.nsamples - 1, tid, NT);   // clamped: samples past the end are never used
         } else {
-            for (int i = lane; i < nin; i += 64) X[nstash + i] = load_sample(C.raw, C.fmt, off + i);
+            for (int i = tid; i < nin; i += NT) X[nstash + i] = load_sample(C.raw, C.fmt, off + i);
         }
         lds_barrier();
         PROF_MARK(0);
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const W
             const int samps = nin - (jl + 1) * Ndft;                   // fsk.c:583
             const int fft_samps = samps >= Ndft ? Ndft : samps;        // fsk.c:584
             // window + digit-reversed placement (kf_work leaves, kiss_fft.c:273-278)
-            for (int n = lane; n < Ndft; n += 64) {
+            for (int n = tid; n < Ndft; n += NT) {
                 const int idx = src_t[n];
                 float2 v = make_float2(0.f, 0.f);
                 if (idx < fft_samps) {
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const W
             for (int s = cfg.nstages - 1; s >= 0; s--) {               // innermost butterflies first
                 const int m = cfg.mstage[s], p = cfg.radix[s], fs = cfg.fstride[s];
                 const int nb = Ndft / p;
-                for (int b = lane; b < nb; b += 64) {
+                for (int b = tid; b < nb; b += NT) {
                     const int blk = b / m, k = b - blk * m;
                     float2 *F = FB + blk * m * p + k;
                     if (p == 4) {                                      // kf_bfly4 (kiss_fft.c:44-90), forward
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const W
                 lds_barrier();
             }
             // |X|^2, band limits, IIR (fsk.c:612-628)
-            for (int i = lane; i < NH; i += 64) {
+            for (int i = tid; i < NH; i += NT) {
                 const float2 v = FB[i];
                 float mag = (v.x * v.x) + (v.y * v.y);
                 if (i < cfg.f_min) mag = 0.f;
@@ -168,12 +171,15 @@ __global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const W
             lds_barrier();
         }
         if (fft_loops == 0) {          // not reachable for hbr geometries (nin >= Ndft); defined behaviour anyway
-            for (int i = lane; i < NH; i += 64) FW[i] = 0.f;
+            for (int i = tid; i < NH; i += NT) FW[i] = 0.f;
             lds_barrier();
         }
         PROF_MARK(1);
-        // M peaks: first-maximum argmax, blank +-f_zero, ascending sort (fsk.c:633-667)
+        // M peaks: first-maximum argmax, blank +-f_zero, ascending sort (fsk.c:633-667) -- wavefront 0, then shared
         int fbin[M];
+#pragma unroll
+        for (int k = 0; k < M; k++) fbin[k] = 0;
+        if (wave == 0) {
 #pragma unroll
         for (int k = 0; k < M; k++) {
             BestBin best; best.v = 0.f; best.i = 0;
@@ -194,9 +200,9 @@ __global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const W
             const int imax = __builtin_amdgcn_readfirstlane((best.v > 0.f) ? best.i : 0);
             int lo = imax - cfg.f_zero; lo = lo < 0 ? 0 : lo;
             int hi = imax + cfg.f_zero; hi = hi > NH ? NH : hi;        // only bins < Ndft/2 are ever read again
-            lds_barrier();
-            for (int j = lo + lane; j < hi; j += 64) FW[j] = 0.f;
-            lds_barrier();
+            wave_sync();
+            for (int j = lo + lane; j < hi; j += 64) FW[j] = 0.f;   // (wavefront 0 only)
+            wave_sync();
             fbin[k] = imax;
         }
 #pragma unroll
@@ -206,6 +212,16 @@ __global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const W
                 if (fbin[b - 1] > fbin[b]) { const int t = fbin[b]; fbin[b] = fbin[b - 1]; fbin[b - 1] = t; }
             }
         }
+        if (NT > 64 && lane == 0) {
+#pragma unroll
+            for (int m = 0; m < M; m++) ((int *)SC)[120 + m] = fbin[m];
+        }
+        }   // wave == 0
+        if (NT > 64) {
+            lds_barrier();
+#pragma unroll
+            for (int m = 0; m < M; m++) fbin[m] = __builtin_amdgcn_readfirstlane(((const int *)SC)[120 + m]);
+        }
         // first run: no valid previous estimate (fsk.c:750-753)
         if (cfg.bin_freq[fbin_prev[0]] < 1.0f) {
 #pragma unroll
@@ -214,8 +230,8 @@ __global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const W
 
         PROF_MARK(2);
         // ---- NCO phasor chain, lanes 0..M-1 (fsk.c:756-764, 781-798, 807-824) ---------------
-        if (lane < M) {
-            // lanes 0..M-1 carry one tone each.  Trip counts are wave-uniform (scalar loop control).
+        if (tid < M) {
+            // lanes 0..M-1 of wavefront 0 carry one tone each.  Trip counts are wave-uniform (scalar loop control).
             int bp = fbin_prev[0], bc = fbin[0];
 #pragma unroll
             for (int m = 1; m < M; m++) if (lane == m) { bp = fbin_prev[m]; bc = fbin[m]; }
@@ -252,7 +268,7 @@ __global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const W
 #pragma unroll
             for (int m = 0; m < M; m++) {
                 float2 *row = PH + m * Lpad;
-                for (int s = lane; s < L; s += 64) {
+                for (int s = tid; s < L; s += NT) {
                     const float2 x = src[s];
                     const float2 p = row[s];
                     const float2 pc = make_float2(p.x, -p.y);
@@ -265,7 +281,7 @@ __global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const W
         PROF_MARK(4);
         // ---- integrate-and-dump: every output re-sums the Ts circular-buffer slots in slot order
         //      (fsk.c:829-840).  Output i covers samples [i*q, i*q+Ts); sample s sits in slot s % Ts.
-        for (int i = lane; i < NI; i += 64) {
+        for (int i = tid; i < NI; i += NT) {
             const int base = i * q;
             const int r = base % Ts;
             int o = (r == 0) ? 0 : Ts - r;                                 // window offset of slot 0
@@ -299,11 +315,11 @@ __global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const W
 
         PROF_MARK(5);
         // ---- stash the tail of the new block for the next frame (fsk.c:851) ------------------
-        for (int i = lane; i < nstash; i += 64) X[i] = X[nstash + nin - nstash + i];
+        for (int i = tid; i < nstash; i += NT) X[i] = X[nstash + nin - nstash + i];
 
         // ---- fine timing: sum_i (sum_m |f_int|^2) * phi_ft[i]  (fsk.c:858-874) ---------------
         float2 *TP = PH;                                                   // down-converted samples are dead now
-        for (int i = lane; i < NI; i += 64) {
+        for (int i = tid; i < NI; i += NT) {
             float ft1 = 0.f;
 #pragma unroll
             for (int m = 0; m < M; m++) {
@@ -316,7 +332,7 @@ __global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const W
         lds_barrier();
         PROF_MARK(6);
         float tcr = 0.f, tci = 0.f;
-        {
+        if (NT == 64 || wave == 0) {
             // sequential float accumulation in index order (fsk.c:870): one packed add per product
             // (re and im sums are independent chains); every lane runs the uniform loop, lane 0's value
             // is used.  The next 8 products are loaded (128-bit LDS reads) before the current 8 are added.
@@ -341,6 +357,11 @@ __global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const W
             }
             for (; i < NI; i++) { const float2 v = TP[i]; acc = acc + (v2f){v.x, v.y}; }
             tcr = acc.x; tci = acc.y;
+        }
+        if (NT > 64) {                                                     // wavefront 0's sums to everyone
+            if (tid == 0) { SC[124] = tcr; SC[125] = tci; }
+            lds_barrier();
+            tcr = SC[124]; tci = SC[125];
         }
         tcr = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(tcr)));   // lane 0's sums, as wave-uniform values
         tci = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(tci)));
@@ -372,7 +393,7 @@ __global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const W
             const float omf = 1 - fract;
             tr_rxt = rx_timing;
             float mymax = 0.f;
-            if (lane < WR_NSYM) {
+            if (tid < WR_NSYM) {
                 const int st = (lane + 1) * P;
                 float tmax[M];
 #pragma unroll
@@ -408,9 +429,9 @@ __global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const W
                 }
             }
             if (cfg.stats) {                                               // Eb/N0 accumulators (fsk.c:984-1007)
-                if (lane < WR_NSYM) { SC[lane] = mymax; SC[WR_NSYM + lane] = sqrtf(mymax); }
+                if (tid < WR_NSYM) { SC[lane] = mymax; SC[WR_NSYM + lane] = sqrtf(mymax); }
                 lds_barrier();
-                if (lane == 0) {
+                if (tid == 0) {
                     float stdebno = 0.f, meanebno = 0.f;
                     for (int i = 0; i < WR_NSYM; i++) { stdebno += SC[i]; meanebno += SC[WR_NSYM + i]; }
                     meanebno = meanebno / cfg.nsym_f;
@@ -430,7 +451,7 @@ __global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const W
                 if (slot < C.dump_cap) {
                     float *d = C.dump + slot * cfg.dump_floats;
                     const int neye = cfg.eye_traces * M * cfg.neyesamp;
-                    for (int e = lane; e < neye; e += 64) {
+                    for (int e = tid; e < neye; e += NT) {
                         const int j = e % cfg.neyesamp;
                         const int tm = e / cfg.neyesamp;                 // = i*M + m
                         const int i = tm / M, m = tm - i * M;
@@ -439,8 +460,8 @@ __global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const W
                         if (ind >= 0 && ind < NI) { const float2 f = FI[m * NI + ind]; v = sqrtf(f.x * f.x + f.y * f.y); }
                         d[e] = v;
                     }
-                    for (int i = lane; i < NH; i += 64) d[neye + i] = FE[i];
-                    if (lane == 0) { d[neye + NH] = (float)high_sample; d[neye + NH + 1] = (float)frames; }
+                    for (int i = tid; i < NH; i += NT) d[neye + i] = FE[i];
+                    if (tid == 0) { d[neye + NH] = (float)high_sample; d[neye + NH + 1] = (float)frames; }
                 }
             }
         }
@@ -449,9 +470,9 @@ __global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const W
         // ---- emit the frame's outputs (fsk_demod.c:403-407): a NaN frame re-emits the previous buffer
         if (C.sd_out) {
             float *so = C.sd_out + frames * Nbits;
-            for (int i = lane; i < Nbits; i += 64) so[i] = SDL[i];
+            for (int i = tid; i < Nbits; i += NT) so[i] = SDL[i];
         }
-        if (C.trace && lane == 0) {
+        if (C.trace && tid == 0) {
             float *tr = C.trace + frames * WR_TRACE_FLOATS;
 #pragma unroll
             for (int m = 0; m < WR_M_MAX; m++) tr[WR_TR_FEST + m] = (m < M) ? cfg.bin_freq[fbin[m < M ? m : 0]] : 0.f;
@@ -468,17 +489,17 @@ __global__ __launch_bounds__(64) void wenet_demod_kernel(WrDemodCfg cfg, const W
         lds_barrier();
         PROF_MARK(9);
     }
-    if (PROF && C.prof && lane == 0) {
+    if (PROF && C.prof && tid == 0) {
 #pragma unroll
         for (int k = 0; k < WR_PROF_PHASES; k++) C.prof[k] = prof[k];
     }
 
     // ---- save carried state ---------------------------------------------------------------
-    for (int i = lane; i < NH; i += 64) st_fft[i] = FE[i];
-    for (int i = lane; i < nstash; i += 64) st_old[i] = X[i];
-    for (int i = lane; i < Nbits; i += 64) st_sd[i] = SDL[i];
-    if (lane < M) hdr->phi_c[lane] = phi_c;
-    if (lane == 0) {
+    for (int i = tid; i < NH; i += NT) st_fft[i] = FE[i];
+    for (int i = tid; i < nstash; i += NT) st_old[i] = X[i];
+    for (int i = tid; i < Nbits; i += NT) st_sd[i] = SDL[i];
+    if (tid < M) hdr->phi_c[tid] = phi_c;
+    if (tid == 0) {
 #pragma unroll
         for (int m = 0; m < M; m++) hdr->f_bin[m] = fbin_prev[m];
         hdr->norm_rx_timing = norm_rx_timing_st;
@@ -495,16 +516,16 @@ extern "C" hipError_t wr_launch_demod_pipe(const WrDemodCfg *cfg, const WrChan *
 extern "C" hipError_t wr_launch_demod_ex(const WrDemodCfg *cfg, const WrChan *d_chans, int nchan, hipStream_t stream, int prof) {
     if (nchan <= 0) return hipSuccess;
     if (cfg->pipe_ok && prof != 2) return wr_launch_demod_pipe(cfg, d_chans, nchan, stream, prof);   // 8 waves per capture, pipelined
-    dim3 grid(nchan), block(64);
-#define WR_LAUNCH(MM, PP, TT)                                                                                            \
+#define WR_LAUNCH(MM, PP, TT, NN)                                                                                        \
     do {                                                                                                                   \
-        (void)hipFuncSetAttribute((const void *)wenet_demod_kernel<MM, PP, TT>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+        (void)hipFuncSetAttribute((const void *)wenet_demod_kernel<MM, PP, TT, NN>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                   cfg->lds_bytes);                                                                          \
-        hipLaunchKernelGGL((wenet_demod_kernel<MM, PP, TT>), grid, block, cfg->lds_bytes, stream, *cfg, d_chans, nchan);   \
+        hipLaunchKernelGGL((wenet_demod_kernel<MM, PP, TT, NN>), dim3(nchan), dim3(NN), cfg->lds_bytes, stream, *cfg, d_chans, nchan); \
     } while (0)
-#define WR_LAUNCH_T(MM, PP) do { if (cfg->tables_in_lds) WR_LAUNCH(MM, PP, true); else WR_LAUNCH(MM, PP, false); } while (0)
-    if (cfg->M == 2) { if (prof) WR_LAUNCH_T(2, true); else WR_LAUNCH_T(2, false); }
-    else             { if (prof) WR_LAUNCH_T(4, true); else WR_LAUNCH_T(4, false); }
+#define WR_LAUNCH_T(MM, PP, NN) do { if (cfg->tables_in_lds) WR_LAUNCH(MM, PP, true, NN); else WR_LAUNCH(MM, PP, false, NN); } while (0)
+    // profiling (prof) keeps the one-wavefront form whose phase timings the instrumentation was written for
+    if (cfg->M == 2) { if (prof) WR_LAUNCH_T(2, true, 64); else WR_LAUNCH_T(2, false, 512); }
+    else             { if (prof) WR_LAUNCH_T(4, true, 64); else WR_LAUNCH_T(4, false, 512); }
 #undef WR_LAUNCH_T
 #undef WR_LAUNCH
     return hipGetLastError();

@@ -35,10 +35,6 @@
 
 namespace {
 
-__device__ __forceinline__ void wave_sync() {     // LDS ordering inside ONE wavefront (it runs in lockstep)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-}
-
 // barrier among the D waves only: monotone LDS counter, one arrival per wave per phase
 __device__ __forceinline__ void dsp_barrier(int *cnt, int target, int lane) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
