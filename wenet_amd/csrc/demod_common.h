@@ -49,13 +49,14 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f cmul_pk(v2f a, v2f b) {
     // (a.x*b.x - a.y*b.y, a.x*b.y + a.y*b.x), each product and each sum rounded separately (no FMA):
     //   t1 = (a.x*b.x, a.y*b.x)   t2 = (a.y*b.y, a.x*b.y)   r = (t1.x - t2.x, t1.y + t2.y)
-    // hipcc needs 5 VALU + 2 nops for this shape; written out it is 3 packed instructions.  The s_nop is the
-    // wait state hipcc itself places between a packed multiply and a packed add that reads its result.
+    // hipcc needs 5 VALU + 2 nops for this shape; written out it is 3 packed instructions, back to back.
+    // (hipcc pads a wait state after packed ops whose src0 has op_sel_hi set -- its dst_sel-forwarding rule keys on a
+    // modifier bit that VOP3P reuses; VALU RAW dependencies are interlocked by the hardware.  Every parity test
+    // runs millions of these dependent steps, the recurrence would expose a single wrong operand.)
 #ifndef WR_CHAIN_SCALAR
     v2f r, t1, t2;
     asm("v_pk_mul_f32 %1, %3, %4 op_sel_hi:[1,0]\n\t"
         "v_pk_mul_f32 %2, %3, %4 op_sel:[1,1] op_sel_hi:[0,1]\n\t"
-        "s_nop 0\n\t"
         "v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]"
         : "=v"(r), "=&v"(t1), "=&v"(t2)
         : "v"(a), "v"(b));

@@ -487,7 +487,7 @@ __global__ __launch_bounds__(WP_THREADS) void wenet_demod_pipe_kernel(WrDemodCfg
     };
 
     // the chain wave is the critical path of every frame: let it win VALU arbitration on its SIMD
-    if (wave == 0) __builtin_amdgcn_s_setprio(3);
+    if (wave == 0 && cfg.chain_prio) __builtin_amdgcn_s_setprio(3);
 
     // ================================ pipeline prologue ========================================
     //   E(0) | C(0),E(1) | D(0),C(1),E(2)         (frame 0 with the true nin, later frames speculative)

@@ -229,6 +229,7 @@ struct DemodTables {
             cfg.p_off_PFT = t;  t = align16(t + cfg.NI * 8);
             cfg.p_off_DPHI = t; t = align16(t + NH * 8);
             cfg.p_lds_bytes = t;
+            cfg.chain_prio = getenv("WENET_RX_CHAIN_PRIO") ? atoi(getenv("WENET_RX_CHAIN_PRIO")) : 0;   // s_setprio for the chain wave: helps one stream (~3 %), costs ~5 % at 2 captures per CU
             cfg.pipe_ok = (Nmax <= 2 * 320 && cfg.L / 8 + 2 <= 80 && t <= 80 * 1024 && getenv("WENET_RX_NO_PIPE") == nullptr) ? 1 : 0;
         }
         cfg.lds_bytes = o;
