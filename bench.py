@@ -95,7 +95,11 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1)))
+        backend = os.environ.get("WENET_BENCH_BACKEND", "nccl")          # "gloo" lets two ranks share one GPU in tests
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1)))
+        else:
+            dist.init_process_group(backend=backend)
     ndev = max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank % ndev)
     dev = torch.device("cuda", local_rank % ndev)
@@ -134,7 +138,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     k_ms /= max(args.steps, 1)
