@@ -13,3 +13,4 @@ for f in glob.glob(f"{root}/pmc_sq/*counter_collection.csv"):
     for (k, c), v in sorted(acc.items()):
         print(k, c, "n=%d" % len(v), "max=%.4g" % max(v))
 PY
+rm -rf $GRAFT_REPO_ROOT/gpurun_out/pmc_sq

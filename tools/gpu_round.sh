@@ -3,25 +3,44 @@ set -x
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 B=${1:-512}
-python bench.py --captures $B --steps 3 --warmup 1 2>&1 | tail -1 > gpurun_out/bench_b$B.json; cat gpurun_out/bench_b$B.json
+python bench.py --captures $B --steps 10 --warmup 1 2>&1 | tail -1 > gpurun_out/bench_b$B.json; cat gpurun_out/bench_b$B.json
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o r01 -- python $GRAFT_REPO_ROOT/bench.py --captures $B --steps 3 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o r01 -- python $GRAFT_REPO_ROOT/bench.py --captures $B --steps 10 --warmup 1 --no-cpu-baseline --no-single-stream > $GRAFT_REPO_ROOT/gpurun_out/prof_bench.log 2>&1
 head -8 $GRAFT_REPO_ROOT/gpurun_out/prof/r01_kernel_stats.csv | cut -c1-200
 # HBM traffic: separate PMC passes (FETCH_SIZE and WRITE_SIZE cannot share a pass), small batch to keep it short
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_fetch -o f -- python $GRAFT_REPO_ROOT/bench.py --captures 64 --steps 1 --warmup 0 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_write -o w -- python $GRAFT_REPO_ROOT/bench.py --captures 64 --steps 1 --warmup 0 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/pmc_write.log 2>&1
 ls $GRAFT_REPO_ROOT/gpurun_out/pmc_fetch $GRAFT_REPO_ROOT/gpurun_out/pmc_write
+python $GRAFT_REPO_ROOT/bench.py --captures 16 --steps 5 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 > $GRAFT_REPO_ROOT/gpurun_out/bench_b16.json
 python - <<'PY'
-import csv, glob, os
+import csv, glob, json, os
 root = os.environ["GRAFT_REPO_ROOT"] + "/gpurun_out"
-for tag in ("pmc_fetch", "pmc_write"):
+# per-launch durations of our kernels from the kernel trace (the stats file averages over warm-up launches too)
+with open(f"{root}/kernel_launches.csv", "w") as fo:
+    fo.write("kernel,grid_x,duration_ms\n")
+    for r in csv.DictReader(open(f"{root}/prof/r01_kernel_trace.csv")):
+        if "wenet" in r["Kernel_Name"]:
+            fo.write('"%s",%s,%.6f\n' % (r["Kernel_Name"].split("(")[0], r["Grid_Size_X"],
+                                        (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6))
+NS = 64 * 9600000
+out = {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (tools/gpu_round.sh), bench.py --captures 64 "
+               "--steps 1 --warmup 0; values are the 64-capture launch (614.4 M IQ samples). FETCH_SIZE is doubled (gfx950 counts "
+               "128-B requests at 64 B, MI355X_MICROARCH.md HBM section); WRITE_SIZE uncorrected.",
+       "samples_in_launch": NS, "kernels": {}}
+for tag, key in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     for f in glob.glob(f"{root}/{tag}/*counter_collection.csv"):
-        rows = list(csv.DictReader(open(f)))
         acc = {}
-        for r in rows:
-            k = r.get("Kernel_Name", "")[:40]
-            if "wenet" not in k: continue
-            acc.setdefault((k, r["Counter_Name"]), []).append(float(r["Counter_Value"]))
-        for (k, c), v in acc.items():
-            print(tag, k, c, "n=%d" % len(v), "mean=%.1f" % (sum(v) / len(v)), "max=%.1f" % max(v))
+        for r in csv.DictReader(open(f)):
+            k = r.get("Kernel_Name", "")
+            if "wenet" in k and r["Counter_Name"] == key:
+                acc[k[:60]] = max(acc.get(k[:60], 0.0), float(r["Counter_Value"]))
+        for k, v in acc.items():
+            out["kernels"].setdefault(k, {})[key + "_KB_raw"] = v
+for k, d in out["kernels"].items():
+    d["read_bytes_corrected"] = 2 * 1024 * d.get("FETCH_SIZE_KB_raw", 0.0)
+    d["write_bytes"] = 1024 * d.get("WRITE_SIZE_KB_raw", 0.0)
+    d["hbm_bytes"] = d["read_bytes_corrected"] + d["write_bytes"]
+    d["hbm_bytes_per_iq_sample"] = d["hbm_bytes"] / NS
+json.dump(out, open(f"{root}/pmc_traffic.json", "w"), indent=1)
+print(json.dumps({k[:30]: round(v["hbm_bytes_per_iq_sample"], 4) for k, v in out["kernels"].items()}))
 PY

@@ -31,6 +31,7 @@
 #define WP_KP 2                     // raw samples prefetched per D thread (2*320 >= N+Ts/2 is required)
 #define WP_DSP_WAVES 5
 #define WP_CK 8                     // the chain wave stores every WP_CK-th phasor; D threads replay the steps in between
+#define WP_SPIN_SLEEP 3                // s_sleep units (64 clk) between polls of a D-wave barrier: spinning waves steal issue slots
 #define WP_CKROW 80                 // checkpoints per (segment, tone) row; needs >= (Nmem-Ts/P)/WP_CK + 2
 
 namespace {
@@ -39,7 +40,7 @@ namespace {
 __device__ __forceinline__ void dsp_barrier(int *cnt, int target, int lane) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(WP_SPIN_SLEEP);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
