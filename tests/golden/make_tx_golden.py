@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Golden vectors for the transmit-side format, FROM THE REFERENCE ITSELF.
+
+Run in the development container (needs /root/reference):
+
+  * parity     tx/ldpc_enc.c `encode` -- compiled unmodified into oracle/_ref/ldpc_enc.so by
+               `make -C oracle ref` exactly as its own header says -- on random 258-byte blocks
+  * noise      benchmarking/generate_lowsnr.py `calculate_variance` + `add_noise`, imported as a module,
+               driven by numpy's legacy global generator with a fixed seed
+
+The rest of the transmitter (tx/PacketTX.py, tx/radio_wrappers.py) cannot be imported here (it needs
+crcmod / pyserial, which this image lacks), so the frame layout is pinned the other way round: the
+reference RECEIVER (oracle/_ref/drs232_ldpc, wenet_ldpc) finds the unique word, decodes the LDPC block and
+accepts the CRC of every frame this repository builds (tests/golden/make_golden.py, tests/test_gpu_tx.py).
+Only data is stored: inputs and expected outputs.
+"""
+import ctypes as C
+import importlib.util
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib as ol  # noqa: E402
+from wenet_amd import siggen  # noqa: E402
+
+REF = os.environ.get("WENET_REF", "/root/reference")
+
+
+def main():
+    ol.build_ref()
+    enc = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "ldpc_enc.so"))
+    enc.encode.restype = None
+    enc.encode.argtypes = [C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(8601)
+    blocks = rng.integers(0, 256, (8, 258), dtype=np.uint8)
+    blocks[0] = 0
+    blocks[1] = 0xFF
+    par = np.zeros((8, 516), np.uint8)
+    for i in range(8):
+        ib = np.unpackbits(blocks[i]).astype(np.uint8)
+        pb = np.zeros(516, np.uint8)
+        enc.encode(ib.ctypes.data, pb.ctypes.data)
+        par[i] = pb
+
+    spec = importlib.util.spec_from_file_location("generate_lowsnr", os.path.join(REF, "benchmarking", "generate_lowsnr.py"))
+    gl = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gl)
+    cfg = siggen.config_v2()
+    bits = rng.integers(0, 2, 400, dtype=np.uint8)
+    x = siggen.modulate(bits, cfg)
+    var = gl.calculate_variance(x, -100.0)
+    np.random.seed(777)
+    y = gl.add_noise(x, variance=var, baud_rate=cfg.Rs, ebno=8.0, fs=cfg.Fs)
+    np.savez_compressed(os.path.join(HERE, "tx_golden.npz"), blocks=blocks, parity=par,
+                        noise_bits=bits, noise_in=x, noise_var=np.float64(var), noise_seed=np.int32(777),
+                        noise_ebno=np.float64(8.0), noise_out=y)
+    print("parity ones per block:", par.sum(axis=1), "noise var", var, "max|y|", np.abs(y).max())
+
+
+if __name__ == "__main__":
+    main()

@@ -1,4 +1,4 @@
-"""CPU: the C-ABI library loads and exports every symbol include/wenet_rx.h declares (no compute calls)."""
+"""CPU: the C-ABI library loads and exports every symbol include/*.h declares (no compute calls)."""
 import os
 import re
 
@@ -8,8 +8,8 @@ from wenet_amd import lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_functions():
-    txt = open(os.path.join(ROOT, "include", "wenet_rx.h")).read()
+def declared_functions(header="wenet_rx.h"):
+    txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(wenet_[a-z0-9_]+)\s*\(", txt)))
 
@@ -21,6 +21,10 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in names if not hasattr(L, n)]
     assert missing == []
     assert sorted(lib.EXPORTS) == names
+    names_tx = declared_functions("wenet_tx.h")
+    assert [n for n in names_tx if not hasattr(L, n)] == []
+    assert sorted(lib.EXPORTS_TX) == names_tx
+    assert sorted(os.listdir(os.path.join(ROOT, "include"))) == ["wenet_rx.h", "wenet_tx.h"]
 
 
 def test_every_declaration_cites_the_reference():
@@ -35,6 +39,7 @@ def test_fails_loudly_without_gpu():
         assert not L.wenet_fsk_create_hbr(960000, 96000, 10, 2, 1200, 400)
         assert not L.wenet_rx_create(960000, 96000, 10, 2, 2, 10, 0, 0)
         assert not L.wenet_deframer_create(2, 10)
+        assert not L.wenet_tx_create(960000, 96000, 2, 2, 168000.0, 96000.0)
 
 
 def test_illegal_rates_are_rejected():

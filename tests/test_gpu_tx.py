@@ -1,0 +1,202 @@
+"""GPU: the batched frame builder / test-signal generator (include/wenet_tx.h).
+
+Bit-exact parts (CRC, LDPC parity, scramble, bit expansion, tone keying) are compared with the numpy statement
+in wenet_amd/siggen.py and with parity vectors produced by the reference's tx/ldpc_enc.c (tests/golden/tx_golden.npz).
+The modulator has no reference implementation on the Wenet path; it is checked through its properties and by
+feeding its captures to the reference RECEIVER (oracle/_ref) and to the oracle.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as ol
+from conftest import GOLDEN_DIR, bits_equal
+from wenet_amd import siggen
+from wenet_amd.fsk import Fsk
+from wenet_amd.rx import RxBatch
+from wenet_amd.tx import Tx
+
+pytestmark = pytest.mark.gpu
+
+
+def numpy_symbols(payloads, cfg):
+    bits = np.concatenate([siggen.bytes_to_air_bits(siggen.frame_packet(bytes(p), cfg.mode), cfg.mode) for p in payloads])
+    if cfg.M == 4:
+        b = bits.reshape(-1, 2)
+        return (3 - ((b[:, 0] << 1) | b[:, 1])).astype(np.uint8)
+    return bits.astype(np.uint8)
+
+
+@pytest.mark.parametrize("name", ["v1", "v2", "4fsk"])
+def test_frame_builder_equals_numpy_statement(name):
+    cfg = siggen.CONFIGS[name]()
+    rng = np.random.default_rng(31)
+    payloads = rng.integers(0, 256, (37, 256), dtype=np.uint8)
+    payloads[0] = 0
+    payloads[1] = 0xFF
+    payloads[2] = 0x56                                   # the transmitter's idle packet body (tx/PacketTX.py:69)
+    tx = Tx.from_config(cfg)
+    assert tx.symbols_per_packet == cfg.symbols_per_frame
+    got = tx.frame_packets(payloads)
+    assert (got == numpy_symbols(payloads, cfg)).all()
+    assert tx.frame_packets(payloads[:0]).size == 0      # empty batch
+    tx.close()
+
+
+def test_parity_equals_reference_encoder_golden():
+    """v1 framing leaves payload+crc+parity unscrambled: recover the 65 parity bytes from the RS-232 symbols and
+    compare with tx/ldpc_enc.c's output for the same 258-byte block (the CRC is part of the block there)."""
+    g = np.load(os.path.join(GOLDEN_DIR, "tx_golden.npz"))
+    cfg = siggen.config_v1()
+    tx = Tx.from_config(cfg)
+    O = ol.oracle()
+    rng = np.random.default_rng(5)
+    payloads = rng.integers(0, 256, (16, 256), dtype=np.uint8)
+    sym = tx.frame_packets(payloads).reshape(16, -1, 10)
+    assert (sym[:, :, 0] == 0).all() and (sym[:, :, 9] == 1).all()
+    by = np.packbits(sym[:, :, 8:0:-1].reshape(16, -1), axis=1)             # LSB-first on air -> bytes
+    assert (by[:, :16] == 0x55).all() and (by[:, 16:20] == [0xAB, 0xCD, 0xEF, 0x01]).all()
+    assert (by[:, 20:276] == payloads).all()
+    for k in range(16):
+        crc = siggen.crc16_ccitt_false(payloads[k].tobytes())
+        assert by[k, 276] == (crc & 0xFF) and by[k, 277] == (crc >> 8)
+        pb = np.zeros(516, np.uint8)
+        O.ora_ldpc_encode(np.unpackbits(by[k, 20:278]), pb)                  # restatement, pinned to the golden below
+        assert (np.unpackbits(by[k, 278:343])[:516] == pb).all() and (np.unpackbits(by[k, 278:343])[516:] == 0).all()
+    for blk, par in zip(g["blocks"], g["parity"]):                           # the reference encoder's own vectors
+        pb = np.zeros(516, np.uint8)
+        O.ora_ldpc_encode(np.unpackbits(blk), pb)
+        assert (pb == par).all()
+    tx.close()
+
+
+def _generate(cfg, payloads, ebno, ppm=0.0, seed=1, fmt="cu8"):
+    tx = Tx.from_config(cfg)
+    dev = torch.device("cuda", 0)
+    p = torch.from_numpy(np.ascontiguousarray(payloads)).to(dev)
+    nsym = payloads.shape[0] * tx.symbols_per_packet
+    sym = torch.empty(nsym, dtype=torch.uint8, device=dev)
+    tx.frame_packets_device(p.data_ptr(), payloads.shape[0], sym.data_ptr())
+    out = torch.zeros(nsym * cfg.Ts * (2 if fmt == "cu8" else 4), dtype=torch.uint8, device=dev)
+    tx.modulate_device([sym.data_ptr()], [nsym], [out.data_ptr()], ebno, ppm=ppm, seeds=[seed], fmt=fmt)
+    torch.cuda.synchronize()
+    raw = out.cpu().numpy()
+    tx.close()
+    return raw if fmt == "cu8" else raw.view(np.int16)
+
+
+@pytest.mark.parametrize("name,fmt", [("v2", "cu8"), ("v1", "cs16"), ("4fsk", "cu8")])
+def test_noise_free_phase_matches_numpy_modulator(name, fmt):
+    cfg = siggen.CONFIGS[name]()
+    rng = np.random.default_rng(77)
+    payloads = rng.integers(0, 256, (3, 256), dtype=np.uint8)
+    raw = _generate(cfg, payloads, 1000.0, fmt=fmt)
+    bits = np.concatenate([siggen.bytes_to_air_bits(siggen.frame_packet(bytes(p), cfg.mode), cfg.mode) for p in payloads])
+    x = siggen.modulate(bits, cfg)
+    if fmt == "cu8":
+        iq = (raw.astype(np.float64).reshape(-1, 2) - 128.0) / 127.5
+        tol = 1.5 / 127.5                                    # one quantisation step (truncation) + phase rounding
+    else:
+        iq = raw.astype(np.float64).reshape(-1, 2) / 1000.0
+        tol = 0.6 / 1000.0 + 2e-5
+    assert iq.shape[0] == x.size
+    assert np.abs(iq[:, 0] - x.real).max() <= tol and np.abs(iq[:, 1] - x.imag).max() <= tol
+
+
+def test_generated_capture_is_decoded_by_the_reference_receiver():
+    """GPU-built frames + GPU modulator -> the UNMODIFIED reference binaries find every packet, and the GPU
+    receive path returns the same bytes."""
+    if not ol.have_ref():
+        pytest.skip("oracle/_ref not built")
+    for name, eb in (("v1", 11.0), ("v2", 11.0)):
+        cfg = siggen.CONFIGS[name]()
+        rng = np.random.default_rng(900)
+        payloads = rng.integers(0, 256, (12, 256), dtype=np.uint8)
+        raw = _generate(cfg, payloads, eb, seed=42)
+        sd, _ = ol.ref_cli_demod(raw, "cu8", cfg.Fs, cfg.Rs, cfg.M, soft=True)
+        pk, _ = ol.ref_cli_ldpc(sd, cfg.mode)
+        got = [pk[i * 256:(i + 1) * 256] for i in range(len(pk) // 256)]
+        sent = [p.tobytes() for p in payloads]
+        assert len(got) >= 10 and all(g in sent for g in got)            # the first frame(s) go to estimator acquisition
+        rx = RxBatch(cfg.Fs, cfg.Rs, cfg.M, framing=cfg.mode)
+        rx.process([raw], "cu8")
+        assert rx.valid_payloads(0) == pk
+        rx.close()
+
+
+def test_noise_level_and_determinism():
+    cfg = siggen.config_v2()
+    rng = np.random.default_rng(4)
+    payloads = rng.integers(0, 256, (6, 256), dtype=np.uint8)
+    a = _generate(cfg, payloads, 8.0, seed=7)
+    b = _generate(cfg, payloads, 8.0, seed=7)
+    c = _generate(cfg, payloads, 8.0, seed=8)
+    assert (a == b).all() and (a != c).mean() > 0.5
+    clean = _generate(cfg, payloads, 1000.0)
+    # noise variance per rail relative to the signal amplitude: sigma^2 = Fs / (2 Rs EbN0)  (generate_lowsnr.py:75-79)
+    za = (a.astype(np.float64).reshape(-1, 2) - 127.5)
+    zc = (clean.astype(np.float64).reshape(-1, 2) - 127.5)
+    gain = np.sum(za * zc) / np.sum(zc * zc)                         # normalisation by max|x| shrinks the noisy capture
+    resid = za - gain * zc
+    want = cfg.Fs / (2.0 * cfg.Rs * 10.0 ** 0.8)
+    got = resid.var() / (gain * 127.5) ** 2
+    assert abs(got / want - 1.0) < 0.03
+    mag = np.hypot(*((a.astype(np.float64).reshape(-1, 2) - 128.0) / 127.5).T)
+    assert 1.0 - 2.5 / 127.5 <= mag.max() <= 1.0 + 1.5 / 127.5              # divided by its own max|x| (generate_lowsnr.py:85-87)
+
+
+def test_symbol_clock_error_moves_the_receiver_timing():
+    """ppm != 0 stretches symbols; the demodulator must slip (nin != N) and its ppm estimate has the right sign;
+    results still equal the oracle's."""
+    cfg = siggen.config_v2()
+    rng = np.random.default_rng(14)
+    payloads = rng.integers(0, 256, (8, 256), dtype=np.uint8)
+    est = {}
+    for ppm in (400.0, -400.0):
+        raw = _generate(cfg, payloads, 12.0, ppm=ppm, seed=3)
+        assert raw.size == 2 * 8 * cfg.symbols_per_frame * cfg.Ts
+        f = Fsk(cfg.Fs, cfg.Rs, cfg.Ts, cfg.M)
+        sd, _, trace = f.demod_stream(raw, "cu8", want_trace=True)
+        ref, _ = ol.oracle_demod(raw, "cu8", cfg.Fs, cfg.Rs, cfg.M)
+        assert bits_equal(sd, ref)
+        assert (trace[:, 4] != cfg.Ts * 48).sum() >= 2              # nin slips
+        est[ppm] = float(np.median(trace[trace.shape[0] // 2:, 6]))  # the demodulator's own ppm estimate (fsk.c:890-896)
+        f.close()
+    assert est[400.0] * est[-400.0] < 0
+    assert 200.0 < abs(est[400.0]) < 600.0 and 200.0 < abs(est[-400.0]) < 600.0
+
+
+def test_batch_of_captures_with_per_capture_parameters():
+    cfg = siggen.config_v2()
+    tx = Tx.from_config(cfg)
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(55)
+    ncap, npk = 5, 9
+    payloads = rng.integers(0, 256, (ncap * npk, 256), dtype=np.uint8)
+    spp = tx.symbols_per_packet
+    sym = torch.empty(ncap * npk * spp, dtype=torch.uint8, device=dev)
+    tx.frame_packets_device(torch.from_numpy(payloads).to(dev).data_ptr(), ncap * npk, sym.data_ptr())
+    nsym = [npk * spp - 100 * c for c in range(ncap)]                          # ragged lengths
+    outs = [torch.zeros(2 * n * cfg.Ts, dtype=torch.uint8, device=dev) for n in nsym]
+    ebno = [20.0, 12.0, 9.0, 1000.0, 3.0]
+    tx.modulate_device([sym.data_ptr() + c * npk * spp for c in range(ncap)], nsym, [o.data_ptr() for o in outs], ebno,
+                       ppm=[0.0, 50.0, -50.0, 0.0, 0.0], seeds=list(range(100, 100 + ncap)))
+    torch.cuda.synchronize()
+    rx = RxBatch(cfg.Fs, cfg.Rs, cfg.M, framing=cfg.mode)
+    rx.enqueue_device([o.data_ptr() for o in outs], [n * cfg.Ts for n in nsym], "cu8")
+    rx.collect()
+    for c in range(4):                                                          # 3 dB: nothing decodes
+        sent = [payloads[c * npk + k].tobytes() for k in range(npk)]
+        blob = rx.valid_payloads(c)
+        got = [blob[i * 256:(i + 1) * 256] for i in range(len(blob) // 256)]
+        assert len(got) >= npk - 3 and all(g in sent for g in got)
+    assert len(rx.valid_payloads(4)) == 0
+    # every capture equals what the oracle makes of the same bytes
+    for c in (1, 4):
+        raw = outs[c].cpu().numpy()
+        ref, _ = ol.oracle_demod(raw, "cu8", cfg.Fs, cfg.Rs, cfg.M)
+        assert bits_equal(rx.soft(c), ref)
+    rx.close()
+    tx.close()

@@ -28,6 +28,11 @@ EXPORTS = [
     "wenet_rx_enable_trace", "wenet_rx_get_trace", "wenet_rx_enable_llr_dump", "wenet_rx_get_llrs",
     "wenet_rx_last_ms", "wenet_rx_device_info", "wenet_rx_version",
 ]
+# every symbol include/wenet_tx.h declares
+EXPORTS_TX = [
+    "wenet_tx_create", "wenet_tx_destroy", "wenet_tx_symbols_per_packet", "wenet_tx_frame_packets",
+    "wenet_tx_modulate",
+]
 
 
 class PacketInfo(C.Structure):
@@ -93,5 +98,11 @@ def load():
     L.wenet_rx_last_ms.restype = f; L.wenet_rx_last_ms.argtypes = [vp, i]
     L.wenet_rx_device_info.argtypes = [i]
     L.wenet_rx_version.restype = C.c_char_p
+    d = C.c_double
+    L.wenet_tx_create.restype = vp; L.wenet_tx_create.argtypes = [i, i, i, i, d, d]
+    L.wenet_tx_destroy.argtypes = [vp]
+    L.wenet_tx_symbols_per_packet.restype = ll; L.wenet_tx_symbols_per_packet.argtypes = [vp]
+    L.wenet_tx_frame_packets.argtypes = [vp, vp, ll, vp, i, vp]
+    L.wenet_tx_modulate.argtypes = [vp, i, vp, vp, vp, vp, vp, i, vp, vp]
     _lib = L
     return L

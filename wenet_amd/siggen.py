@@ -164,12 +164,17 @@ def modulate(bits: np.ndarray, cfg: ModemConfig, ppm: float = 0.0) -> np.ndarray
     return np.exp(1j * ph)
 
 
-def add_noise(x: np.ndarray, cfg: ModemConfig, ebno_db: float, rng) -> np.ndarray:
+def add_noise(x: np.ndarray, cfg: ModemConfig, ebno_db: float, rng, normal=None) -> np.ndarray:
+    """benchmarking/generate_lowsnr.py:70-89 (same expression order; `normal(n)` replaces the script's
+    numpy.random.randn so that the test can drive both with one stream)."""
+    if normal is None:
+        normal = rng.standard_normal
     bps = 1.0 if cfg.M == 2 else 2.0
     ebno = 10.0 ** (ebno_db / 10.0)
     nv = np.var(x) * cfg.Fs / (cfg.Rs * ebno * bps)
-    s = np.sqrt(nv / 2.0)
-    noisy = x + s * rng.standard_normal(x.size) + 1j * s * rng.standard_normal(x.size)
+    ri = np.sqrt(nv / 2.0) * normal(len(x))
+    rq = np.sqrt(nv / 2.0) * normal(len(x))
+    noisy = x + (ri + 1j * rq)
     return noisy / np.max(np.abs(noisy))
 
 
