@@ -111,11 +111,25 @@ def main():
     nsym = int(args.seconds * cfg.Rs)
     nsamp = nsym * cfg.Ts
     B = args.captures
-    # synthetic captures, generated on the GPU: distinct payload streams (up to 8) x independent noise
-    streams = [siggen.air_symbols(cfg, nsym, 2001 + 97 * k + 1000 * rank)[0] for k in range(min(B, 8))]
-    caps = [siggen.make_capture_torch(cfg, streams[i % len(streams)], args.ebno, 7000 + i + 100000 * rank, dev)
-            for i in range(B)]
+    # synthetic captures, born in HBM: random payloads -> frames -> M-FSK + AWGN by the library's own generator
+    # kernels (include/wenet_tx.h; format pinned in tests/test_gpu_tx.py).  torch only owns the memory.
+    from wenet_amd.tx import Tx
+    tx = Tx.from_config(cfg)
+    spp = tx.symbols_per_packet
+    nfr = nsym // spp + 1
+    g = torch.Generator(device=dev)
+    g.manual_seed(2001 + 1000 * rank)
+    payloads = torch.randint(0, 256, (B * nfr, 256), dtype=torch.uint8, device=dev, generator=g)
+    symbols = torch.empty(B * nfr * spp, dtype=torch.uint8, device=dev)
+    tx.frame_packets_device(payloads.data_ptr(), B * nfr, symbols.data_ptr())
+    caps = [torch.empty(2 * nsamp, dtype=torch.uint8, device=dev) for _ in range(B)]
     torch.cuda.synchronize()
+    tg = time.perf_counter()
+    tx.modulate_device([symbols.data_ptr() + i * nfr * spp for i in range(B)], [nsym] * B, [c.data_ptr() for c in caps],
+                       args.ebno, seeds=[7000 + i + 100000 * rank for i in range(B)])
+    torch.cuda.synchronize()
+    datagen_s = time.perf_counter() - tg
+    del symbols
     ptrs = [int(c.data_ptr()) for c in caps]
     ns = [nsamp] * B
 
@@ -180,6 +194,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "datagen": {"by": "wenet_tx_modulate (GPU)", "ms": round(datagen_s * 1e3, 1),
+                        "gsamples_per_s": round(B * nsamp / datagen_s / 1e9, 2)},
             "config": {"workload": f"{cfg.name} {cfg.M}-FSK Rs={cfg.Rs} Fs={cfg.Fs} cu8 Eb/N0={args.ebno}dB "
                                    f"{args.seconds:g}s x {B} independent captures per GPU (BASELINE config 2 shape, batched)",
                        "captures_per_gpu": B, "samples_per_capture": nsamp, "framing": cfg.mode, "ldpc_max_iter": 10},

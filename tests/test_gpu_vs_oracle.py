@@ -236,6 +236,27 @@ def test_heavy_clock_error_many_slips(name, ppm):
     f.close()
 
 
+@pytest.mark.parametrize("name,ppm,shift", [("v1", 3000.0, 0.0), ("v1", 5000.0, 0.0), ("v1", -6000.0, 0.0), ("v2", 4000.0, 0.0),
+                                            ("v2", 0.0, 30000.0), ("v2", 0.0, -45000.0), ("v1", 3000.0, 12000.0), ("v2", 0.0, 260000.0)])
+def test_baud_rate_error_and_frequency_shift(name, ppm, shift):
+    """The reference benchmark's robustness knobs (benchmarking/test_demod.py:71-73, README "Baud Rate Error":
+    resampling by 1.003 .. 1.006, and a frequency shift before the demodulator).  Whatever the reference does
+    with such a capture -- degrade, lose lock, chase a tone that left the estimator band -- the GPU does the same."""
+    import dataclasses
+    cfg0 = siggen.CONFIGS[name]()
+    cfg = dataclasses.replace(cfg0, f_low=cfg0.f_low + shift)
+    raw, _ = siggen.make_capture(cfg, 4, 12.0, seed=int(abs(ppm) + abs(shift) / 100), ppm=ppm)
+    ref, tr = ol.oracle_demod(raw, "cu8", cfg.Fs, cfg.Rs, cfg.M, want_trace=True)
+    rx = RxBatch(cfg.Fs, cfg.Rs, cfg.M, framing=cfg.mode)
+    rx.enable_trace()
+    rx.process([raw], "cu8")
+    assert bits_equal(rx.soft(0), ref)
+    assert bits_equal(np.ascontiguousarray(rx.trace(0)[:, :7]), np.ascontiguousarray(tr[:, :7]))
+    d = ol.oracle_deframe(ref, cfg.mode)
+    assert rx.valid_payloads(0) == b"".join(bytes(d["bytes"][i][:256]) for i in range(d["n"]) if d["crc_ok"][i])
+    rx.close()
+
+
 def test_every_capture_length_around_frame_boundaries():
     """0..4 frames +- one sample, one launch each and all together as a ragged batch."""
     cfg = siggen.config_v2()
