@@ -64,6 +64,19 @@ __global__ void k(float *out, long long *cyc, int iters) {
                 asm volatile("v_pk_mul_f32 %1, %0, %3 op_sel_hi:[1,0]\n v_pk_mul_f32 %2, %0, %3 op_sel:[1,1] op_sel_hi:[0,1]\n s_nop 0\n"
                              "v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "+v"(p), "=&v"(t1), "=&v"(t2) : "v"(q));
             }
+        } else if (MODE == 10) {  // complex multiply chain on a lane PAIR (re in even lane, im in odd lane): mul, nop, mul_dpp, add
+            float t1, t2;
+            for (int u = 0; u < 4; u++)
+                asm volatile("v_mul_f32 %1, %0, %3\n s_nop 0\n v_mul_f32_dpp %2, %0, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                             "v_add_f32 %0, %1, %2" : "+v"(a), "=&v"(t1), "=&v"(t2) : "v"(b), "v"(c));
+        } else if (MODE == 11) {  // lane pair, both products local, swap inside the add: mul, mul, nop 1, add_dpp
+            float t1, t2;
+            for (int u = 0; u < 4; u++)
+                asm volatile("v_mul_f32 %2, %0, %4\n v_mul_f32 %1, %0, %3\n s_nop 0\n v_add_f32_dpp %0, %2, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+                             : "+v"(a), "=&v"(t1), "=&v"(t2) : "v"(b), "v"(c));
+        } else if (MODE == 12) {  // dependent v_mul_f32 x8
+            asm volatile("v_mul_f32 %0, %0, %1\n v_mul_f32 %0, %0, %1\n v_mul_f32 %0, %0, %1\n v_mul_f32 %0, %0, %1\n"
+                         "v_mul_f32 %0, %0, %1\n v_mul_f32 %0, %0, %1\n v_mul_f32 %0, %0, %1\n v_mul_f32 %0, %0, %1" : "+v"(a) : "v"(b));
         } else if (MODE == 6) {   // packed cmul without the nop
             v2f t1, t2;
             for (int u = 0; u < 4; u++)
@@ -80,7 +93,7 @@ template <int MODE> void run(const char *name, int ops_per_iter) {
     float *out; long long *cyc;
     hipMalloc(&out, 4 * 1024 * 1024); hipMalloc(&cyc, 8 * 4096);
     const int iters = 20000;
-    for (int waves : {1, 4}) {       // waves per block (block = one CU here: 1 block)
+    for (int waves : {1, 4, 8, 16}) {       // waves per block (block = one CU here: 1 block)
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         hipLaunchKernelGGL(k<MODE>, dim3(1), dim3(64 * waves), 32768, 0, out, cyc, 100);
         hipEventRecord(e0); hipLaunchKernelGGL(k<MODE>, dim3(1), dim3(64 * waves), 32768, 0, out, cyc, iters); hipEventRecord(e1);
@@ -98,6 +111,9 @@ int main() {
     run<3>("cmul packed+nop (per step)", 4);
     run<6>("cmul packed no nop", 4);
     run<4>("cmul scalar (per step)", 4);
+    run<12>("dep v_mul_f32", 8);
+    run<10>("cmul lane-pair mul_dpp", 4);
+    run<11>("cmul lane-pair add_dpp", 4);
     run<9>("cmul packed+nop, 2 lanes", 4);
     run<7>("cmul + ds_write (compiler)", 4);
     run<8>("cmul + ds_write in nop slot", 4);

@@ -48,8 +48,12 @@ enum { CT_NIN_NEXT = 0, CT_CNT = 1, CT_FBIN = 4 /* [4 frames][4 tones] */, CT_IN
 
 }  // namespace
 
-template <int M, bool PROF>
-__global__ __launch_bounds__(WP_THREADS) void wenet_demod_pipe_kernel(WrDemodCfg cfg, const WrChan *chans, int nchan) {
+// RAW: every capture of the launch is cu8 -> the sample ring keeps the raw byte pairs (2 B instead of 8 B per
+// sample; (u8-127)/128 is exact, so converting at each read gives the same floats) and the timing-product
+// phasors stay in global memory.  That brings the workgroup under a third of a CU's LDS and, with the register
+// bound below, lets THREE captures share a CU instead of two.
+template <int M, bool PROF, bool RAW>
+__global__ __launch_bounds__(WP_THREADS, RAW ? 6 : 5) void wenet_demod_pipe_kernel(WrDemodCfg cfg, const WrChan *chans, int nchan) {
     const int ch = blockIdx.x;
     if (ch >= nchan) return;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -58,6 +62,7 @@ __global__ __launch_bounds__(WP_THREADS) void wenet_demod_pipe_kernel(WrDemodCfg
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float2 *XR = (float2 *)(smem + cfg.p_off_XR);     // [ring]        sample ring, index (abs + nstash) & mask
+    unsigned short *XRr = (unsigned short *)(smem + cfg.p_off_XR);      // the same ring as raw cu8 pairs (RAW)
     float2 *DCb = (float2 *)(smem + cfg.p_off_PH);    // [M][Lpad]     mixed samples -> timing products
     float2 *CKb = (float2 *)(smem + cfg.p_off_CK);    // [2 frames][2 segments][M][WP_CKROW] phasor checkpoints
     float2 *CKD = (float2 *)(smem + cfg.p_off_CKD);   // [2 frames][2 segments][M] NCO step of each segment
@@ -81,6 +86,17 @@ __global__ __launch_bounds__(WP_THREADS) void wenet_demod_pipe_kernel(WrDemodCfg
     const int Nbits = cfg.Nbits, Nmax = N + Ts / 2;
     const int rmask = cfg.p_ring - 1;
 #define RIDX(a) ((int)(((a) + nstash) & rmask))
+    auto ring_get = [&](int ri) -> float2 {
+        if (RAW) { const unsigned w = XRr[ri]; return make_float2(((float)(w & 0xffu) - 127.0f) / 128.0f, ((float)(w >> 8) - 127.0f) / 128.0f); }
+        return XR[ri];
+    };
+    auto ring_put_raw = [&](int ri, uint2 r, int fmt) {               // r as returned by load_raw
+        if (RAW) XRr[ri] = (unsigned short)r.x; else XR[ri] = convert_raw(r, fmt);
+    };
+    auto ring_put_f = [&](int ri, float2 v) {                          // carried samples: exact inverse of the cu8 conversion
+        if (RAW) XRr[ri] = (unsigned short)((unsigned)(int)(v.x * 128.0f + 127.0f) | ((unsigned)(int)(v.y * 128.0f + 127.0f) << 8));
+        else XR[ri] = v;
+    };
 
     // ---- carried state -> LDS ------------------------------------------------------------------
     WrChanHdr *hdr = (WrChanHdr *)C.state;
@@ -92,12 +108,12 @@ __global__ __launch_bounds__(WP_THREADS) void wenet_demod_pipe_kernel(WrDemodCfg
         int *src_w = (int *)(smem + cfg.p_off_SRC); float2 *pft_w = (float2 *)(smem + cfg.p_off_PFT);
         float2 *dphi_w = (float2 *)(smem + cfg.p_off_DPHI);
         for (int i = tid; i < Ndft; i += WP_THREADS) { tw_w[i] = cfg.tw[i]; hann_w[i] = cfg.hann[i]; src_w[i] = cfg.fft_src[i]; }
-        for (int i = tid; i < NI; i += WP_THREADS) pft_w[i] = cfg.phi_ft[i];
+        if (!RAW) for (int i = tid; i < NI; i += WP_THREADS) pft_w[i] = cfg.phi_ft[i];
         for (int i = tid; i < NH; i += WP_THREADS) dphi_w[i] = cfg.dphi_tab[i];
     }
     for (int i = tid; i < NH; i += WP_THREADS) FEr[3 * NH + i] = st_fft[i];           // "after frame -1" lives in slot 3
     for (int i = tid; i < Nbits; i += WP_THREADS) SDL[i] = st_sd[i];
-    for (int i = tid; i < nstash; i += WP_THREADS) XR[RIDX((long long)(i - nstash))] = st_old[i];
+    for (int i = tid; i < nstash; i += WP_THREADS) ring_put_f(RIDX((long long)(i - nstash)), st_old[i]);
     if (tid < M) { PHE[2 * 4 + tid] = hdr->phi_c[tid]; CT[CT_FBIN + 3 * 4 + tid] = hdr->f_bin[tid]; }   // frame -1 -> slots 2 / 3
     if (tid == 0) { CT[CT_CNT] = 0; CT[CT_NIN_NEXT] = hdr->nin; }
     int nin = __builtin_amdgcn_readfirstlane(hdr->nin);
@@ -105,7 +121,8 @@ __global__ __launch_bounds__(WP_THREADS) void wenet_demod_pipe_kernel(WrDemodCfg
     {
         const long long last = C.nsamples - 1;
         for (long long i = tid; i < 4LL * Nmax; i += WP_THREADS)
-            XR[RIDX(i)] = (C.nsamples > 0) ? load_sample(C.raw, C.fmt, i < last ? i : last) : make_float2(0.f, 0.f);
+            if (C.nsamples > 0) ring_put_raw(RIDX(i), load_raw(C.raw, C.fmt, i < last ? i : last), C.fmt);
+            else ring_put_f(RIDX(i), make_float2(0.f, 0.f));
     }
     long long filled = 4LL * Nmax;                    // ring holds absolute samples [off - nstash, filled)
     lds_barrier();
@@ -124,7 +141,7 @@ __global__ __launch_bounds__(WP_THREADS) void wenet_demod_pipe_kernel(WrDemodCfg
                 float2 v = make_float2(0.f, 0.f);
                 if (idx < fft_samps) {
                     const float h = hann_t[idx];
-                    const float2 x = XR[RIDX(off_j + idx + Ndft * jl)];
+                    const float2 x = ring_get(RIDX(off_j + idx + Ndft * jl));
                     v = make_float2(h * x.x, h * x.y);
                 }
                 FB[n] = v;
@@ -282,7 +299,7 @@ __global__ __launch_bounds__(WP_THREADS) void wenet_demod_pipe_kernel(WrDemodCfg
                 float2 *row = PH + m * Lpad + s0;
                 float2 x[WP_CK];
 #pragma unroll
-                for (int u = 0; u < WP_CK; u++) x[u] = XR[RIDX(src0 + s0 + (u < cnt ? u : 0))];
+                for (int u = 0; u < WP_CK; u++) x[u] = ring_get(RIDX(src0 + s0 + (u < cnt ? u : 0)));
 #pragma unroll
                 for (int u = 0; u < WP_CK; u++) {
                     if (u < cnt) {
@@ -293,6 +310,47 @@ __global__ __launch_bounds__(WP_THREADS) void wenet_demod_pipe_kernel(WrDemodCfg
             }
         }
         dsp_barrier(&CT[CT_CNT], WP_DSP_WAVES * (++dsp_phase), lane);
+        if (q == 1 && (Ts == 10 || Ts == 8) && NI % Ts == 0) {
+            // Fast path (one sample per integrator step).  The Ts circular-buffer slots are summed in SLOT order
+            // (fsk.c:829-840), i.e. the window row[i .. i+Ts) rotated by o = (-i) mod Ts.  Each D wave takes whole
+            // residue classes i mod Ts, so o is wave-uniform and the rotation is resolved at compile time (no index
+            // arithmetic per element); one lane does both tones of its output and the timing product right away,
+            // which also saves the barrier between the two steps.
+            auto residue = [&](int r, auto TSC, auto OC) {
+                constexpr int TS = decltype(TSC)::value, O = decltype(OC)::value;
+                for (int j = lane; j < NI / TS; j += 64) {
+                    const int i = j * TS + r;
+                    float ft1 = 0.f;
+#pragma unroll
+                    for (int m = 0; m < M; m++) {
+                        const v2f *row = (const v2f *)PH + m * Lpad + i;
+                        v2f v[TS];
+#pragma unroll
+                        for (int u = 0; u < TS; u++) v[u] = row[u];
+                        v2f acc = {0.f, 0.f};
+#pragma unroll
+                        for (int u = 0; u < TS; u++) acc = acc + v[(O + u) % TS];
+                        FI[m * NI + i] = make_float2(acc.x, acc.y);
+                        ft1 += (acc.x * acc.x) + (acc.y * acc.y);           // fsk.c:862-868
+                    }
+                    const float2 pf = RAW ? cfg.phi_ft[i] : pft_t[i];
+                    TP[i] = make_float2(ft1 * pf.x, ft1 * pf.y);
+                }
+            };
+            auto classes = [&](auto TSC) {
+                constexpr int TS = decltype(TSC)::value;
+                for (int r = wave - 3; r < TS; r += WP_DSP_WAVES) {
+                    switch ((r == 0) ? 0 : TS - r) {
+#define WP_ROT(K) case K: residue(r, TSC, std::integral_constant<int, (K) % TS>()); break;
+                        WP_ROT(0) WP_ROT(1) WP_ROT(2) WP_ROT(3) WP_ROT(4) WP_ROT(5) WP_ROT(6) WP_ROT(7) WP_ROT(8) WP_ROT(9)
+#undef WP_ROT
+                    }
+                }
+            };
+            if (Ts == 10) classes(std::integral_constant<int, 10>()); else classes(std::integral_constant<int, 8>());
+            wave_sync();
+            return;
+        }
         {
             // one row per (tone, output): sum the Ts circular-buffer slots in slot order (fsk.c:829-840), loads first
             auto integrate_row = [&](int m, int i, auto TSC) {
@@ -335,7 +393,7 @@ __global__ __launch_bounds__(WP_THREADS) void wenet_demod_pipe_kernel(WrDemodCfg
                 const float2 v = FI[m * NI + i];
                 ft1 += (v.x * v.x) + (v.y * v.y);
             }
-            const float2 pf = pft_t[i];
+            const float2 pf = RAW ? cfg.phi_ft[i] : pft_t[i];
             TP[i] = make_float2(ft1 * pf.x, ft1 * pf.y);
         }
         wave_sync();
@@ -352,21 +410,33 @@ __global__ __launch_bounds__(WP_THREADS) void wenet_demod_pipe_kernel(WrDemodCfg
             typedef float v4f __attribute__((ext_vector_type(4)));
             const v4f *TP4 = (const v4f *)TP;
             v2f acc = {0.f, 0.f};
-            v4f cur[4], nxt[4];
+            v4f bufA[4], bufB[4];                                        // ping-pong: loads of one batch fly while the other is summed
             int i = 0;
             if (NI >= 8) {
 #pragma unroll
-                for (int u = 0; u < 4; u++) cur[u] = TP4[u];
-                for (i = 8; i + 8 <= NI; i += 8) {
+                for (int u = 0; u < 4; u++) bufA[u] = TP4[u];
+                for (i = 8; i + 16 <= NI; i += 16) {
 #pragma unroll
-                    for (int u = 0; u < 4; u++) nxt[u] = TP4[(i >> 1) + u];
+                    for (int u = 0; u < 4; u++) bufB[u] = TP4[(i >> 1) + u];
 #pragma unroll
-                    for (int u = 0; u < 4; u++) { acc = acc + cur[u].xy; acc = acc + cur[u].zw; }
+                    for (int u = 0; u < 4; u++) { acc = acc + bufA[u].xy; acc = acc + bufA[u].zw; }
 #pragma unroll
-                    for (int u = 0; u < 4; u++) cur[u] = nxt[u];
+                    for (int u = 0; u < 4; u++) bufA[u] = TP4[(i >> 1) + 4 + u];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { acc = acc + bufB[u].xy; acc = acc + bufB[u].zw; }
                 }
+                if (i + 8 <= NI) {
 #pragma unroll
-                for (int u = 0; u < 4; u++) { acc = acc + cur[u].xy; acc = acc + cur[u].zw; }
+                    for (int u = 0; u < 4; u++) bufB[u] = TP4[(i >> 1) + u];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { acc = acc + bufA[u].xy; acc = acc + bufA[u].zw; }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { acc = acc + bufB[u].xy; acc = acc + bufB[u].zw; }
+                    i += 8;
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { acc = acc + bufA[u].xy; acc = acc + bufA[u].zw; }
+                }
             }
             for (; i < NI; i++) { const float2 v = TP[i]; acc = acc + (v2f){v.x, v.y}; }
             tcr = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(acc.x)));
@@ -530,7 +600,7 @@ __global__ __launch_bounds__(WP_THREADS) void wenet_demod_pipe_kernel(WrDemodCfg
         } else {
             // stage the next nin samples into the ring, issue the following prefetch
 #pragma unroll
-            for (int k = 0; k < WP_KP; k++) { const int i = t + WP_DSP_THREADS * k; if (i < nin) XR[RIDX(filled + i)] = convert_raw(pre[k], C.fmt); }
+            for (int k = 0; k < WP_KP; k++) { const int i = t + WP_DSP_THREADS * k; if (i < nin) ring_put_raw(RIDX(filled + i), pre[k], C.fmt); }
             {
                 const long long nf = filled + nin, last = C.nsamples - 1;
 #pragma unroll
@@ -577,7 +647,7 @@ __global__ __launch_bounds__(WP_THREADS) void wenet_demod_pipe_kernel(WrDemodCfg
         const int jl = kf - 1;                                           // last committed frame
         const float *FEk = FEr + (jl & 3) * NH;
         for (int i = tid; i < NH; i += WP_THREADS) st_fft[i] = FEk[i];
-        for (int i = tid; i < nstash; i += WP_THREADS) st_old[i] = XR[RIDX(off - nstash + i)];
+        for (int i = tid; i < nstash; i += WP_THREADS) st_old[i] = ring_get(RIDX(off - nstash + i));
         for (int i = tid; i < Nbits; i += WP_THREADS) st_sd[i] = SDL[i];
         if (tid < M) { hdr->phi_c[tid] = PHE[(jl % 3) * 4 + tid]; hdr->f_bin[tid] = CT[CT_FBIN + (jl & 3) * 4 + tid]; }
     }
@@ -595,14 +665,21 @@ __global__ __launch_bounds__(WP_THREADS) void wenet_demod_pipe_kernel(WrDemodCfg
 extern "C" hipError_t wr_launch_demod_pipe(const WrDemodCfg *cfg, const WrChan *d_chans, int nchan, hipStream_t stream, int prof) {
     if (nchan <= 0) return hipSuccess;
     dim3 grid(nchan), block(WP_THREADS);
-#define WP_LAUNCH(MM, PP)                                                                                                    \
-    do {                                                                                                                     \
-        (void)hipFuncSetAttribute((const void *)wenet_demod_pipe_kernel<MM, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                  cfg->p_lds_bytes);                                                                          \
-        hipLaunchKernelGGL((wenet_demod_pipe_kernel<MM, PP>), grid, block, cfg->p_lds_bytes, stream, *cfg, d_chans, nchan);   \
+#define WP_LAUNCH(MM, PP, RR)                                                                                                    \
+    do {                                                                                                                         \
+        (void)hipFuncSetAttribute((const void *)wenet_demod_pipe_kernel<MM, PP, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  cfg->p_lds_bytes);                                                                              \
+        hipLaunchKernelGGL((wenet_demod_pipe_kernel<MM, PP, RR>), grid, block, cfg->p_lds_bytes, stream, *cfg, d_chans, nchan);   \
     } while (0)
-    if (cfg->M == 2) { if (prof) WP_LAUNCH(2, true); else WP_LAUNCH(2, false); }
-    else             { if (prof) WP_LAUNCH(4, true); else WP_LAUNCH(4, false); }
+    // cfg->p_raw: the caller guarantees every capture is cu8 (and carried samples came from cu8) and has put the
+    // raw-ring LDS layout into cfg->p_off_*
+    if (cfg->p_raw) {
+        if (cfg->M == 2) { if (prof) WP_LAUNCH(2, true, true); else WP_LAUNCH(2, false, true); }
+        else             { if (prof) WP_LAUNCH(4, true, true); else WP_LAUNCH(4, false, true); }
+    } else {
+        if (cfg->M == 2) { if (prof) WP_LAUNCH(2, true, false); else WP_LAUNCH(2, false, false); }
+        else             { if (prof) WP_LAUNCH(4, true, false); else WP_LAUNCH(4, false, false); }
+    }
 #undef WP_LAUNCH
     return hipGetLastError();
 }

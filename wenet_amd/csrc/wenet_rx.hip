@@ -97,6 +97,47 @@ struct DemodTables {
         cfg.f_zero = (int)(((long long)est_space * cfg.Ndft) / cfg.Fs);
     }
 
+    // pipelined kernel: sample ring (>= 4 frames + tail), checkpoint/integrator/product double buffers, state rings,
+    // tables.  Two layouts: float2 ring (any input format, 2 captures per CU) and raw cu8 ring with the phi_ft
+    // table left in global memory (cu8 only, fits three times into a CU's 160 KiB).
+    static bool pipe_layout(WrDemodCfg &c, bool raw) {
+            const int M = c.M, Ndft = c.Ndft, NH = c.Ndft / 2, nsyms = c.Nsym;
+            const int Nmax = c.N + c.Ts / 2;
+            int ring = 1;
+            while (ring < 4 * Nmax + c.nstash) ring <<= 1;
+            int t = 0;
+            c.p_ring = ring;
+            c.p_off_XR = t;   t = align16(t + ring * (raw ? 2 : 8));
+            c.p_off_PH = t;   t = align16(t + M * c.Lpad * 8);
+            c.p_off_CK = t;   t = align16(t + 2 * 2 * M * 80 * 8);      // WP_CKROW = 80
+            c.p_off_CKD = t;  t = align16(t + 2 * 2 * M * 8);
+            c.p_off_FI = t;   t = align16(t + 2 * M * c.NI * 8);
+            c.p_off_TP = t;   t = align16(t + 2 * c.NI * 8);
+            c.p_off_FB = t;   t = align16(t + Ndft * 8);
+            c.p_off_FE = t;   t = align16(t + 4 * NH * 4);
+            c.p_off_FW = t;   t = align16(t + NH * 4);
+            c.p_off_SD = t;   t = align16(t + c.Nbits * 4);
+            c.p_off_SC = t;   t = align16(t + (4 * nsyms + 16) * 4);
+            c.p_off_PHE = t;  t = align16(t + 3 * 4 * 8);
+            c.p_off_CT = t;   t = align16(t + 32 * 4);
+            c.p_off_TW = t;   t = align16(t + Ndft * 8);
+            c.p_off_HANN = t; t = align16(t + Ndft * 4);
+            c.p_off_SRC = t;  t = align16(t + Ndft * 4);
+            c.p_off_PFT = t;  if (!raw) t = align16(t + c.NI * 8);
+            c.p_off_DPHI = t; t = align16(t + NH * 8);
+            c.p_lds_bytes = t;
+            c.p_raw = raw ? 1 : 0;
+            return Nmax <= 2 * 320 && c.L / 8 + 2 <= 80;
+    }
+
+    // configuration copy for the raw-cu8-ring variant of the pipelined kernel, or pipe_ok == 0 in it if it does not apply
+    WrDemodCfg raw_cfg() const {
+        WrDemodCfg c = cfg;
+        const bool fits = pipe_layout(c, true);
+        if (!(cfg.pipe_ok && fits && c.p_lds_bytes <= 53 * 1024 && getenv("WENET_RX_NO_RAW") == nullptr)) { c = cfg; }
+        return c;
+    }
+
     bool build(int Fs, int Rs, int P, int M) {
         memset(&cfg, 0, sizeof(cfg));
         if (Fs <= 0 || Rs <= 0 || P <= 0) return false;                 // fsk.c:137-141
@@ -204,33 +245,10 @@ struct DemodTables {
                 o = t;
             }
         }
-        {   // pipelined kernel: sample ring (>= 4 frames + tail), checkpoint/integrator/product double buffers, state rings, tables
-            const int Nmax = cfg.N + cfg.Ts / 2;
-            int ring = 1;
-            while (ring < 4 * Nmax + cfg.nstash) ring <<= 1;
-            int t = 0;
-            cfg.p_ring = ring;
-            cfg.p_off_XR = t;   t = align16(t + ring * 8);
-            cfg.p_off_PH = t;   t = align16(t + M * cfg.Lpad * 8);
-            cfg.p_off_CK = t;   t = align16(t + 2 * 2 * M * 80 * 8);      // WP_CKROW = 80
-            cfg.p_off_CKD = t;  t = align16(t + 2 * 2 * M * 8);
-            cfg.p_off_FI = t;   t = align16(t + 2 * M * cfg.NI * 8);
-            cfg.p_off_TP = t;   t = align16(t + 2 * cfg.NI * 8);
-            cfg.p_off_FB = t;   t = align16(t + Ndft * 8);
-            cfg.p_off_FE = t;   t = align16(t + 4 * NH * 4);
-            cfg.p_off_FW = t;   t = align16(t + NH * 4);
-            cfg.p_off_SD = t;   t = align16(t + cfg.Nbits * 4);
-            cfg.p_off_SC = t;   t = align16(t + (4 * nsyms + 16) * 4);
-            cfg.p_off_PHE = t;  t = align16(t + 3 * 4 * 8);
-            cfg.p_off_CT = t;   t = align16(t + 32 * 4);
-            cfg.p_off_TW = t;   t = align16(t + Ndft * 8);
-            cfg.p_off_HANN = t; t = align16(t + Ndft * 4);
-            cfg.p_off_SRC = t;  t = align16(t + Ndft * 4);
-            cfg.p_off_PFT = t;  t = align16(t + cfg.NI * 8);
-            cfg.p_off_DPHI = t; t = align16(t + NH * 8);
-            cfg.p_lds_bytes = t;
+        {
+            const bool fits = pipe_layout(cfg, false);
             cfg.chain_prio = getenv("WENET_RX_CHAIN_PRIO") ? atoi(getenv("WENET_RX_CHAIN_PRIO")) : 0;   // s_setprio for the chain wave: helps one stream (~3 %), costs ~5 % at 2 captures per CU
-            cfg.pipe_ok = (Nmax <= 2 * 320 && cfg.L / 8 + 2 <= 80 && t <= 80 * 1024 && getenv("WENET_RX_NO_PIPE") == nullptr) ? 1 : 0;
+            cfg.pipe_ok = (fits && cfg.p_lds_bytes <= 80 * 1024 && getenv("WENET_RX_NO_PIPE") == nullptr) ? 1 : 0;
         }
         cfg.lds_bytes = o;
         if (o > 160 * 1024) { fprintf(stderr, "libwenet_rx: configuration needs %d bytes of LDS (>160 KiB)\n", o); return false; }
@@ -398,6 +416,7 @@ struct wenet_fsk {
     float snr_est = 0.f;           // fsk->stats->snr_est recursion (fsk.c:1021), host side
     float f_est_last[4] = {0, 0, 0, 0};
     std::vector<wenet_modem_stats> stats_out;
+    bool carried_cu8 = true;       // the carried samp_old[] are zeros or came from cu8 input (raw-ring variant allowed)
 };
 
 static bool fsk_reset_state(wenet_fsk *f) {
@@ -486,9 +505,14 @@ extern "C" long wenet_fsk_demod_stream(wenet_fsk *f, int fmt, const void *raw, l
         }
     }
     WR_CHECK(hipMemcpy(f->d_chan.p, &ch, sizeof(ch), hipMemcpyHostToDevice), -3);
-    WR_CHECK(wr_launch_demod(&f->tab.cfg, f->d_chan.as<WrChan>(), 1, 0), -4);
+    {
+        const bool raw = (fmt == WENET_FMT_CU8) && f->carried_cu8;
+        const WrDemodCfg launch_cfg = raw ? f->tab.raw_cfg() : f->tab.cfg;
+        WR_CHECK(wr_launch_demod(&launch_cfg, f->d_chan.as<WrChan>(), 1, 0), -4);
+    }
     WR_CHECK(hipMemcpy(&f->hdr, f->d_state.p, sizeof(WrChanHdr), hipMemcpyDeviceToHost), -3);
     const long frames = (long)f->hdr.frames_call;
+    if (frames > 0) f->carried_cu8 = (fmt == WENET_FMT_CU8);           // samp_old[] was rewritten from this input
     if (consumed) *consumed = (long)f->hdr.consumed_call;
     if (frames > 0 && out) WR_CHECK(hipMemcpy(out, f->d_out.p, (size_t)frames * c.Nbits * out_elt, hipMemcpyDeviceToHost), -3);
     std::vector<float> tr;
@@ -823,7 +847,9 @@ extern "C" int wenet_rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw,
     a.llr_out = rx->want_llr ? rx->d_llr.as<float>() : nullptr;
     fill_decode_tables(a, t);
     WR_CHECK(hipEventRecord(rx->ev[0], stream), -4);
-    WR_CHECK(wr_launch_demod_ex(&rx->tab.cfg, rx->d_chans.as<WrChan>(), nchan, stream, rx->profile ? (getenv("WENET_RX_PROFILE")[0] == '2' ? 2 : 1) : 0), -4);
+    // every capture starts from reset state; with cu8 input the three-per-CU raw-ring variant applies
+    const WrDemodCfg launch_cfg = (fmt == WENET_FMT_CU8) ? rx->tab.raw_cfg() : rx->tab.cfg;
+    WR_CHECK(wr_launch_demod_ex(&launch_cfg, rx->d_chans.as<WrChan>(), nchan, stream, rx->profile ? (getenv("WENET_RX_PROFILE")[0] == '2' ? 2 : 1) : 0), -4);
     WR_CHECK(hipEventRecord(rx->ev[1], stream), -4);
     WR_CHECK(wr_launch_deframe(rx->d_dchans.as<WrDeframeChan>(), nchan, rx->mode, stream), -4);
     WR_CHECK(hipEventRecord(rx->ev[2], stream), -4);
