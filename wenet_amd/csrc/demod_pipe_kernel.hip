@@ -558,7 +558,9 @@ __global__ __launch_bounds__(WP_THREADS, RAW ? 6 : 5) void wenet_demod_pipe_kern
     };
 
     // the chain wave is the critical path of every frame: let it win VALU arbitration on its SIMD
-    if (wave == 0 && cfg.chain_prio) __builtin_amdgcn_s_setprio(3);
+    if (wave == 0 && (cfg.chain_prio & 1)) __builtin_amdgcn_s_setprio(3);
+    if (wave == 2 && (cfg.chain_prio & 2)) __builtin_amdgcn_s_setprio(2);
+    if (wave == 1 && (cfg.chain_prio & 4)) __builtin_amdgcn_s_setprio(1);
 
     // ================================ pipeline prologue ========================================
     //   E(0) | C(0),E(1) | D(0),C(1),E(2)         (frame 0 with the true nin, later frames speculative)

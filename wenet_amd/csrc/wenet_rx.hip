@@ -247,7 +247,7 @@ struct DemodTables {
         }
         {
             const bool fits = pipe_layout(cfg, false);
-            cfg.chain_prio = getenv("WENET_RX_CHAIN_PRIO") ? atoi(getenv("WENET_RX_CHAIN_PRIO")) : 0;   // s_setprio for the chain wave: helps one stream (~3 %), costs ~5 % at 2 captures per CU
+            cfg.chain_prio = getenv("WENET_RX_CHAIN_PRIO") ? atoi(getenv("WENET_RX_CHAIN_PRIO")) : 7;   // s_setprio: bit0 chain wave (3), bit1 T wave (2), bit2 estimator (1): the serial waves win VALU arbitration against the parallel D waves sharing their SIMDs (-10 % at 512 captures)
             cfg.pipe_ok = (fits && cfg.p_lds_bytes <= 80 * 1024 && getenv("WENET_RX_NO_PIPE") == nullptr) ? 1 : 0;
         }
         cfg.lds_bytes = o;
