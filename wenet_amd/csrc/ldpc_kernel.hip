@@ -102,21 +102,16 @@ __global__ __launch_bounds__(64) void wenet_deframe_kernel(const WrDeframeChan *
 // =============================================================================================
 namespace {
 
-// phi0 (phi0.c:13-218) through a 90-entry LDS table: entry = {u_lo | u_hi<<16, v0, v1, v2},
-// value = x >= u_hi ? v2 : x >= u_lo ? v1 : v0   (built and exhaustively checked in wenet_rx.hip).
+// phi0 (phi0.c:13-218) through an LDS table keyed by the float bits of y = x*65536 (wenet_internal.h): the
+// reference truncates y to an integer and walks thresholds; "trunc(y) >= T" equals "y >= T" for integer T, and
+// within one table cell phi0 steps at most once, so one ordered compare of the raw bits finishes the job.  The
+// clamped key also covers y < 1, negatives and NaN/Inf/overflow (x86 cvttss2si -> INT_MIN -> 10.0).  No branches.
 __device__ __forceinline__ float phi0_dev(float xf, const uint4 *lut) {
-    const float y = xf * 65536.0f;
-    // x86 cvttss2si semantics of (int32_t)(float): NaN / out of range -> INT32_MIN
-    const int x = (y >= -2147483648.0f && y < 2147483648.0f) ? (int)y : (int)0x80000000;
-    if (x >= 655360) return 0.0f;                  // SI16(10.0f)
-    if (x < 1) return 10.0f;
-    int idx;
-    if (x >= 327680) idx = 80 + (19 - (x >> 15));  // [5,10)
-    else if (x >= 65536) idx = 16 + (79 - (x >> 12));   // [1,5)
-    else idx = 31 - __clz(x);                      // exponent class below 1.0
-    const uint4 e = lut[idx];
-    const int u_lo = (int)(e.x & 0xffffu), u_hi = (int)(e.x >> 16);
-    return (x >= u_hi) ? __uint_as_float(e.w) : ((x >= u_lo) ? __uint_as_float(e.z) : __uint_as_float(e.y));
+    const int b = __float_as_int(xf * 65536.0f);
+    int key = (b >> 18) - WR_PHI0_KEY_BIAS;
+    key = min(max(key, 0), WR_PHI0_LUT_ENTRIES - 1);
+    const uint4 e = lut[key];
+    return __uint_as_float((b >= (int)e.x) ? e.z : e.y);
 }
 
 __device__ __forceinline__ float with_sign(float mag, int neg) {
@@ -229,11 +224,10 @@ __global__ __launch_bounds__(WR_DEC_THREADS) void wenet_decode_kernel(WrDecodeAr
     const int n = (A.input_kind == WR_DEC_IN_SD64) ? A.n_sd : WR_NCODE;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // float msg[14*516] | uint16 vedge[2064*3] | uint4 lut[90] | bit/byte staging
+    // float msg[14*516] | uint4 lut[642] | bit/byte staging
     float    *msg  = (float *)smem;
-    uint16_t *vedge = (uint16_t *)(smem + 14 * WR_NPAR * 4);                       // 28896
-    uint4    *lut  = (uint4 *)(smem + 14 * WR_NPAR * 4 + WR_NDATA * 3 * 2 + 0);    // 28896+12384 = 41280 (16B aligned)
-    uint8_t  *bitbuf = (uint8_t *)(smem + 41280 + WR_PHI0_LUT_ENTRIES * 16);       // [2580] decoded bits, then [258] bytes
+    uint4    *lut  = (uint4 *)(smem + WR_DEC_OFF_LUT);
+    uint8_t  *bitbuf = (uint8_t *)(smem + WR_DEC_OFF_BITS);                        // [2580] decoded bits, then [258] bytes
 
     float llr[WR_VARS_PER_THREAD];
     WrPacketOut *out = A.out ? &A.out[slot] : nullptr;
@@ -256,53 +250,57 @@ __global__ __launch_bounds__(WR_DEC_THREADS) void wenet_decode_kernel(WrDecodeAr
     }
     if (A.stop_after_llr) return;
 
-    // ---- tables into LDS ----------------------------------------------------------------------
-    for (int i = tid; i < WR_NDATA * 3; i += WR_DEC_THREADS) vedge[i] = A.vedge[i];
+    // ---- tables: phi0 LUT into LDS; this thread's edge addresses into registers (the same five variables
+    //      every iteration).  Variables tid + 576 t, t = 0..2, are data bits of degree 3 for every thread;
+    //      t = 3 straddles the data/parity boundary at 2064 and t = 4 is parity (degree 2, the last one 1) or nothing.
     for (int i = tid; i < WR_PHI0_LUT_ENTRIES; i += WR_DEC_THREADS) lut[i] = A.phi0_lut[i];
+    int ea[WR_VARS_PER_THREAD][3], deg[WR_VARS_PER_THREAD];
+#pragma unroll
+    for (int t = 0; t < WR_VARS_PER_THREAD; t++) {
+        const int v = tid + t * WR_DEC_THREADS;
+        deg[t] = (v < WR_NCODE) ? var_degree(v) : 0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) ea[t][k] = (k < deg[t]) ? var_edge(v, k, A.vedge) : 0;
+    }
+    if (tid == 0) msg[13 * WR_NPAR] = 0.f;                      // check 0 has 13 edges: its 14th slot stays a neutral +0
     __syncthreads();
 
     // ---- initial variable->check messages: phi0(|llr|), sign = llr<0 (mpdecode_core.c:353-359)
 #pragma unroll
     for (int t = 0; t < WR_VARS_PER_THREAD; t++) {
-        const int v = tid + t * WR_DEC_THREADS;
-        if (v < WR_NCODE) {
-            const float m0 = with_sign(phi0_dev(fabsf(llr[t]), lut), llr[t] < 0.f);
-            const int d = var_degree(v);
-            for (int k = 0; k < d; k++) msg[var_edge(v, k, vedge)] = m0;
-        }
+        const float m0 = with_sign(phi0_dev(fabsf(llr[t]), lut), llr[t] < 0.f);
+#pragma unroll
+        for (int k = 0; k < 3; k++) if (t < 3 || k < deg[t]) msg[ea[t][k]] = m0;
     }
     __syncthreads();
 
     int result = A.max_iter, pcc = 0, pcc_written = 0;
     unsigned bits = 0;                                          // bit t = hard decision of variable tid+t*576
     for (int iter = 0; iter < A.max_iter; iter++) {
-        // ---- update r: thread = check (mpdecode_core.c:414-436) ------------------------------
+        // ---- update r: thread = check (mpdecode_core.c:414-436).  All 14 slots are processed for every check:
+        //      the phantom 14th edge of check 0 adds +0.0 LAST to phi_sum (no change) and contributes no sign.
         int ok = 0;
         if (tid < WR_NPAR) {
-            const int deg = (tid == 0) ? 13 : 14;
             float mv[14];
             unsigned sgn = 0, sbits = 0;
-            float phi_sum = 0.f;
 #pragma unroll
             for (int k = 0; k < 14; k++) {
-                if (k < deg) {
-                    const float m = msg[k * WR_NPAR + tid];
-                    const unsigned sb = __float_as_uint(m) >> 31;
-                    sbits |= sb << k;
-                    sgn ^= sb;
-                    mv[k] = fabsf(m);
-                    phi_sum = (k == 0) ? mv[0] : (phi_sum + mv[k]);
-                } else mv[k] = 0.f;
+                const unsigned m = __float_as_uint(msg[k * WR_NPAR + tid]);
+                sbits |= (m >> 31) << k;
+                mv[k] = __uint_as_float(m & 0x7fffffffu);
             }
+            sgn = __popc(sbits) & 1u;
+            float phi_sum = mv[0];
+#pragma unroll
+            for (int k = 1; k < 14; k++) phi_sum = phi_sum + mv[k];
             ok = (sgn == 0);
+            const unsigned flip = sgn ? ~sbits : sbits;         // sign of edge k = check parity XOR its own sign
 #pragma unroll
             for (int k = 0; k < 14; k++) {
-                if (k < deg) {
-                    const float r = phi0_dev(phi_sum - mv[k], lut);
-                    const unsigned neg = sgn ^ ((sbits >> k) & 1u);
-                    msg[k * WR_NPAR + tid] = neg ? -r : r;
-                }
+                const float r = phi0_dev(phi_sum - mv[k], lut);
+                msg[k * WR_NPAR + tid] = __uint_as_float(__float_as_uint(r) | (((flip >> k) & 1u) << 31));
             }
+            if (tid == 0) msg[13 * WR_NPAR] = 0.f;
         }
         const int ssum = __syncthreads_count(ok);
         // ---- update q: thread = variable (mpdecode_core.c:439-464) ---------------------------
@@ -310,29 +308,25 @@ __global__ __launch_bounds__(WR_DEC_THREADS) void wenet_decode_kernel(WrDecodeAr
         bits = 0;
 #pragma unroll
         for (int t = 0; t < WR_VARS_PER_THREAD; t++) {
-            const int v = tid + t * WR_DEC_THREADS;
-            if (v < WR_NCODE) {
-                const int d = var_degree(v);
-                int ea[3];
+            if (t < 3 || deg[t] > 0) {
                 float cm[3];
                 float Qi = llr[t];
 #pragma unroll
                 for (int k = 0; k < 3; k++) {
-                    if (k < d) {
-                        ea[k] = var_edge(v, k, vedge);
-                        cm[k] = msg[ea[k]];
+                    if (t < 3 || k < deg[t]) {
+                        cm[k] = msg[ea[t][k]];
                         Qi += cm[k];
                     }
                 }
                 const int b = Qi < 0.f;
                 bits |= (unsigned)b << t;
-                if (b && v < WR_NDATA) any_data = 1;
+                if (b && (t < 3 || tid + t * WR_DEC_THREADS < WR_NDATA)) any_data = 1;
 #pragma unroll
                 for (int k = 0; k < 3; k++) {
-                    if (k < d) {
+                    if (t < 3 || k < deg[t]) {
                         const float temp_sum = Qi - cm[k];
                         const float mag = phi0_dev(fabsf(temp_sum), lut);
-                        msg[ea[k]] = with_sign(mag, !(temp_sum > 0.f));
+                        msg[ea[t][k]] = with_sign(mag, !(temp_sum > 0.f));
                     }
                 }
             }
@@ -370,7 +364,7 @@ __global__ __launch_bounds__(WR_DEC_THREADS) void wenet_decode_kernel(WrDecodeAr
     }
 }
 
-#define WR_DEC_LDS_BYTES (41280 + WR_PHI0_LUT_ENTRIES * 16 + 2592 + 272)
+
 
 extern "C" hipError_t wr_launch_deframe(const WrDeframeChan *d_chans, int nchan, int mode, hipStream_t stream) {
     if (nchan <= 0) return hipSuccess;

@@ -174,4 +174,14 @@ static const float WR_PHI0_LT1_V[27] = {  // value when x > T[k] (and x <= T[k-1
     3.292243417f, 3.638586634f, 3.985045009f, 4.331560985f, 4.678105767f, 5.024664952f, 5.371231340f,
     5.717801329f, 6.064373119f, 6.410945809f, 6.757518949f, 7.104092314f, 7.450665792f, 7.797239326f,
     8.143812888f, 8.490386464f, 8.836960047f, 9.183533634f, 9.530107222f, 9.876680812f};
-#define WR_PHI0_LUT_ENTRIES 90   // 16 exponent classes below 1.0 + 64 + 10
+// phi0 as a table keyed by the float bits of y = x*65536: 20 binades [1, 2^20) x 32 mantissa cells, plus entry 0
+// (y < 1, negatives, -NaN -> 10.0) and entry 641 (y >= 2^20: 0.0, or 10.0 from 2^31 up incl. +Inf/+NaN = x86 INT_MIN).
+// entry = {threshold float bits, value below, value at/above, 0}; at most one step of phi0 falls into a cell (checked).
+#define WR_PHI0_CELLS 32
+#define WR_PHI0_BINADES 20
+#define WR_PHI0_LUT_ENTRIES (WR_PHI0_BINADES * WR_PHI0_CELLS + 2)
+#define WR_PHI0_KEY_BIAS ((0x3f800000 >> 18) - 1)   // key = (bits >> 18) - bias: y = 1.0 -> 1
+// LDS carve-up of wenet_decode_kernel: float msg[14][516] | uint4 lut[] | bits[2592] + bytes[272]
+#define WR_DEC_OFF_LUT  (14 * WR_NPAR * 4)
+#define WR_DEC_OFF_BITS (WR_DEC_OFF_LUT + WR_PHI0_LUT_ENTRIES * 16)
+#define WR_DEC_LDS_BYTES (WR_DEC_OFF_BITS + 2592 + 272)

@@ -314,17 +314,18 @@ float phi0_linear_int(int x) {                                          // phi0.
     return 10.0f;
 }
 inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
-float phi0_lut_eval(const uint32_t *lut, int x) {                       // host twin of phi0_dev
-    if (x >= 655360) return 0.0f;
-    if (x < 1) return 10.0f;
-    int idx;
-    if (x >= 327680) idx = 80 + (19 - (x >> 15));
-    else if (x >= 65536) idx = 16 + (79 - (x >> 12));
-    else idx = 31 - __builtin_clz((unsigned)x);
-    const uint32_t *e = lut + idx * 4;
-    const int u_lo = (int)(e[0] & 0xffffu), u_hi = (int)(e[0] >> 16);
-    uint32_t u = (x >= u_hi) ? e[3] : ((x >= u_lo) ? e[2] : e[1]);
+float phi0_lut_eval(const uint32_t *lut, float y) {                     // host twin of phi0_dev: y = xf * 65536
+    int32_t b; memcpy(&b, &y, 4);
+    int key = (b >> 18) - WR_PHI0_KEY_BIAS;
+    key = key < 0 ? 0 : (key > WR_PHI0_LUT_ENTRIES - 1 ? WR_PHI0_LUT_ENTRIES - 1 : key);
+    const uint32_t *e = lut + key * 4;
+    const uint32_t u = (b >= (int32_t)e[0]) ? e[2] : e[1];
     float f; memcpy(&f, &u, 4); return f;
+}
+float phi0_x86(float xf) {                                              // phi0.c:13-15 with cvttss2si semantics of the cast
+    const float y = xf * 65536.0f;
+    const int x = (y >= -2147483648.0f && y < 2147483648.0f) ? (int)y : INT32_MIN;
+    return phi0_linear_int(x);
 }
 
 struct LdpcTables {
@@ -346,29 +347,37 @@ struct LdpcTables {
                 vedge[v * 3 + deg[v]++] = (uint16_t)(j * WR_NPAR + c);   // slot-major edge address
             }
         for (int v = 0; v < WR_NDATA; v++) if (deg[v] != 3) { fprintf(stderr, "libwenet_rx: code table: column weight != 3\n"); return false; }
-        // phi0 LUT
+        // phi0 LUT keyed by the float bits of y (see wenet_internal.h)
         std::vector<uint32_t> lut(WR_PHI0_LUT_ENTRIES * 4, 0);
-        int thr[27];
-        for (int k = 0; k < 27; k++) thr[k] = si16(WR_PHI0_LT1_T[k]);
-        // below 1.0: "x > T" == "x >= T+1"; per exponent class of x at most two such bounds U fall
-        // inside the class (checked).  entry = {u_lo | u_hi<<16, v0, v1, v2}, value = x>=u_hi ? v2 : x>=u_lo ? v1 : v0
-        for (int e = 0; e < 16; e++) {
-            const int lo = 1 << e, hi = (1 << (e + 1)) - 1;
-            int u[3], nu = 0;
-            for (int k = 26; k >= 0; k--) { const int U = thr[k] + 1; if (U > lo && U <= hi) { if (nu < 3) u[nu] = U; nu++; } }
-            if (nu > 2) { fprintf(stderr, "libwenet_rx: phi0 table: >2 thresholds in one exponent class\n"); return false; }
-            const int u_lo = nu >= 1 ? u[0] : 0xffff, u_hi = nu >= 2 ? u[1] : 0xffff;
-            uint32_t *en = &lut[e * 4];
-            en[0] = (uint32_t)u_lo | ((uint32_t)u_hi << 16);
-            en[1] = f2u(phi0_linear_int(lo));
-            en[2] = nu >= 1 ? f2u(phi0_linear_int(u_lo)) : en[1];      // unused slots repeat their neighbour,
-            en[3] = nu >= 2 ? f2u(phi0_linear_int(u_hi)) : en[2];      // so the 0xffff sentinel is harmless at x=65535
+        {
+            uint32_t *e0 = &lut[0];
+            e0[0] = 0x7fffffffu; e0[1] = e0[2] = f2u(10.0f);
+            uint32_t *eN = &lut[(WR_PHI0_LUT_ENTRIES - 1) * 4];
+            eN[0] = 0x4f000000u; eN[1] = f2u(0.0f); eN[2] = f2u(10.0f);                 // 2^31
+            for (int k = 1; k <= WR_PHI0_BINADES * WR_PHI0_CELLS; k++) {
+                const int e = (k - 1) / WR_PHI0_CELLS, c = (k - 1) % WR_PHI0_CELLS;
+                const double lo = ldexp(1.0 + (double)c / WR_PHI0_CELLS, e), hi = ldexp(1.0 + (double)(c + 1) / WR_PHI0_CELLS, e);
+                const int x0 = (int)floor(lo), x1 = (int)ceil(hi) - 1;                  // integer parts met inside the cell
+                uint32_t *en = &lut[k * 4];
+                en[0] = 0x7fffffffu; en[1] = en[2] = f2u(phi0_linear_int(x0));
+                int steps = 0;
+                for (int x = x0 + 1; x <= x1; x++)
+                    if (f2u(phi0_linear_int(x)) != f2u(phi0_linear_int(x - 1))) { steps++; en[0] = f2u((float)x); en[2] = f2u(phi0_linear_int(x)); }
+                if (steps > 1) { fprintf(stderr, "libwenet_rx: phi0 table: %d steps in cell %d\n", steps, k); return false; }
+            }
         }
-        for (int i = 0; i < 64; i++) { uint32_t *en = &lut[(16 + i) * 4]; en[0] = 0; en[1] = en[2] = en[3] = f2u(WR_PHI0_1_5[i]); }
-        for (int i = 0; i < 10; i++) { uint32_t *en = &lut[(80 + i) * 4]; en[0] = 0; en[1] = en[2] = en[3] = f2u(WR_PHI0_5_10[i]); }
-        for (int x = -4; x <= 700000; x++)                              // exhaustive self-check of the table form
-            if (f2u(phi0_lut_eval(lut.data(), x)) != f2u(phi0_linear_int(x))) {
-                fprintf(stderr, "libwenet_rx: phi0 table self-check failed at x=%d\n", x);
+        // self-check against the reference form, every integer part and arguments in between, plus the odd cases
+        for (int x = 0; x <= 1100000; x++)
+            for (float fr : {0.0f, 0.5f}) {
+                const float y = (float)x + fr, xf = y / 65536.0f;
+                if (f2u(phi0_lut_eval(lut.data(), xf * 65536.0f)) != f2u(phi0_x86(xf))) {
+                    fprintf(stderr, "libwenet_rx: phi0 table self-check failed at y=%g\n", (double)y);
+                    return false;
+                }
+            }
+        for (float xf : {-0.0f, -1.0f, -1e30f, 1e-30f, 1.5e-5f, 16.0f, 32767.0f, 32767.99f, 32768.0f, 1e9f, 3e38f, INFINITY, -INFINITY, NAN, -NAN})
+            if (f2u(phi0_lut_eval(lut.data(), xf * 65536.0f)) != f2u(phi0_x86(xf))) {
+                fprintf(stderr, "libwenet_rx: phi0 table self-check failed at xf=%g\n", (double)xf);
                 return false;
             }
         size_t a_v = 0, a_l = (WR_NDATA * 3 * 2 + 255) & ~255, a_s = a_l + ((WR_PHI0_LUT_ENTRIES * 16 + 255) & ~255);
