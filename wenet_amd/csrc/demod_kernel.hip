@@ -132,9 +132,10 @@ __global__ __launch_bounds__(NT) void wenet_demod_kernel(WrDemodCfg cfg, const W
             lds_barrier();
             for (int s = cfg.nstages - 1; s >= 0; s--) {               // innermost butterflies first
                 const int m = cfg.mstage[s], p = cfg.radix[s], fs = cfg.fstride[s];
+                const int lgm = 31 - __clz(m);
                 const int nb = Ndft / p;
                 for (int b = tid; b < nb; b += NT) {
-                    const int blk = b / m, k = b - blk * m;
+                    const int blk = b >> lgm, k = b & (m - 1);           // m is a power of two (Ndft is)
                     float2 *F = FB + blk * m * p + k;
                     if (p == 4) {                                      // kf_bfly4 (kiss_fft.c:44-90), forward
                         const float2 s0 = cmul(F[m], tw_t[k * fs]);

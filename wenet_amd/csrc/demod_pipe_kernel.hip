@@ -149,9 +149,10 @@ __global__ __launch_bounds__(WP_THREADS, RAW ? 6 : 5) void wenet_demod_pipe_kern
             wave_sync();
             for (int s = cfg.nstages - 1; s >= 0; s--) {
                 const int m = cfg.mstage[s], p = cfg.radix[s], fs = cfg.fstride[s];
+                const int lgm = 31 - __clz(m);
                 const int nb = Ndft / p;
                 for (int b = lane; b < nb; b += 64) {
-                    const int blk = b / m, k = b - blk * m;
+                    const int blk = b >> lgm, k = b & (m - 1);           // m is a power of two (Ndft is)
                     float2 *F = FB + blk * m * p + k;
                     if (p == 4) {                                       // kf_bfly4 (kiss_fft.c:44-90)
                         const float2 s0 = cmul(F[m], tw_t[k * fs]);
@@ -420,10 +421,12 @@ __global__ __launch_bounds__(WP_THREADS, RAW ? 6 : 5) void wenet_demod_pipe_kern
                     for (int u = 0; u < 4; u++) bufB[u] = TP4[(i >> 1) + u];
 #pragma unroll
                     for (int u = 0; u < 4; u++) { acc = acc + bufA[u].xy; acc = acc + bufA[u].zw; }
-#pragma unroll
+                    asm volatile("" : "+v"(acc) : : "memory");           // keep the reload of A behind its last use (else the
+#pragma unroll                                                           // scheduler hoists it and pays 8 register copies per round)
                     for (int u = 0; u < 4; u++) bufA[u] = TP4[(i >> 1) + 4 + u];
 #pragma unroll
                     for (int u = 0; u < 4; u++) { acc = acc + bufB[u].xy; acc = acc + bufB[u].zw; }
+                    asm volatile("" : "+v"(acc) : : "memory");
                 }
                 if (i + 8 <= NI) {
 #pragma unroll
