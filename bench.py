@@ -76,7 +76,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--captures", type=int, default=int(os.environ.get("WENET_BENCH_CAPTURES", "768")),
+    ap.add_argument("--captures", type=int, default=int(os.environ.get("WENET_BENCH_CAPTURES", "3072")),
                     help="independent captures per GPU")
     ap.add_argument("--seconds", type=float, default=10.0, help="length of each capture")
     ap.add_argument("--ebno", type=float, default=8.0)
