@@ -69,6 +69,34 @@ def test_streaming_chunks_equal_one_shot():
     f.close()
 
 
+def test_streaming_with_changing_input_format():
+    """One stream handle fed the same signal alternately as cu8 and as the exactly equivalent cf32 / cs16-free
+    floats: the cu8 launches use the raw-byte sample ring (three captures per CU), the others the float ring, and
+    the carried samp_old[] crosses from one to the other.  The result must equal the oracle's on the cu8 stream."""
+    cfg = siggen.config_v2()
+    raw, _ = siggen.make_capture(cfg, 4, 9.0, seed=41, ppm=220.0)
+    ref, _ = ol.oracle_demod(raw, "cu8", cfg.Fs, cfg.Rs, cfg.M)
+    as_f32 = ((raw.astype(np.float32) - 127.0) / 128.0)                  # exact (src/fsk_demod.c:283-284)
+    f = Fsk(cfg.Fs, cfg.Rs, cfg.Ts, cfg.M)
+    rng = np.random.default_rng(8)
+    pos, out, k = 0, [], 0
+    nsamp = raw.size // 2
+    while True:
+        n = int(rng.integers(200, 4000))
+        hi = min(pos + n, nsamp)
+        if k % 3 == 1:
+            sd, used, _ = f.demod_stream(np.ascontiguousarray(as_f32[2 * pos:2 * hi]), "cf32")
+        else:
+            sd, used, _ = f.demod_stream(np.ascontiguousarray(raw[2 * pos:2 * hi]), "cu8")
+        out.append(sd)
+        pos += used
+        k += 1
+        if hi == nsamp and used == 0:
+            break
+    assert bits_equal(np.concatenate(out), ref)
+    f.close()
+
+
 def test_edge_cases_demod():
     cfg = siggen.config_v2()
     f = Fsk(cfg.Fs, cfg.Rs, cfg.Ts, cfg.M)

@@ -408,42 +408,82 @@ __global__ __launch_bounds__(WP_THREADS, RAW ? 6 : 5) void wenet_demod_pipe_kern
         const float2 *TP = TPb + (kf & 1) * NI;
         float tcr, tci;
         {
-            typedef float v4f __attribute__((ext_vector_type(4)));
-            const v4f *TP4 = (const v4f *)TP;
-            v2f acc = {0.f, 0.f};
-            v4f bufA[4], bufB[4];                                        // ping-pong: loads of one batch fly while the other is summed
-            int i = 0;
-            if (NI >= 8) {
+            if (cfg.p_tsum_split) {
+                // Real part in even lanes, imaginary part in odd lanes: 490 dependent PLAIN adds per frame instead of packed
+                // ones (a packed-f32 op occupies the SIMD twice as long, and this wave shares its SIMD with other captures).
+                const float *TPf = (const float *)TP + (lane & 1);
+                float acc = 0.f;
+                float bufA[8], bufB[8];                                      // ping-pong: loads of one batch fly while the other is summed
+                int i = 0;
+                if (NI >= 8) {
 #pragma unroll
-                for (int u = 0; u < 4; u++) bufA[u] = TP4[u];
-                for (i = 8; i + 16 <= NI; i += 16) {
+                    for (int u = 0; u < 8; u++) bufA[u] = TPf[2 * u];
+                    for (i = 8; i + 16 <= NI; i += 16) {
 #pragma unroll
-                    for (int u = 0; u < 4; u++) bufB[u] = TP4[(i >> 1) + u];
+                        for (int u = 0; u < 8; u++) bufB[u] = TPf[2 * (i + u)];
 #pragma unroll
-                    for (int u = 0; u < 4; u++) { acc = acc + bufA[u].xy; acc = acc + bufA[u].zw; }
-                    asm volatile("" : "+v"(acc) : : "memory");           // keep the reload of A behind its last use (else the
+                        for (int u = 0; u < 8; u++) acc = acc + bufA[u];
+                        asm volatile("" : "+v"(acc) : : "memory");           // keep the reload of A behind its last use (else the
+#pragma unroll                                                           // scheduler hoists it and pays register copies per round)
+                        for (int u = 0; u < 8; u++) bufA[u] = TPf[2 * (i + 8 + u)];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) acc = acc + bufB[u];
+                        asm volatile("" : "+v"(acc) : : "memory");
+                    }
+                    if (i + 8 <= NI) {
+#pragma unroll
+                        for (int u = 0; u < 8; u++) bufB[u] = TPf[2 * (i + u)];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) acc = acc + bufA[u];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) acc = acc + bufB[u];
+                        i += 8;
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 8; u++) acc = acc + bufA[u];
+                    }
+                }
+                for (; i < NI; i++) acc = acc + TPf[2 * i];
+                tcr = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(acc), 0));
+                tci = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(acc), 1));
+            } else {
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                const v4f *TP4 = (const v4f *)TP;
+                v2f acc = {0.f, 0.f};
+                v4f bufA[4], bufB[4];                                        // ping-pong: loads of one batch fly while the other is summed
+                int i = 0;
+                if (NI >= 8) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) bufA[u] = TP4[u];
+                    for (i = 8; i + 16 <= NI; i += 16) {
+#pragma unroll
+                        for (int u = 0; u < 4; u++) bufB[u] = TP4[(i >> 1) + u];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) { acc = acc + bufA[u].xy; acc = acc + bufA[u].zw; }
+                        asm volatile("" : "+v"(acc) : : "memory");           // keep the reload of A behind its last use (else the
 #pragma unroll                                                           // scheduler hoists it and pays 8 register copies per round)
-                    for (int u = 0; u < 4; u++) bufA[u] = TP4[(i >> 1) + 4 + u];
+                        for (int u = 0; u < 4; u++) bufA[u] = TP4[(i >> 1) + 4 + u];
 #pragma unroll
-                    for (int u = 0; u < 4; u++) { acc = acc + bufB[u].xy; acc = acc + bufB[u].zw; }
-                    asm volatile("" : "+v"(acc) : : "memory");
+                        for (int u = 0; u < 4; u++) { acc = acc + bufB[u].xy; acc = acc + bufB[u].zw; }
+                        asm volatile("" : "+v"(acc) : : "memory");
+                    }
+                    if (i + 8 <= NI) {
+#pragma unroll
+                        for (int u = 0; u < 4; u++) bufB[u] = TP4[(i >> 1) + u];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) { acc = acc + bufA[u].xy; acc = acc + bufA[u].zw; }
+#pragma unroll
+                        for (int u = 0; u < 4; u++) { acc = acc + bufB[u].xy; acc = acc + bufB[u].zw; }
+                        i += 8;
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 4; u++) { acc = acc + bufA[u].xy; acc = acc + bufA[u].zw; }
+                    }
                 }
-                if (i + 8 <= NI) {
-#pragma unroll
-                    for (int u = 0; u < 4; u++) bufB[u] = TP4[(i >> 1) + u];
-#pragma unroll
-                    for (int u = 0; u < 4; u++) { acc = acc + bufA[u].xy; acc = acc + bufA[u].zw; }
-#pragma unroll
-                    for (int u = 0; u < 4; u++) { acc = acc + bufB[u].xy; acc = acc + bufB[u].zw; }
-                    i += 8;
-                } else {
-#pragma unroll
-                    for (int u = 0; u < 4; u++) { acc = acc + bufA[u].xy; acc = acc + bufA[u].zw; }
-                }
+                for (; i < NI; i++) { const float2 v = TP[i]; acc = acc + (v2f){v.x, v.y}; }
+                tcr = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(acc.x)));
+                tci = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(acc.y)));
             }
-            for (; i < NI; i++) { const float2 v = TP[i]; acc = acc + (v2f){v.x, v.y}; }
-            tcr = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(acc.x)));
-            tci = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(acc.y)));
         }
         int nin_next = nin_cur;
         float tr_mean = 0.f, tr_std = 0.f, tr_rxt = 0.f;
