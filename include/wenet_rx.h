@@ -157,6 +157,11 @@ long long wenet_rx_frames(wenet_rx *rx, int ch);            /* modem frames demo
 long long wenet_rx_packets(wenet_rx *rx, int ch);           /* packets completed (valid or not) */
 /* copies up to cap packets of channel ch: 258 bytes each + info; returns count */
 long long wenet_rx_get_packets(wenet_rx *rx, int ch, uint8_t *pkt_bytes, wenet_packet_info *info, long long cap);
+/* CRC-valid packets of channel ch by type byte (payload[0]), counted on the GPU next to the CRC gate -- the
+ * dispatch rx/rx_ssdv.py:195-224 performs per packet with rx/WenetPackets.py:28-35:
+ * counts[0..3] = 0x00 text, 0x01 GPS, 0x02 orientation, 0x03 secondary payload; [4] 0x54 image telemetry;
+ * [5] 0x55 SSDV; [6] 0x56 idle; [7] anything else.  Returns 0, <0 on error. */
+int wenet_rx_packet_census(wenet_rx *rx, int ch, long long counts[8]);
 /* soft-decision stream of channel ch (Nbits per frame); returns floats copied */
 long long wenet_rx_get_soft(wenet_rx *rx, int ch, float *sd, long long cap);
 /* per-frame trace of channel ch (10 floats per frame, see wenet_fsk_demod_stream); enable before process */

@@ -200,3 +200,24 @@ def test_batch_of_captures_with_per_capture_parameters():
         assert bits_equal(rx.soft(c), ref)
     rx.close()
     tx.close()
+
+
+def test_packet_type_census_is_counted_on_the_gpu():
+    """First payload byte = Wenet packet type (rx/WenetPackets.py:28-35); the batch API reports CRC-valid packets per type."""
+    from wenet_amd import packets as P
+    cfg = siggen.config_v2()
+    rng = np.random.default_rng(321)
+    types = [0x00, 0x01, 0x02, 0x03, 0x54, 0x55, 0x55, 0x55, 0x56, 0x56, 0x9A, 0x55, 0x01, 0x55]
+    payloads = rng.integers(0, 256, (len(types), 256), dtype=np.uint8)
+    payloads[:, 0] = types
+    caps = [_generate(cfg, payloads, 12.0, seed=5), _generate(cfg, payloads[::-1].copy(), 4.0, seed=6)]
+    rx = RxBatch(cfg.Fs, cfg.Rs, cfg.M, framing=cfg.mode)
+    rx.process(caps, "cu8")
+    for c in range(2):
+        blob = rx.valid_payloads(c)
+        want = [0] * 8
+        for i in range(len(blob) // 256):
+            want[P.census_class(blob[256 * i:256 * i + 256])] += 1
+        assert rx.census(c) == want
+    assert sum(rx.census(0)) >= len(types) - 2 and rx.census(0)[5] >= 4 and sum(rx.census(1)) == 0      # 4 dB: nothing valid
+    rx.close()

@@ -89,3 +89,19 @@ def test_noise_model_matches_reference_script_golden():
     np.random.seed(int(g["noise_seed"]))
     y = siggen.add_noise(x, cfg, float(g["noise_ebno"]), None, normal=np.random.randn)   # generate_lowsnr.py:70-89
     assert y.dtype == g["noise_out"].dtype and (y == g["noise_out"]).all()
+
+
+def test_packet_vocabulary():
+    """wenet_amd/packets.py (rx/WenetPackets.py:28-47,80-123 restated; reference module not importable here)."""
+    from wenet_amd import packets as P
+    assert [P.census_class(bytes([t]) + b"\0" * 255) for t in (0, 1, 2, 3, 0x54, 0x55, 0x56, 0x10, 0xFF)] == [0, 1, 2, 3, 4, 5, 6, 7, 7]
+    assert P.decode_packet_type(b"\x55abc") == 0x55
+    for cs in ("VK5QI", "N0CALL", "A", "W1AW-9"):
+        assert P.ssdv_decode_callsign(P.ssdv_encode_callsign(cs)) == cs
+    pkt = bytearray(256)
+    pkt[0], pkt[1] = 0x55, 0x66
+    pkt[2:6] = P.ssdv_encode_callsign("VK5QI")
+    pkt[6], pkt[7], pkt[8], pkt[9], pkt[10] = 7, 1, 44, 40, 30
+    info = P.ssdv_packet_info(bytes(pkt))
+    assert info == {"callsign": "VK5QI", "packet_type": "FEC", "image_id": 7, "packet_id": 300, "width": 640, "height": 480, "error": "None"}
+    assert P.ssdv_packet_info(b"\x56" * 256)["error"] != "None" and P.ssdv_packet_info(b"\x55" * 10)["error"] != "None"

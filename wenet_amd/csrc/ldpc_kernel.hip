@@ -262,6 +262,11 @@ __global__ __launch_bounds__(256) void wenet_crc_kernel(WrDecodeArgs A) {
     const unsigned tx = tail & 0xffffu;                 // packet[256] | packet[257] << 8
     out->crc_ok = (uint8_t)(crc == tx);
     out->done = 1;
+    if (A.census && crc == tx) {                        // what rx_ssdv.py:195-224 dispatches on, counted where the packet is
+        const unsigned t = w[0] & 0xffu;
+        const int cls = t <= 3u ? (int)t : (t >= 0x54u && t <= 0x56u ? (int)(t - 0x54u + 4u) : 7);
+        atomicAdd(&A.census[ch * WR_CENSUS_CLASSES + cls], 1u);
+    }
 }
 
 __global__ __launch_bounds__(WR_DEC_THREADS) void wenet_decode_kernel(WrDecodeArgs A) {

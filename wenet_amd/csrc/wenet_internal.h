@@ -127,6 +127,9 @@ struct WrPacketOut {            // one per packet slot
 };
 
 enum { WR_DEC_IN_STREAM = 0, WR_DEC_IN_SD64 = 1, WR_DEC_IN_LLR = 2 };
+// packet type classes (first payload byte, rx/WenetPackets.py:28-35): 0x00 text, 0x01 GPS, 0x02 orientation,
+// 0x03 secondary payload, 0x54 image telemetry, 0x55 SSDV, 0x56 idle, anything else
+#define WR_CENSUS_CLASSES 8
 
 struct WrDecodeArgs {
     int input_kind;             // WR_DEC_IN_*
@@ -146,6 +149,7 @@ struct WrDecodeArgs {
     float       *llr_out;               // optional [nchan*max_pk*n]
     uint8_t     *bits_out;              // optional [nchan*max_pk*2580] all decoded bits (run_ldpc_decoder API)
     double      *esn0;                  // [nchan*max_pk] estEsN0 per packet (wenet_llr_stats_kernel -> decode)
+    unsigned    *census;                // optional [nchan][WR_CENSUS_CLASSES]: CRC-valid packets by type byte (wenet_crc_kernel)
     // tables
     const uint16_t *vedge;              // [2064*3] edge address (slot*516+check) per data bit, socket order
     const uint4    *phi0_lut;           // [90]

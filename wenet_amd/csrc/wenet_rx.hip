@@ -749,7 +749,8 @@ struct wenet_rx {
     bool want_trace = false, want_llr = false;
     int nchan = 0, max_pk = 0;
     std::vector<long long> sd_off, cap_frames;           // per channel: float offset into d_sd, frame capacity
-    DevBuf d_states, d_chans, d_dchans, d_dstates, d_sd, d_starts, d_out, d_trace, d_llr, d_raw, d_prof, d_esn0;
+    DevBuf d_states, d_chans, d_dchans, d_dstates, d_sd, d_starts, d_out, d_trace, d_llr, d_raw, d_prof, d_esn0, d_census;
+    std::vector<unsigned> h_census;
     bool profile = false;
     std::vector<float> h_states;
     std::vector<WrDeframeState> h_dstates;
@@ -783,6 +784,11 @@ extern "C" wenet_rx *wenet_rx_create(int Fs, int Rs, int P, int M, int framing_m
     return rx;
 }
 extern "C" void wenet_rx_destroy(wenet_rx *rx) { delete rx; }
+extern "C" int wenet_rx_packet_census(wenet_rx *rx, int ch, long long counts[8]) {
+    if (!rx || rx->pending || ch < 0 || ch >= rx->nchan || (size_t)(ch + 1) * WR_CENSUS_CLASSES > rx->h_census.size()) return -1;
+    for (int k = 0; k < WR_CENSUS_CLASSES; k++) counts[k] = rx->h_census[(size_t)ch * WR_CENSUS_CLASSES + k];
+    return 0;
+}
 extern "C" void wenet_rx_enable_trace(wenet_rx *rx, int on) { if (rx) { rx->want_trace = on != 0; rx->tab.cfg.stats = on ? 1 : 0; } }
 extern "C" void wenet_rx_enable_llr_dump(wenet_rx *rx, int on) { if (rx) rx->want_llr = on != 0; }
 
@@ -809,7 +815,8 @@ extern "C" int wenet_rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw,
     if (!rx->d_states.reserve(stb * nchan) || !rx->d_chans.reserve(sizeof(WrChan) * nchan) ||
         !rx->d_dchans.reserve(sizeof(WrDeframeChan) * nchan) || !rx->d_dstates.reserve(sizeof(WrDeframeState) * nchan) ||
         !rx->d_sd.reserve((size_t)rx->sd_off[nchan] * 4) || !rx->d_starts.reserve((size_t)nchan * max_pk * 8) ||
-        !rx->d_out.reserve((size_t)nchan * max_pk * sizeof(WrPacketOut)) || !rx->d_esn0.reserve((size_t)nchan * max_pk * 8))
+        !rx->d_out.reserve((size_t)nchan * max_pk * sizeof(WrPacketOut)) || !rx->d_esn0.reserve((size_t)nchan * max_pk * 8) ||
+        !rx->d_census.reserve((size_t)nchan * WR_CENSUS_CLASSES * 4))
         return -2;
     if (rx->want_trace && !rx->d_trace.reserve((size_t)(rx->sd_off[nchan] / c.Nbits) * WR_TRACE_FLOATS * 4)) return -2;
     if (rx->want_llr && !rx->d_llr.reserve((size_t)nchan * max_pk * WR_NCODE * 4)) return -2;
@@ -822,6 +829,7 @@ extern "C" int wenet_rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw,
     for (int i = 0; i < nchan; i++) memcpy(&rx->h_states[(size_t)i * c.st_floats], st0.data(), stb);
     WR_CHECK(hipMemcpyAsync(rx->d_states.p, rx->h_states.data(), stb * nchan, hipMemcpyHostToDevice, stream), -3);
     WR_CHECK(hipMemsetAsync(rx->d_dstates.p, 0, sizeof(WrDeframeState) * nchan, stream), -3);
+    WR_CHECK(hipMemsetAsync(rx->d_census.p, 0, (size_t)nchan * WR_CENSUS_CLASSES * 4, stream), -3);
     std::vector<WrChan> chans(nchan);
     std::vector<WrDeframeChan> dch(nchan);
     for (int i = 0; i < nchan; i++) {
@@ -853,6 +861,7 @@ extern "C" int wenet_rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw,
     a.dchans = rx->d_dchans.as<WrDeframeChan>();
     a.out = rx->d_out.as<WrPacketOut>();
     a.esn0 = rx->d_esn0.as<double>();
+    a.census = rx->d_census.as<unsigned>();
     a.llr_out = rx->want_llr ? rx->d_llr.as<float>() : nullptr;
     fill_decode_tables(a, t);
     WR_CHECK(hipEventRecord(rx->ev[0], stream), -4);
@@ -878,6 +887,8 @@ extern "C" int wenet_rx_collect(wenet_rx *rx) {
     rx->h_dstates.resize(nchan);
     WR_CHECK(hipMemcpy(rx->h_states.data(), rx->d_states.p, (size_t)c.st_floats * 4 * nchan, hipMemcpyDeviceToHost), -3);
     WR_CHECK(hipMemcpy(rx->h_dstates.data(), rx->d_dstates.p, sizeof(WrDeframeState) * nchan, hipMemcpyDeviceToHost), -3);
+    rx->h_census.resize((size_t)nchan * WR_CENSUS_CLASSES);
+    WR_CHECK(hipMemcpy(rx->h_census.data(), rx->d_census.p, rx->h_census.size() * 4, hipMemcpyDeviceToHost), -3);
     // packet slots + start offsets: one contiguous device->pinned-host copy each (per-capture copies of only the
     // filled slots cost ~1000 small transfers for 512 captures)
     const size_t n_slots = (size_t)nchan * rx->max_pk;

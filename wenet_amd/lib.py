@@ -24,7 +24,7 @@ EXPORTS = [
     "wenet_run_ldpc_decoder", "wenet_sd_to_llr", "wenet_ldpc_decode_batch",
     "wenet_deframer_create", "wenet_deframer_destroy", "wenet_deframer_push",
     "wenet_rx_create", "wenet_rx_destroy", "wenet_rx_process", "wenet_rx_enqueue", "wenet_rx_collect",
-    "wenet_rx_frames", "wenet_rx_packets", "wenet_rx_get_packets", "wenet_rx_get_soft",
+    "wenet_rx_frames", "wenet_rx_packets", "wenet_rx_get_packets", "wenet_rx_packet_census", "wenet_rx_get_soft",
     "wenet_rx_enable_trace", "wenet_rx_get_trace", "wenet_rx_enable_llr_dump", "wenet_rx_get_llrs",
     "wenet_rx_last_ms", "wenet_rx_device_info", "wenet_rx_version",
 ]
@@ -90,6 +90,7 @@ def load():
     L.wenet_rx_frames.restype = ll; L.wenet_rx_frames.argtypes = [vp, i]
     L.wenet_rx_packets.restype = ll; L.wenet_rx_packets.argtypes = [vp, i]
     L.wenet_rx_get_packets.restype = ll; L.wenet_rx_get_packets.argtypes = [vp, i, vp, vp, ll]
+    L.wenet_rx_packet_census.argtypes = [vp, i, C.POINTER(ll)]
     L.wenet_rx_get_soft.restype = ll; L.wenet_rx_get_soft.argtypes = [vp, i, vp, ll]
     L.wenet_rx_enable_trace.argtypes = [vp, i]
     L.wenet_rx_get_trace.restype = ll; L.wenet_rx_get_trace.argtypes = [vp, i, vp, ll]

@@ -85,6 +85,13 @@ class RxBatch:
         p = self.packets(ch)
         return b"".join(bytes(p["bytes"][i][:256]) for i in range(p["n"]) if p["crc_ok"][i])
 
+    def census(self, ch):
+        """CRC-valid packets of capture ch by Wenet packet type (wenet_amd.packets.CENSUS_CLASSES order)."""
+        c = (C.c_longlong * 8)()
+        if self._L.wenet_rx_packet_census(self._h, ch, c) < 0:
+            raise RuntimeError("wenet_rx_packet_census failed")
+        return [int(x) for x in c]
+
     def soft(self, ch):
         n = self.frames(ch) * self.Nbits
         sd = np.zeros(max(n, 1), np.float32)
