@@ -298,15 +298,16 @@ __global__ __launch_bounds__(WP_THREADS, RAW ? 6 : 5) void wenet_demod_pipe_kern
                 const v2f d = {dd.x, dd.y};
                 v2f phi = ((const v2f *)(CKb + (((j & 1) * 2 + (segB ? 1 : 0)) * M + m) * WP_CKROW))[cc];
                 float2 *row = PH + m * Lpad + s0;
+                float2 *dump = PH + M * Lpad;                            // steps past the end of a segment land here (no branches)
+                const int rbase = RIDX(src0 + s0);
                 float2 x[WP_CK];
 #pragma unroll
-                for (int u = 0; u < WP_CK; u++) x[u] = ring_get(RIDX(src0 + s0 + (u < cnt ? u : 0)));
+                for (int u = 0; u < WP_CK; u++) x[u] = ring_get((rbase + (u < cnt ? u : 0)) & rmask);
 #pragma unroll
                 for (int u = 0; u < WP_CK; u++) {
-                    if (u < cnt) {
-                        row[u] = cmul(x[u], make_float2(phi.x, -phi.y));
-                        phi = cmul_pk(phi, d);
-                    }
+                    float2 *dst = (u < cnt) ? row + u : dump;
+                    *dst = cmul(x[u], make_float2(phi.x, -phi.y));
+                    phi = cmul_pk(phi, d);
                 }
             }
         }

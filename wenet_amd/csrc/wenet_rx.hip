@@ -108,7 +108,7 @@ struct DemodTables {
             int t = 0;
             c.p_ring = ring;
             c.p_off_XR = t;   t = align16(t + ring * (raw ? 2 : 8));
-            c.p_off_PH = t;   t = align16(t + M * c.Lpad * 8);
+            c.p_off_PH = t;   t = align16(t + (M * c.Lpad + 2) * 8);    // + a dump slot for the mix stage
             c.p_off_CK = t;   t = align16(t + 2 * 2 * M * 80 * 8);      // WP_CKROW = 80
             c.p_off_CKD = t;  t = align16(t + 2 * 2 * M * 8);
             c.p_off_FI = t;   t = align16(t + 2 * M * c.NI * 8);
