@@ -285,6 +285,33 @@ def test_baud_rate_error_and_frequency_shift(name, ppm, shift):
     rx.close()
 
 
+@pytest.mark.parametrize("M,Ts,P,fmt,nopipe", [(4, 8, 8, "cu8", False), (4, 10, 10, "cs16", False), (2, 10, 5, "cu8", False),
+                                               (2, 10, 2, "cs16", False), (2, 12, 12, "cu8", False), (2, 12, 6, "cf32", False),
+                                               (2, 16, 16, "cu8", False), (2, 10, 10, "cu8", True), (4, 8, 4, "cu8", True)])
+def test_configuration_matrix(M, Ts, P, fmt, nopipe, monkeypatch):
+    """Every kernel variant against the oracle: pipelined kernel with 2 and 4 tones, raw-byte and float sample ring,
+    the fast (Ts 8/10, P = Ts) and the generic integrator path (other Ts, fsk_demod's -p option), and the sequential
+    kernel (configurations too large for the pipeline, or forced)."""
+    import dataclasses
+    if nopipe:
+        monkeypatch.setenv("WENET_RX_NO_PIPE", "1")
+    Rs = 48000
+    cfg = dataclasses.replace(siggen.config_v1(), name="m", M=M, Fs=Rs * Ts, Rs=Rs, f_low=Rs * 1.0, f_space=float(Rs))
+    raw, _ = siggen.make_capture(cfg, 2 if M == 2 else 3, 11.0, seed=100 * M + Ts + P, fmt=fmt, ppm=120.0)
+    ref, tr = ol.oracle_demod(raw, fmt, cfg.Fs, cfg.Rs, M, P=P, want_trace=True)
+    f = Fsk(cfg.Fs, cfg.Rs, P, M)
+    sd, _, gtr = f.demod_stream(raw, fmt, want_trace=True)
+    assert sd.size > 0 and bits_equal(sd, ref)
+    assert bits_equal(np.ascontiguousarray(gtr[:, :7]), np.ascontiguousarray(tr[:, :7]))
+    f.close()
+    rx = RxBatch(cfg.Fs, cfg.Rs, M, P=P, framing=cfg.mode)
+    rx.process([raw, raw[:raw.size // 2]], fmt)
+    assert bits_equal(rx.soft(0), ref)
+    d = ol.oracle_deframe(ref, cfg.mode)
+    assert rx.valid_payloads(0) == b"".join(bytes(d["bytes"][i][:256]) for i in range(d["n"]) if d["crc_ok"][i])
+    rx.close()
+
+
 def test_every_capture_length_around_frame_boundaries():
     """0..4 frames +- one sample, one launch each and all together as a ragged batch."""
     cfg = siggen.config_v2()
