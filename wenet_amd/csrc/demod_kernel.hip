@@ -46,6 +46,8 @@ __global__ __launch_bounds__(NT) void wenet_demod_kernel(WrDemodCfg cfg, const W
     float  *FW = (float *)(smem + cfg.off_FW);    // [Ndft/2]             peak-search working copy
     float  *SDL = (float *)(smem + cfg.off_SD);   // [Nbits]              last soft decisions (kept across a NaN frame)
     float  *SC = (float *)(smem + cfg.off_SC);    // [4*Nsym + 16]        scratch
+    float2 *CKb = (float2 *)(smem + cfg.off_CK);  // [2 segments][M][ckrow] every 8th NCO phasor (checkpoints)
+    float2 *CKD = (float2 *)(smem + cfg.off_CKD); // [2 segments][M]        NCO step of each segment
     // configuration tables: LDS copies (TLDS) or the global originals (configurations too big for LDS)
     const float2 *tw_t   = TLDS ? (const float2 *)(smem + cfg.off_TW) : cfg.tw;
     const float  *hann_t = TLDS ? (const float *)(smem + cfg.off_HANN) : cfg.hann;
@@ -241,21 +243,33 @@ __global__ __launch_bounds__(NT) void wenet_demod_kernel(WrDemodCfg cfg, const W
             v2f phi = cmul_pk((v2f){bo.x, bo.y}, (v2f){phi_c.x, phi_c.y});   // back the phase off (fsk.c:758-759)
             float2 dd = dphi_t[bp];                                          // step with the PREVIOUS estimate
             v2f d = {dd.x, dd.y};
-            v2f *ph = (v2f *)(PH + lane * Lpad);
-            int s = 0;
-            for (; s < nold; s++) { ph[s] = phi; phi = cmul_pk(phi, d); }    // old samples (2..2.5 Ts steps)
+            // Only every 8th phasor is stored (a store per step doubles the cost of the dependent chain); the
+            // down-conversion threads replay the steps in between with the same instruction sequence.
+            const int ckrow = cfg.ckrow;
+            v2f *ckA = (v2f *)(CKb + (0 * M + lane) * ckrow);
+            v2f *ckB = (v2f *)(CKb + (1 * M + lane) * ckrow);
+            CKD[0 * M + lane] = dd;
+            int s = 0, c = 0;
+            for (; s + 8 <= nold; s += 8, c++) {
+                ckA[c] = phi;
+#pragma unroll
+                for (int u = 0; u < 8; u++) phi = cmul_pk(phi, d);
+            }
+            if (s < nold) { ckA[c] = phi; for (; s < nold; s++) phi = cmul_pk(phi, d); }
             {                                                              // comp_normalize, new estimate
                 const float av = sqrtf(phi.x * phi.x + phi.y * phi.y);
                 phi = (v2f){phi.x / av, phi.y / av};
                 dd = dphi_t[bc];
                 d = (v2f){dd.x, dd.y};
             }
-            // new samples: manual unroll by 8 (inline asm is 'convergent', the loop unroller leaves it alone)
-            for (; s + 8 <= L; s += 8) {
+            CKD[1 * M + lane] = dd;
+            c = 0;
+            for (; s + 8 <= L; s += 8, c++) {
+                ckB[c] = phi;
 #pragma unroll
-                for (int u = 0; u < 8; u++) { ph[s + u] = phi; phi = cmul_pk(phi, d); }
+                for (int u = 0; u < 8; u++) phi = cmul_pk(phi, d);
             }
-            for (; s < L; s++) { ph[s] = phi; phi = cmul_pk(phi, d); }
+            if (s < L) { ckB[c] = phi; for (; s < L; s++) phi = cmul_pk(phi, d); }
             phi_c = make_float2(phi.x, phi.y);                             // saved un-normalised (fsk.c:846)
         }
 #pragma unroll
@@ -263,17 +277,26 @@ __global__ __launch_bounds__(NT) void wenet_demod_kernel(WrDemodCfg cfg, const W
         lds_barrier();
 
         PROF_MARK(3);
-        // ---- down-convert: sample * conj(phasor), in place (fsk.c:791,817) ------------------
+        // ---- down-convert: sample * conj(phasor) (fsk.c:791,817); one thread per (tone, checkpoint) replays the
+        //      <= 8 chain steps after its checkpoint ----------------------------------------------------------------
         {
             const float2 *src = X + (nstash - nold);                       // fsk.c:775: old tail then new block, contiguous
-#pragma unroll
-            for (int m = 0; m < M; m++) {
-                float2 *row = PH + m * Lpad;
-                for (int s = tid; s < L; s += NT) {
-                    const float2 x = src[s];
-                    const float2 p = row[s];
-                    const float2 pc = make_float2(p.x, -p.y);
-                    row[s] = cmul(x, pc);
+            const int nA = (nold + 7) / 8, nB = (L - nold + 7) / 8;
+            const int per_tone = nA + nB;
+            for (int w = tid; w < M * per_tone; w += NT) {
+                const int m = w / per_tone, c = w - m * per_tone;
+                const bool segB = c >= nA;
+                const int cc = segB ? c - nA : c;
+                const int s0 = segB ? nold + cc * 8 : cc * 8;
+                const int send = segB ? L : nold;
+                const int cnt = (send - s0) < 8 ? (send - s0) : 8;
+                const float2 dd = CKD[(segB ? 1 : 0) * M + m];
+                const v2f d = {dd.x, dd.y};
+                v2f phi = ((const v2f *)(CKb + ((segB ? 1 : 0) * M + m) * cfg.ckrow))[cc];
+                float2 *row = PH + m * Lpad + s0;
+                for (int u = 0; u < cnt; u++) {
+                    row[u] = cmul(src[s0 + u], make_float2(phi.x, -phi.y));
+                    phi = cmul_pk(phi, d);
                 }
             }
         }
@@ -340,21 +363,35 @@ __global__ __launch_bounds__(NT) void wenet_demod_kernel(WrDemodCfg cfg, const W
             typedef float v4f __attribute__((ext_vector_type(4)));
             const v4f *TP4 = (const v4f *)TP;
             v2f acc = {0.f, 0.f};
-            v4f cur[4], nxt[4];
+            v4f bufA[4], bufB[4];                                        // ping-pong: loads of one batch fly while the other is summed
             int i = 0;
             if (NI >= 8) {
 #pragma unroll
-                for (int u = 0; u < 4; u++) cur[u] = TP4[u];
-                for (i = 8; i + 8 <= NI; i += 8) {
+                for (int u = 0; u < 4; u++) bufA[u] = TP4[u];
+                for (i = 8; i + 16 <= NI; i += 16) {
 #pragma unroll
-                    for (int u = 0; u < 4; u++) nxt[u] = TP4[(i >> 1) + u];
+                    for (int u = 0; u < 4; u++) bufB[u] = TP4[(i >> 1) + u];
 #pragma unroll
-                    for (int u = 0; u < 4; u++) { acc = acc + cur[u].xy; acc = acc + cur[u].zw; }
+                    for (int u = 0; u < 4; u++) { acc = acc + bufA[u].xy; acc = acc + bufA[u].zw; }
+                    asm volatile("" : "+v"(acc) : : "memory");           // keep the reload of A behind its last use (no register copies)
 #pragma unroll
-                    for (int u = 0; u < 4; u++) cur[u] = nxt[u];
+                    for (int u = 0; u < 4; u++) bufA[u] = TP4[(i >> 1) + 4 + u];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { acc = acc + bufB[u].xy; acc = acc + bufB[u].zw; }
+                    asm volatile("" : "+v"(acc) : : "memory");
                 }
+                if (i + 8 <= NI) {
 #pragma unroll
-                for (int u = 0; u < 4; u++) { acc = acc + cur[u].xy; acc = acc + cur[u].zw; }
+                    for (int u = 0; u < 4; u++) bufB[u] = TP4[(i >> 1) + u];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { acc = acc + bufA[u].xy; acc = acc + bufA[u].zw; }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { acc = acc + bufB[u].xy; acc = acc + bufB[u].zw; }
+                    i += 8;
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { acc = acc + bufA[u].xy; acc = acc + bufA[u].zw; }
+                }
             }
             for (; i < NI; i++) { const float2 v = TP[i]; acc = acc + (v2f){v.x, v.y}; }
             tcr = acc.x; tci = acc.y;

@@ -233,6 +233,9 @@ struct DemodTables {
         cfg.off_FW = o; o = align16(o + NH * 4);
         cfg.off_SD = o; o = align16(o + cfg.Nbits * 4);
         cfg.off_SC = o; o = align16(o + (4 * nsyms + 16) * 4);
+        cfg.ckrow = cfg.L / 8 + 2;
+        cfg.off_CK = o; o = align16(o + 2 * M * cfg.ckrow * 8);
+        cfg.off_CKD = o; o = align16(o + 2 * M * 8);
         {   // LDS copies of the configuration tables when they fit next to the working set
             int t = o;
             const int o_tw = t;   t = align16(t + Ndft * 8);
