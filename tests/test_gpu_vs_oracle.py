@@ -312,6 +312,28 @@ def test_configuration_matrix(M, Ts, P, fmt, nopipe, monkeypatch):
     rx.close()
 
 
+@pytest.mark.parametrize("split", ["0", "1"])
+def test_both_timing_sum_variants(split, monkeypatch):
+    """The batch chain picks the lane-split timing sum when there are more captures than CUs and the packed one
+    otherwise; both are forced here on a small batch (slips, low SNR and a NaN-free silent capture included)."""
+    monkeypatch.setenv("WENET_RX_TSUM_SPLIT", split)
+    caps, cfgs = [], []
+    for name, eb, ppm, seed in (("v2", 8.0, 0.0, 1), ("v2", 5.0, 300.0, 2), ("v2", 14.0, -2500.0, 3)):
+        cfg = siggen.CONFIGS[name]()
+        raw, _ = siggen.make_capture(cfg, 3, eb, seed=seed, ppm=ppm)
+        caps.append(raw)
+    caps.append(np.full(2 * 480 * 20, 127, np.uint8))
+    cfg = siggen.config_v2()
+    rx = RxBatch(cfg.Fs, cfg.Rs, cfg.M, framing=cfg.mode)
+    rx.enable_trace()
+    rx.process(caps, "cu8")
+    for i, raw in enumerate(caps):
+        ref, tr = ol.oracle_demod(raw, "cu8", cfg.Fs, cfg.Rs, cfg.M, want_trace=True)
+        assert bits_equal(rx.soft(i), ref)
+        assert bits_equal(np.ascontiguousarray(rx.trace(i)[:, :7]), np.ascontiguousarray(tr[:, :7]))
+    rx.close()
+
+
 def test_every_capture_length_around_frame_boundaries():
     """0..4 frames +- one sample, one launch each and all together as a ragged batch."""
     cfg = siggen.config_v2()

@@ -871,7 +871,7 @@ extern "C" int wenet_rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw,
     // every capture starts from reset state; with cu8 input the three-per-CU raw-ring variant applies
     WrDemodCfg launch_cfg = (fmt == WENET_FMT_CU8) ? rx->tab.raw_cfg() : rx->tab.cfg;
     // more captures than CUs: SIMD time matters more than the latency of one frame (see tstage in demod_pipe_kernel.hip)
-    launch_cfg.p_tsum_split = (nchan > wenet_rx_device_info(1)) ? 1 : 0;
+    launch_cfg.p_tsum_split = getenv("WENET_RX_TSUM_SPLIT") ? atoi(getenv("WENET_RX_TSUM_SPLIT")) : ((nchan > wenet_rx_device_info(1)) ? 1 : 0);
     WR_CHECK(wr_launch_demod_ex(&launch_cfg, rx->d_chans.as<WrChan>(), nchan, stream, rx->profile ? (getenv("WENET_RX_PROFILE")[0] == '2' ? 2 : 1) : 0), -4);
     WR_CHECK(hipEventRecord(rx->ev[1], stream), -4);
     WR_CHECK(wr_launch_deframe(rx->d_dchans.as<WrDeframeChan>(), nchan, rx->mode, stream), -4);
