@@ -602,9 +602,10 @@ __global__ __launch_bounds__(WP_THREADS, RAW ? 6 : 5) void wenet_demod_pipe_kern
     };
 
     // the chain wave is the critical path of every frame: let it win VALU arbitration on its SIMD
-    if (wave == 0 && (cfg.chain_prio & 1)) __builtin_amdgcn_s_setprio(3);
-    if (wave == 2 && (cfg.chain_prio & 2)) __builtin_amdgcn_s_setprio(2);
-    if (wave == 1 && (cfg.chain_prio & 4)) __builtin_amdgcn_s_setprio(1);
+    {   // cfg.chain_prio = chain | T << 2 | estimator << 4 (two bits each; s_setprio takes an immediate)
+        const int pr = (wave == 0) ? (cfg.chain_prio & 3) : (wave == 2) ? ((cfg.chain_prio >> 2) & 3) : (wave == 1) ? ((cfg.chain_prio >> 4) & 3) : 0;
+        if (pr == 3) __builtin_amdgcn_s_setprio(3); else if (pr == 2) __builtin_amdgcn_s_setprio(2); else if (pr == 1) __builtin_amdgcn_s_setprio(1);
+    }
 
     // ================================ pipeline prologue ========================================
     //   E(0) | C(0),E(1) | D(0),C(1),E(2)         (frame 0 with the true nin, later frames speculative)

@@ -250,7 +250,10 @@ struct DemodTables {
         }
         {
             const bool fits = pipe_layout(cfg, false);
-            cfg.chain_prio = getenv("WENET_RX_CHAIN_PRIO") ? atoi(getenv("WENET_RX_CHAIN_PRIO")) : 7;   // s_setprio: bit0 chain wave (3), bit1 T wave (2), bit2 estimator (1): the serial waves win VALU arbitration against the parallel D waves sharing their SIMDs (-10 % at 512 captures)
+            // s_setprio of the serial waves: chain | T << 2 | estimator << 4 (0..3 each); default: all three one step above the
+            // parallel D waves, so that they win VALU arbitration on the SIMDs they share (-10 % at two captures per CU;
+            // ranking the three against each other measured no better)
+            cfg.chain_prio = getenv("WENET_RX_CHAIN_PRIO") ? atoi(getenv("WENET_RX_CHAIN_PRIO")) : (1 | 1 << 2 | 1 << 4);
             cfg.pipe_ok = (fits && cfg.p_lds_bytes <= 80 * 1024 && getenv("WENET_RX_NO_PIPE") == nullptr) ? 1 : 0;
         }
         cfg.lds_bytes = o;
