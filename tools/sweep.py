@@ -18,11 +18,20 @@ a = ap.parse_args()
 cfg = siggen.CONFIGS[a.config]()
 nsym = int(a.seconds * cfg.Rs); nsamp = nsym * cfg.Ts
 ebs = [a.lo + (a.hi - a.lo) * c / (a.n - 1) for c in range(a.n)]
-caps, pls = [], []
-for c, eb in enumerate(ebs):
-    sym, pl = siggen.air_symbols(cfg, nsym, 3000 + c)
-    caps.append(siggen.make_capture_torch(cfg, sym, eb, 3000 + c)); pls.append(pl)
+from wenet_amd.tx import Tx
+dev = torch.device("cuda", 0)
+tx = Tx.from_config(cfg)
+spp = tx.symbols_per_packet; nfr = nsym // spp + 1
+g = torch.Generator(device=dev); g.manual_seed(3000)
+pay = torch.randint(0, 256, (a.n * nfr, 256), dtype=torch.uint8, device=dev, generator=g)
+sym = torch.empty(a.n * nfr * spp, dtype=torch.uint8, device=dev)
+tx.frame_packets_device(pay.data_ptr(), a.n * nfr, sym.data_ptr())
+caps = [torch.empty(2 * nsamp, dtype=torch.uint8, device=dev) for _ in range(a.n)]
+tx.modulate_device([sym.data_ptr() + c * nfr * spp for c in range(a.n)], [nsym] * a.n, [c.data_ptr() for c in caps], ebs,
+                   seeds=[3000 + c for c in range(a.n)])
 torch.cuda.synchronize()
+pay_h = pay.cpu().numpy().reshape(a.n, nfr, 256)
+pls = [[pay_h[c, k].tobytes() for k in range(nfr)] for c in range(a.n)]
 rx = RxBatch(cfg.Fs, cfg.Rs, cfg.M, framing=cfg.mode)
 ptrs = [int(c.data_ptr()) for c in caps]; ns = [nsamp] * a.n
 rx.enqueue_device(ptrs, ns, "cu8"); rx.collect()
