@@ -77,6 +77,21 @@ __global__ void k(float *out, long long *cyc, int iters) {
         } else if (MODE == 12) {  // dependent v_mul_f32 x8
             asm volatile("v_mul_f32 %0, %0, %1\n v_mul_f32 %0, %0, %1\n v_mul_f32 %0, %0, %1\n v_mul_f32 %0, %0, %1\n"
                          "v_mul_f32 %0, %0, %1\n v_mul_f32 %0, %0, %1\n v_mul_f32 %0, %0, %1\n v_mul_f32 %0, %0, %1" : "+v"(a) : "v"(b));
+        } else if (MODE == 13 || MODE == 14 || MODE == 15) {   // packed cmul / dependent plain adds with EXEC narrowed ONCE (no branches in the loop)
+            if (i == 0) {
+                if (MODE == 13 || MODE == 15) asm volatile("s_mov_b64 exec, 3" ::: "memory");
+                else asm volatile("s_mov_b64 exec, 0xffffffff" ::: "memory");          // lower 32 lanes only
+            }
+            v2f t1, t2;
+            if (MODE == 15) {
+                asm volatile("v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1\n"
+                             "v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1" : "+v"(a) : "v"(b));
+            } else {
+                for (int u = 0; u < 4; u++)
+                    asm volatile("v_pk_mul_f32 %1, %0, %3 op_sel_hi:[1,0]\n v_pk_mul_f32 %2, %0, %3 op_sel:[1,1] op_sel_hi:[0,1]\n"
+                                 "v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "+v"(p), "=&v"(t1), "=&v"(t2) : "v"(q));
+            }
+            if (i == iters - 1) asm volatile("s_mov_b64 exec, -1" ::: "memory");
         } else if (MODE == 6) {   // packed cmul without the nop
             v2f t1, t2;
             for (int u = 0; u < 4; u++)
@@ -112,6 +127,9 @@ int main() {
     run<6>("cmul packed no nop", 4);
     run<4>("cmul scalar (per step)", 4);
     run<12>("dep v_mul_f32", 8);
+    run<13>("cmul packed, exec=2 lanes", 4);
+    run<14>("cmul packed, exec=32 lanes", 4);
+    run<15>("dep v_add_f32, exec=2 lanes", 8);
     run<10>("cmul lane-pair mul_dpp", 4);
     run<11>("cmul lane-pair add_dpp", 4);
     run<9>("cmul packed+nop, 2 lanes", 4);
