@@ -9,6 +9,7 @@ import subprocess
 import numpy as np
 import pytest
 
+import oracle_lib as ol
 from conftest import load_golden
 from wenet_amd import siggen
 
@@ -102,3 +103,36 @@ def test_cli_error_behaviour(tmp_path):
     # empty input: exit 0, nothing written, summary line printed (PER of 0/0 as the reference prints it)
     r = subprocess.run([f"{BIN}/wenet_ldpc", "-", "-"], stdin=subprocess.DEVNULL, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 0 and r.stdout == b"" and b"packets: 0 packet_errors: 0" in r.stderr
+
+
+@pytest.mark.parametrize("flags", [["-f"], ["-f", "-s"], ["-f", "--stats=50"]])
+def test_testframe_mode_matches_reference(flags, tmp_path):
+    """fsk_demod -f (src/fsk_demod.c:226-245,304-343): sliding compare against the known 100-bit frame (srand(158324)),
+    'errs: ...' lines or, with -t, one JSON line per frame with a detection.  Same stderr as the reference binary."""
+    import ctypes as C
+    import json
+    import re
+    if not ol.have_ref():
+        pytest.skip("oracle/_ref not built")
+    libc = C.CDLL("libc.so.6")
+    libc.srand(158324)
+    frame = np.array([libc.rand() & 1 for _ in range(100)], np.uint8)
+    cfg = siggen.config_v2()
+    rng = np.random.default_rng(9)
+    bits = np.concatenate([rng.integers(0, 2, 777, dtype=np.uint8), np.tile(frame, 40), rng.integers(0, 2, 300, dtype=np.uint8), np.tile(frame, 9)])
+    x = siggen.add_noise(siggen.modulate(bits, cfg), cfg, 9.0, rng)
+    raw = tmp_path / "tf.cu8"
+    siggen.to_cu8(x).tofile(raw)
+    outs = []
+    for exe in (os.path.join(ol.REF_DIR, "fsk_demod"), os.path.join(BIN, "fsk_demod")):
+        p = subprocess.run([exe, "--cu8"] + flags + [str(cfg.M), str(cfg.Fs), str(cfg.Rs), str(raw), str(tmp_path / "o.bin")],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True)
+        outs.append((p.stderr.decode(), (tmp_path / "o.bin").read_bytes()))
+    (ref_err, ref_out), (my_err, my_out) = outs
+    assert my_out == ref_out
+    strip = lambda t: re.sub(r'"secs": \d+', '"secs": 0', t)
+    assert strip(my_err) == strip(ref_err)
+    assert ("errs:" in ref_err) or ('"frames"' in ref_err)                  # the pattern was really found
+    if "--stats=50" in flags:
+        last = json.loads([l for l in my_err.splitlines() if l.startswith("{")][-1])
+        assert last["frames"] >= 40 and last["bits"] == 100 * last["frames"]

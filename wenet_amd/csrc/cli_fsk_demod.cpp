@@ -5,8 +5,8 @@
 //   usage: fsk_demod [-l] [-p P] [-s] [(-c|-d)] [-t [r]] [-f] (2|4) SampleRate SymbolRate In Out
 //
 // Differences that cannot be avoided, all outside the data path:
-//   * -l/--lbr (fsk_create, 1-second frames) and -f/--testframes are not part of the Wenet receive
-//     chain: they exit(1) with a message instead of silently doing something else.
+//   * -l/--lbr (fsk_create, 1-second frames) is not part of the Wenet receive chain:
+//     it exits(1) with a message instead of silently doing something else.
 //   * input is read in blocks (whatever the pipe holds, at least one frame) instead of exactly nin
 //     samples per fread; the frames produced, their order and the trailing-partial-frame rule
 //     (src/fsk_demod.c:270) are identical.
@@ -35,7 +35,7 @@ static void usage(const char *argv0) {                                      /* f
     fprintf(stderr, " -c --cs16         -  The raw input file will be in complex signed 16 bit format.\n");
     fprintf(stderr, " -d --cu8          -  The raw input file will be in complex unsigned 8 bit format.\n");
     fprintf(stderr, "                        If neither -c nor -d are used, the input should be in signed 16 bit format.\n");
-    fprintf(stderr, " -f --testframes   -  Testframe mode (not supported by this build)\n");
+    fprintf(stderr, " -f --testframes   -  Testframe mode, prints stats to stderr when a testframe is detected, if -t (JSON) \n");
     fprintf(stderr, " -t[r] --stats=[r] -  Print out modem statistics to stderr in JSON.\n");
     fprintf(stderr, "                         r, if provided, sets the number of modem frames between statistic printouts.\n");
     fprintf(stderr, " -s --soft-dec     -  The output file will be in a soft-decision format, with one 32-bit float per bit.\n");
@@ -43,12 +43,19 @@ static void usage(const char *argv0) {                                      /* f
     exit(1);
 }
 
-static void print_stats(const wenet_modem_stats &s, int M) {               /* fsk_demod.c:351-392 */
+#define TEST_FRAME_SIZE 100                                                 /* fsk_demod.c:30 */
+
+static void print_stats(const wenet_modem_stats &s, int M, int testframe_mode = 0, int testframecnt = 0, int bitcnt = 0, int biterr = 0) {   /* fsk_demod.c:351-392 */
     fprintf(stderr, "{");
     time_t seconds = time(NULL);
     fprintf(stderr, "\"secs\": %ld, \"EbNodB\": %5.1f, \"ppm\": %4d,", (long)seconds, s.snr_est, (int)s.ppm);
     fprintf(stderr, " \"f1_est\":%.1f, \"f2_est\":%.1f", s.f_est[0], s.f_est[1]);
     if (M == 4) fprintf(stderr, ", \"f3_est\":%.1f, \"f4_est\":%.1f", s.f_est[2], s.f_est[3]);
+    if (testframe_mode) {                                                   /* fsk_demod.c:363,389-391 */
+        fprintf(stderr, ", \"frames\":%d, \"bits\":%d, \"errs\":%d", testframecnt, bitcnt, biterr);
+        fprintf(stderr, "}\n");
+        return;
+    }
     fprintf(stderr, ",\t\"eye_diagram\":[");
     for (int i = 0; i < s.neyetr; i++) {
         fprintf(stderr, "[");
@@ -109,7 +116,6 @@ int main(int argc, char *argv[]) {
     if (P == 0) P = Fs / Rs;                                                 /* fsk_demod.c:186-188 */
     if ((M != 2) && (M != 4)) { fprintf(stderr, "Mode %d is not valid. Mode must be 2 or 4.\n", M); usage(argv[0]); }
     if (!hbr) { fprintf(stderr, "fsk_demod (wenet_rx): --lbr mode is not supported by this build\n"); exit(1); }
-    if (testframe_mode) { fprintf(stderr, "fsk_demod (wenet_rx): --testframes is not supported by this build\n"); exit(1); }
 
     FILE *fin = (strcmp(argv[dx + 3], "-") == 0) ? stdin : fopen(argv[dx + 3], "r");
     FILE *fout = (strcmp(argv[dx + 4], "-") == 0) ? stdout : fopen(argv[dx + 4], "w");
@@ -126,7 +132,15 @@ int main(int argc, char *argv[]) {
         int stats_loop = (int)(1 / (stats_rate * loop_time));
         // stats_ctr starts at 0: frame 0 prints nothing and decrements to -1, frame 1 prints and reloads
         // stats_loop, ... => snapshots at frames 1, 1+(stats_loop+1), ...
-        wenet_fsk_enable_stats(fsk, 1, (long)stats_loop + 1);
+        if (testframe_mode) wenet_fsk_enable_stats(fsk, 0, 1);              // stats of any frame may be asked for (printed on detection)
+        else wenet_fsk_enable_stats(fsk, 1, (long)stats_loop + 1);
+    }
+    /* testframe mode (fsk_demod.c:226-245, 304-343): known 100-bit frame from a known seed, sliding compare */
+    uint8_t bitbuf_tx[TEST_FRAME_SIZE], bitbuf_rx[TEST_FRAME_SIZE];
+    int testframecnt = 0, bitcnt = 0, biterr = 0;
+    if (testframe_mode) {
+        srand(158324);
+        for (int i = 0; i < TEST_FRAME_SIZE; i++) { bitbuf_tx[i] = rand() & 0x1; bitbuf_rx[i] = 0; }
     }
     if (signal(SIGTERM, sig_handler) == SIG_ERR) printf("\ncan't catch SIGTERM\n");
 
@@ -134,10 +148,10 @@ int main(int argc, char *argv[]) {
     const size_t bps = (size_t)bytes_per_sample * complex_input;
     const bool piped = (fin == stdin || fout == stdout);
     // block size: files -> ~4 MiB; pipes -> a handful of frames so that latency stays low
-    const size_t max_block = piped ? (size_t)(N + Ts) * 64 : (size_t)4 << 20;
+    const size_t max_block = (piped || testframe_mode) ? (size_t)(N + Ts) * 64 : (size_t)4 << 20;
     std::vector<uint8_t> buf;
     std::vector<uint8_t> out((size_t)(max_block / (N - Ts / 2) + 2) * Nbits * 4);
-    std::vector<wenet_modem_stats> stats(64);
+    std::vector<wenet_modem_stats> stats(testframe_mode ? 96 : 64);
     bool eof = false;
     const int fd = fileno(fin);
     while (true) {
@@ -158,7 +172,27 @@ int main(int argc, char *argv[]) {
         const long cap = (long)(out.size() / ((size_t)Nbits * 4));
         long frames = wenet_fsk_demod_stream(fsk, fmt, buf.data(), (long)have, soft_dec_mode, out.data(), cap, &consumed, NULL);
         if (frames < 0) { fprintf(stderr, "fsk_demod (wenet_rx): GPU demodulation failed (%ld)\n", frames); exit(1); }
-        if (enable_stats) {
+        if (testframe_mode) {
+            int ns = enable_stats ? wenet_fsk_get_stats(fsk, stats.data(), (int)stats.size()) : 0;   // one snapshot per frame
+            for (long f = 0; f < frames; f++) {
+                bool detected = false;
+                for (int j = 0; j < Nbits; j++) {
+                    memmove(bitbuf_rx, bitbuf_rx + 1, TEST_FRAME_SIZE - 1);
+                    if (soft_dec_mode) bitbuf_rx[TEST_FRAME_SIZE - 1] = ((const float *)out.data())[f * Nbits + j] < 0.0;
+                    else bitbuf_rx[TEST_FRAME_SIZE - 1] = out[(size_t)f * Nbits + j];
+                    int errs = 0;
+                    for (int i = 0; i < TEST_FRAME_SIZE; i++) errs += bitbuf_rx[i] != bitbuf_tx[i];
+                    if (errs < 0.1 * TEST_FRAME_SIZE) {
+                        detected = true;
+                        testframecnt++; bitcnt += TEST_FRAME_SIZE; biterr += errs;
+                        if (enable_stats == 0)
+                            fprintf(stderr, "errs: %d FSK BER %f, bits tested %d, bit errors %d\n", errs, ((float)biterr / (float)bitcnt), bitcnt, biterr);
+                    }
+                }
+                // with -t the JSON goes out on frames with a detection only (stats_ctr never runs in this mode, fsk_demod.c:346,398-400)
+                if (enable_stats && detected && f < ns) print_stats(stats[f], M, 1, testframecnt, bitcnt, biterr);
+            }
+        } else if (enable_stats) {
             int ns = wenet_fsk_get_stats(fsk, stats.data(), (int)stats.size());
             for (int i = 0; i < ns; i++) print_stats(stats[i], M);
         }
