@@ -262,6 +262,14 @@ __global__ __launch_bounds__(WP_THREADS, RAW ? 6 : 5) void wenet_demod_pipe_kern
             }
             CKD[((j & 1) * 2 + 1) * M + lane] = dd;
             c = 0;
+            for (; s + 4 * WP_CK <= L; s += 4 * WP_CK, c += 4) {            // four checkpoints per trip: a taken branch costs ~16 cycles
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    ckB[c + k] = phi;
+#pragma unroll
+                    for (int u = 0; u < WP_CK; u++) phi = cmul_pk(phi, d);
+                }
+            }
             for (; s + WP_CK <= L; s += WP_CK, c++) {
                 ckB[c] = phi;
 #pragma unroll
