@@ -772,10 +772,27 @@ struct wenet_rx {
         h_pin_cap = bytes + bytes / 4;
         return true;
     }
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // per sub-batch: [0] before demod, [1] after demod, [2] after deframe, [3] after decode; copied = its input is in HBM
+    struct ChunkEv { hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; hipEvent_t copied = nullptr; };
+    std::vector<ChunkEv> cev;
+    int nchunks = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;      // host-fed batches: H2D of sub-batch k+1 runs under the kernels of sub-batch k
     bool pending = false;
-    ~wenet_rx() { for (auto &e : ev) if (e) (void)hipEventDestroy(e); if (h_pin) (void)hipHostFree(h_pin); }
+    bool chunk_events(int n) {
+        while ((int)cev.size() < n) {
+            ChunkEv c;
+            for (auto &e : c.ev) if (hipEventCreate(&e) != hipSuccess) return false;
+            if (hipEventCreateWithFlags(&c.copied, hipEventDisableTiming) != hipSuccess) return false;
+            cev.push_back(c);
+        }
+        return true;
+    }
+    ~wenet_rx() {
+        for (auto &c : cev) { for (auto &e : c.ev) if (e) (void)hipEventDestroy(e); if (c.copied) (void)hipEventDestroy(c.copied); }
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
+        if (h_pin) (void)hipHostFree(h_pin);
+    }
 };
 
 extern "C" wenet_rx *wenet_rx_create(int Fs, int Rs, int P, int M, int framing_mode, int max_iter, int est_lo, int est_hi) {
@@ -786,7 +803,7 @@ extern "C" wenet_rx *wenet_rx_create(int Fs, int Rs, int P, int M, int framing_m
     if (!rx->tab.build(Fs, Rs, P, M)) { delete rx; return nullptr; }
     if (est_lo > 0 && est_hi > est_lo) rx->tab.set_band(est_lo, est_hi);       // fsk_demod.c:215-218
     rx->mode = framing_mode; rx->max_iter = max_iter; rx->spp = 323 * (framing_mode == 1 ? 10 : 8);
-    for (auto &e : rx->ev) if (hipEventCreate(&e) != hipSuccess) { delete rx; return nullptr; }
+    if (!rx->chunk_events(1)) { delete rx; return nullptr; }
     return rx;
 }
 extern "C" void wenet_rx_destroy(wenet_rx *rx) { delete rx; }
@@ -798,7 +815,10 @@ extern "C" int wenet_rx_packet_census(wenet_rx *rx, int ch, long long counts[8])
 extern "C" void wenet_rx_enable_trace(wenet_rx *rx, int on) { if (rx) { rx->want_trace = on != 0; rx->tab.cfg.stats = on ? 1 : 0; } }
 extern "C" void wenet_rx_enable_llr_dump(wenet_rx *rx, int on) { if (rx) rx->want_llr = on != 0; }
 
-extern "C" int wenet_rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const long long *nsamples, int fmt, void *stream_v) {
+// raw[i]: device address of capture i.  host_src != nullptr: its content still has to be copied there from host_src[i];
+// the batch is then cut into sub-batches whose uploads (copy stream) overlap the kernels of the previous sub-batch.
+static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const long long *nsamples, int fmt, void *stream_v,
+                      const void *const *host_src) {
     if (!rx || nchan <= 0 || fmt < 0 || fmt > 3) return -1;
     LdpcTables *t = ldpc_tables();
     if (!t) return -1;
@@ -870,26 +890,57 @@ extern "C" int wenet_rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw,
     a.census = rx->d_census.as<unsigned>();
     a.llr_out = rx->want_llr ? rx->d_llr.as<float>() : nullptr;
     fill_decode_tables(a, t);
-    WR_CHECK(hipEventRecord(rx->ev[0], stream), -4);
     // every capture starts from reset state; with cu8 input the three-per-CU raw-ring variant applies
     WrDemodCfg launch_cfg = (fmt == WENET_FMT_CU8) ? rx->tab.raw_cfg() : rx->tab.cfg;
     // more captures than CUs: SIMD time matters more than the latency of one frame (see tstage in demod_pipe_kernel.hip)
     launch_cfg.p_tsum_split = getenv("WENET_RX_TSUM_SPLIT") ? atoi(getenv("WENET_RX_TSUM_SPLIT")) : ((nchan > wenet_rx_device_info(1)) ? 1 : 0);
-    WR_CHECK(wr_launch_demod_ex(&launch_cfg, rx->d_chans.as<WrChan>(), nchan, stream, rx->profile ? (getenv("WENET_RX_PROFILE")[0] == '2' ? 2 : 1) : 0), -4);
-    WR_CHECK(hipEventRecord(rx->ev[1], stream), -4);
-    WR_CHECK(wr_launch_deframe(rx->d_dchans.as<WrDeframeChan>(), nchan, rx->mode, stream), -4);
-    WR_CHECK(hipEventRecord(rx->ev[2], stream), -4);
-    WR_CHECK(wr_launch_decode(&a, stream), -4);
-    WR_CHECK(hipEventRecord(rx->ev[3], stream), -4);
+    const int prof = rx->profile ? (getenv("WENET_RX_PROFILE")[0] == '2' ? 2 : 1) : 0;
+    // host-fed: a first sub-batch of one capture per CU gets the kernels going early, then three per CU (= one full round of
+    // the demod kernel) per sub-batch; device-resident input: everything in one go
+    const int ncu = wenet_rx_device_info(1) > 0 ? wenet_rx_device_info(1) : 256;
+    std::vector<int> bounds(1, 0);
+    if (host_src) { for (int b = ncu; b < nchan; b += 3 * ncu) bounds.push_back(b); }
+    bounds.push_back(nchan);
+    rx->nchunks = (int)bounds.size() - 1;
+    if (!rx->chunk_events(rx->nchunks)) return -4;
+    if (host_src && !rx->copy_stream) WR_CHECK(hipStreamCreateWithFlags(&rx->copy_stream, hipStreamNonBlocking), -4);
+    for (int k = 0; k < rx->nchunks; k++) {
+        const int lo = bounds[k], hi = bounds[k + 1], n = hi - lo;
+        wenet_rx::ChunkEv &e = rx->cev[k];
+        if (host_src) {
+            for (int i = lo; i < hi; i++)
+                WR_CHECK(hipMemcpyAsync((void *)raw[i], host_src[i], (size_t)nsamples[i] * kBytesPerSample[fmt], hipMemcpyHostToDevice, rx->copy_stream), -3);
+            WR_CHECK(hipEventRecord(e.copied, rx->copy_stream), -4);
+            WR_CHECK(hipStreamWaitEvent(stream, e.copied, 0), -4);
+        }
+        WrDecodeArgs ak = a;
+        ak.nchan = n;
+        ak.dchans = a.dchans + lo;
+        ak.out = a.out + (size_t)lo * max_pk;
+        ak.esn0 = a.esn0 + (size_t)lo * max_pk;
+        ak.census = a.census + (size_t)lo * WR_CENSUS_CLASSES;
+        if (a.llr_out) ak.llr_out = a.llr_out + (size_t)lo * max_pk * WR_NCODE;
+        WR_CHECK(hipEventRecord(e.ev[0], stream), -4);
+        WR_CHECK(wr_launch_demod_ex(&launch_cfg, rx->d_chans.as<WrChan>() + lo, n, stream, prof), -4);
+        WR_CHECK(hipEventRecord(e.ev[1], stream), -4);
+        WR_CHECK(wr_launch_deframe(rx->d_dchans.as<WrDeframeChan>() + lo, n, rx->mode, stream), -4);
+        WR_CHECK(hipEventRecord(e.ev[2], stream), -4);
+        WR_CHECK(wr_launch_decode(&ak, stream), -4);
+        WR_CHECK(hipEventRecord(e.ev[3], stream), -4);
+    }
     rx->pending = true;
     return 0;
+}
+
+extern "C" int wenet_rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const long long *nsamples, int fmt, void *stream_v) {
+    return rx_enqueue(rx, nchan, raw, nsamples, fmt, stream_v, nullptr);
 }
 
 extern "C" int wenet_rx_collect(wenet_rx *rx) {
     if (!rx || !rx->pending) return -1;
     const WrDemodCfg &c = rx->tab.cfg;
     const int nchan = rx->nchan;
-    WR_CHECK(hipEventSynchronize(rx->ev[3]), -4);
+    WR_CHECK(hipEventSynchronize(rx->cev[rx->nchunks - 1].ev[3]), -4);
     rx->h_dstates.resize(nchan);
     WR_CHECK(hipMemcpy(rx->h_states.data(), rx->d_states.p, (size_t)c.st_floats * 4 * nchan, hipMemcpyDeviceToHost), -3);
     WR_CHECK(hipMemcpy(rx->h_dstates.data(), rx->d_dstates.p, sizeof(WrDeframeState) * nchan, hipMemcpyDeviceToHost), -3);
@@ -920,11 +971,8 @@ extern "C" int wenet_rx_process(wenet_rx *rx, int nchan, const void *const *raw,
     for (int i = 0; i < nchan; i++) off[i + 1] = (off[i] + (size_t)nsamples[i] * kBytesPerSample[fmt] + 255) & ~(size_t)255;
     if (!rx->d_raw.reserve(off[nchan] + 256)) return -2;
     std::vector<const void *> dptr(nchan);
-    for (int i = 0; i < nchan; i++) {
-        dptr[i] = rx->d_raw.as<char>() + off[i];
-        WR_CHECK(hipMemcpy((void *)dptr[i], raw[i], (size_t)nsamples[i] * kBytesPerSample[fmt], hipMemcpyHostToDevice), -3);
-    }
-    int rc = wenet_rx_enqueue(rx, nchan, dptr.data(), nsamples, fmt, stream);
+    for (int i = 0; i < nchan; i++) dptr[i] = rx->d_raw.as<char>() + off[i];
+    int rc = rx_enqueue(rx, nchan, dptr.data(), nsamples, fmt, stream, raw);        // uploads overlap the kernels, sub-batch by sub-batch
     return rc < 0 ? rc : wenet_rx_collect(rx);
 }
 
@@ -972,9 +1020,18 @@ extern "C" long long wenet_rx_get_llrs(wenet_rx *rx, int ch, float *llr, long lo
 }
 extern "C" float wenet_rx_last_ms(wenet_rx *rx, int what) {
     if (!rx || what < 0 || what > 3) return -1.f;
+    if (rx->nchunks <= 0) return -1.f;
     float ms = 0.f;
-    hipError_t e = (what == 3) ? hipEventElapsedTime(&ms, rx->ev[0], rx->ev[3]) : hipEventElapsedTime(&ms, rx->ev[what], rx->ev[what + 1]);
-    return e == hipSuccess ? ms : -1.f;
+    if (what == 3) {                                                   // first launch to last completion (host-fed: uploads included)
+        if (hipEventElapsedTime(&ms, rx->cev[0].ev[0], rx->cev[rx->nchunks - 1].ev[3]) != hipSuccess) return -1.f;
+        return ms;
+    }
+    for (int k = 0; k < rx->nchunks; k++) {                            // kernel time summed over the sub-batches
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, rx->cev[k].ev[what], rx->cev[k].ev[what + 1]) != hipSuccess) return -1.f;
+        ms += t;
+    }
+    return ms;
 }
 
 // development aid (not in the public header): per-phase cycle totals of channel ch from the last
