@@ -12,6 +12,7 @@
 //     (src/fsk_demod.c:270) are identical.
 #include <errno.h>
 #include <getopt.h>
+#include <poll.h>
 #include <signal.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -127,9 +128,11 @@ int main(int argc, char *argv[]) {
     if (fin == NULL || fout == NULL || fsk == NULL) { fprintf(stderr, "Couldn't open files\n"); exit(1); }
 
     const int Nbits = wenet_fsk_info(fsk, 6), N = wenet_fsk_info(fsk, 1), Ts = wenet_fsk_info(fsk, 2);
+    int stats_period = 1;
     if (enable_stats) {                                                      /* fsk_demod.c:247-251, 345-401 */
         float loop_time = ((float)wenet_fsk_nin(fsk)) / ((float)Fs);
         int stats_loop = (int)(1 / (stats_rate * loop_time));
+        stats_period = testframe_mode ? 1 : stats_loop + 1;
         // stats_ctr starts at 0: frame 0 prints nothing and decrements to -1, frame 1 prints and reloads
         // stats_loop, ... => snapshots at frames 1, 1+(stats_loop+1), ...
         if (testframe_mode) wenet_fsk_enable_stats(fsk, 0, 1);              // stats of any frame may be asked for (printed on detection)
@@ -147,11 +150,13 @@ int main(int argc, char *argv[]) {
     const int fmt = (complex_input == 1) ? WENET_FMT_S16_REAL : (bytes_per_sample == 1 ? WENET_FMT_CU8 : WENET_FMT_CS16);
     const size_t bps = (size_t)bytes_per_sample * complex_input;
     const bool piped = (fin == stdin || fout == stdout);
-    // block size: files -> ~4 MiB; pipes -> a handful of frames so that latency stays low
-    const size_t max_block = (piped || testframe_mode) ? (size_t)(N + Ts) * 64 : (size_t)4 << 20;
+    // block size (samples): ~4 MiB.  A pipe is drained: the first read blocks until something arrives (live streams keep
+    // their latency: a block is whatever the pipe holds), then everything already waiting is taken along, so a fast
+    // upstream (cat of a file) gives big blocks.  Testframe mode keeps small blocks (one stats snapshot per frame).
+    const size_t max_block = testframe_mode ? (size_t)(N + Ts) * 64 : (size_t)4 << 20;
     std::vector<uint8_t> buf;
     std::vector<uint8_t> out((size_t)(max_block / (N - Ts / 2) + 2) * Nbits * 4);
-    std::vector<wenet_modem_stats> stats(testframe_mode ? 96 : 64);
+    std::vector<wenet_modem_stats> stats(enable_stats ? (max_block / (size_t)(N - Ts / 2) + 2) / (size_t)stats_period + 2 : 1);   // snapshots one call can produce
     bool eof = false;
     const int fd = fileno(fin);
     while (true) {
@@ -163,7 +168,15 @@ int main(int argc, char *argv[]) {
             buf.resize(old + want);
             ssize_t got = read(fd, buf.data() + old, want);
             if (got < 0) { if (errno == EINTR) { buf.resize(old); continue; } got = 0; }
-            buf.resize(old + (size_t)got);
+            size_t filled = (size_t)got;
+            while (got > 0 && filled < want) {                                   /* drain what is already there */
+                struct pollfd pf = {fd, POLLIN, 0};
+                if (poll(&pf, 1, 0) <= 0 || !(pf.revents & POLLIN)) break;
+                ssize_t more = read(fd, buf.data() + old + filled, want - filled);
+                if (more <= 0) break;
+                filled += (size_t)more;
+            }
+            buf.resize(old + filled);
             if (got == 0) eof = true;
             have = buf.size() / bps;
         }

@@ -2,6 +2,7 @@
 // `wenet_ldpc` (WENET_FRAMING=2) executables (src/drs232_ldpc.c:105-285, src/wenet_ldpc.c): same argv,
 // float32 symbols in, CRC-valid 256-byte packets out with a flush after each, same stderr lines.
 #include <errno.h>
+#include <poll.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -50,7 +51,9 @@ int main(int argc, char *argv[]) {
     wenet_deframer *d = wenet_deframer_create(WENET_FRAMING, 10 /* MAX_ITER, src/H2064_516_sparse.h:15 */);
     if (!d) { fprintf(stderr, "wenet_rx: no GPU available\n"); exit(1); }
 
-    const size_t block = (fin == stdin) ? 4096 : (1u << 20);                 /* symbols per read */
+    // One GPU call per block.  A pipe is drained: the first read blocks (live streams keep their latency), then
+    // whatever else is already waiting is taken along, so that a fast upstream (a file through cat) gives big blocks.
+    const size_t block = (1u << 20);                                         /* symbols per block, at most */
     std::vector<float> buf(block);
     std::vector<uint8_t> pk(((block / 2584) + 4) * 258);
     std::vector<wenet_packet_info> info((block / 2584) + 4);
@@ -60,7 +63,14 @@ int main(int argc, char *argv[]) {
         ssize_t got = read(fd, (char *)buf.data() + partial, block * sizeof(float) - partial);
         if (got < 0) { if (errno == EINTR) continue; break; }
         if (got == 0) break;
-        const size_t bytes = partial + (size_t)got;
+        size_t bytes = partial + (size_t)got;
+        while (bytes < block * sizeof(float)) {                              /* drain what is already there */
+            struct pollfd pf = {fd, POLLIN, 0};
+            if (poll(&pf, 1, 0) <= 0 || !(pf.revents & POLLIN)) break;
+            ssize_t more = read(fd, (char *)buf.data() + bytes, block * sizeof(float) - bytes);
+            if (more <= 0) break;
+            bytes += (size_t)more;
+        }
         const size_t nsym = bytes / sizeof(float);
         long n = wenet_deframer_push(d, buf.data(), (long)nsym, pk.data(), info.data(), (long)info.size());
         if (n < 0) { fprintf(stderr, "wenet_rx: GPU decode failed (%ld)\n", n); exit(1); }

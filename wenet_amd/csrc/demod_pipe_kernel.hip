@@ -554,11 +554,21 @@ __global__ __launch_bounds__(WP_THREADS, RAW ? 6 : 5) void wenet_demod_pipe_kern
                 }
             }
             if (cfg.stats) {
-                if (lane < WR_NSYM) { SC[lane] = mymax; SC[WR_NSYM + lane] = sqrtf(mymax); }
+                if (lane < WR_NSYM) ((float2 *)SC)[lane] = make_float2(mymax, sqrtf(mymax));
                 wave_sync();
                 if (lane == 0) {
-                    float stdebno = 0.f, meanebno = 0.f;
-                    for (int i = 0; i < WR_NSYM; i++) { stdebno += SC[i]; meanebno += SC[WR_NSYM + i]; }
+                    // the two running sums of fsk.c:998-1004 are independent chains: one packed add per symbol, loads up front
+                    v2f acc = {0.f, 0.f};
+                    const v2f *sc2 = (const v2f *)SC;
+#pragma unroll
+                    for (int i0 = 0; i0 < WR_NSYM; i0 += 16) {
+                        v2f w[16];
+#pragma unroll
+                        for (int u = 0; u < 16; u++) w[u] = sc2[i0 + u];
+#pragma unroll
+                        for (int u = 0; u < 16; u++) acc = acc + w[u];
+                    }
+                    float stdebno = acc.x, meanebno = acc.y;
                     meanebno = meanebno / cfg.nsym_f;
                     stdebno = (stdebno / cfg.nsym_f) - (meanebno * meanebno);
                     if ((double)stdebno > 0.0) stdebno = (float)sqrt((double)stdebno); else stdebno = 0.0f;
