@@ -290,7 +290,11 @@ __global__ __launch_bounds__(WP_THREADS, RAW ? 6 : 5) void wenet_demod_pipe_kern
         float2 *FI = FIb + (j & 1) * M * NI;
         float2 *TP = TPb + (j & 1) * NI;
         const long long src0 = off_j - nold;                             // chain step s <-> absolute sample src0 + s
-        {
+        const bool fastI = (q == 1 && (Ts == 10 || Ts == 8) && NI % Ts == 0);                // fast integrator path
+        const int padTs = (fastI && Ts == 8) ? 8 : 0;                                          // ... with padded rows (Ts = 8 only: at Ts = 10
+                                                                                               // the conflicts are mild and the padding arithmetic costs more)
+        auto mix = [&](auto PADC) {
+            constexpr int PADTS = decltype(PADC)::value;             // 0: rows unpadded; 8: one pad element after every 8 samples
             // one D thread per (tone, checkpoint): replay the <= WP_CK chain steps that follow the checkpoint
             // (the same cmul_pk sequence the chain wave ran) and mix each sample with its conjugate phasor
             const int nA = (nold + WP_CK - 1) / WP_CK, nB = (L - nold + WP_CK - 1) / WP_CK;
@@ -305,7 +309,10 @@ __global__ __launch_bounds__(WP_THREADS, RAW ? 6 : 5) void wenet_demod_pipe_kern
                 const float2 dd = CKD[((j & 1) * 2 + (segB ? 1 : 0)) * M + m];
                 const v2f d = {dd.x, dd.y};
                 v2f phi = ((const v2f *)(CKb + (((j & 1) * 2 + (segB ? 1 : 0)) * M + m) * WP_CKROW))[cc];
-                float2 *row = PH + m * Lpad + s0;
+                // In the fast integrator layout one element of padding follows every Ts samples (sample s sits at s + s/Ts):
+                // lane strides of 8 and Ts elements would hit only 2..16 of the 32 LDS banks, 9 and Ts+1 hit all of them.
+                const int pq0 = PADTS ? s0 / (PADTS ? PADTS : 1) : 0, pr0 = s0 - pq0 * PADTS;
+                float2 *row = PH + m * Lpad + s0 + pq0;
                 float2 *dump = PH + M * Lpad;                            // steps past the end of a segment land here (no branches)
                 const int rbase = RIDX(src0 + s0);
                 float2 x[WP_CK];
@@ -313,14 +320,15 @@ __global__ __launch_bounds__(WP_THREADS, RAW ? 6 : 5) void wenet_demod_pipe_kern
                 for (int u = 0; u < WP_CK; u++) x[u] = ring_get((rbase + (u < cnt ? u : 0)) & rmask);
 #pragma unroll
                 for (int u = 0; u < WP_CK; u++) {
-                    float2 *dst = (u < cnt) ? row + u : dump;
+                    float2 *dst = (u < cnt) ? row + u + ((PADTS && pr0 + u >= PADTS) ? 1 : 0) : dump;      // (WP_CK <= Ts: at most one pad crossed)
                     *dst = cmul(x[u], make_float2(phi.x, -phi.y));
                     phi = cmul_pk(phi, d);
                 }
             }
-        }
+                };
+        if (padTs) mix(std::integral_constant<int, 8>()); else mix(std::integral_constant<int, 0>());
         dsp_barrier(&CT[CT_CNT], WP_DSP_WAVES * (++dsp_phase), lane);
-        if (q == 1 && (Ts == 10 || Ts == 8) && NI % Ts == 0) {
+        if (fastI) {
             // Fast path (one sample per integrator step).  The Ts circular-buffer slots are summed in SLOT order
             // (fsk.c:829-840), i.e. the window row[i .. i+Ts) rotated by o = (-i) mod Ts.  Each D wave takes whole
             // residue classes i mod Ts, so o is wave-uniform and the rotation is resolved at compile time (no index
@@ -333,10 +341,12 @@ __global__ __launch_bounds__(WP_THREADS, RAW ? 6 : 5) void wenet_demod_pipe_kern
                     float ft1 = 0.f;
 #pragma unroll
                     for (int m = 0; m < M; m++) {
-                        const v2f *row = (const v2f *)PH + m * Lpad + i;
+                        constexpr int R = (TS - O) % TS;                    // this residue class (wave-uniform, == r)
+                        constexpr bool PAD = (TS == 8);                     // rows padded by one element per TS samples (see the mix stage)
+                        const v2f *row = (const v2f *)PH + m * Lpad + (PAD ? j * (TS + 1) + R : i);
                         v2f v[TS];
 #pragma unroll
-                        for (int u = 0; u < TS; u++) v[u] = row[u];
+                        for (int u = 0; u < TS; u++) v[u] = row[u + ((PAD && R + u >= TS) ? 1 : 0)];
                         v2f acc = {0.f, 0.f};
 #pragma unroll
                         for (int u = 0; u < TS; u++) acc = acc + v[(O + u) % TS];

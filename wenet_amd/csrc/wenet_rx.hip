@@ -157,7 +157,7 @@ struct DemodTables {
         cfg.q = cfg.Ts / P;
         cfg.L = cfg.Nmem - cfg.q;
         cfg.NI = (nsyms + 1) * P;
-        cfg.Lpad = cfg.L + (cfg.L & 1);
+        cfg.Lpad = (cfg.L + cfg.L / 8 + 3) & ~1;                          // room for one pad element per Ts >= 8 samples (pipelined kernel, fast integrator)
         cfg.P_f = (float)P;
         cfg.nsym_f = (float)nsyms;
         cfg.tc = (float)(0.95 * Ndft / Fs);                             // fsk.c:573
