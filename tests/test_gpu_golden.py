@@ -15,6 +15,17 @@ from wenet_amd.rx import RxBatch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["float-ring", "raw-ring"])
+def ring_variant(request, monkeypatch):
+    """Every golden case runs through both sample-ring variants of the pipelined demodulator: the float ring (what a
+    small batch gets) and the raw cu8 ring (what a batch of more than two captures per CU gets; forced here)."""
+    if request.param == "raw-ring":
+        monkeypatch.setenv("WENET_RX_FORCE_RAW", "1")
+    else:
+        monkeypatch.delenv("WENET_RX_FORCE_RAW", raising=False)
+    return request.param
+
+
 def test_reference_kat_through_run_ldpc_decoder():
     kat = load_golden("ldpc_kat")
     it, bits, pcc = run_ldpc_decoder(make_ldpc_struct(10), kat["llr"], -7)

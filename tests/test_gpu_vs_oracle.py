@@ -69,10 +69,11 @@ def test_streaming_chunks_equal_one_shot():
     f.close()
 
 
-def test_streaming_with_changing_input_format():
+def test_streaming_with_changing_input_format(monkeypatch):
     """One stream handle fed the same signal alternately as cu8 and as the exactly equivalent cf32 / cs16-free
     floats: the cu8 launches use the raw-byte sample ring (three captures per CU), the others the float ring, and
     the carried samp_old[] crosses from one to the other.  The result must equal the oracle's on the cu8 stream."""
+    monkeypatch.setenv("WENET_RX_FORCE_RAW", "1")
     cfg = siggen.config_v2()
     raw, _ = siggen.make_capture(cfg, 4, 9.0, seed=41, ppm=220.0)
     ref, _ = ol.oracle_demod(raw, "cu8", cfg.Fs, cfg.Rs, cfg.M)
@@ -295,6 +296,8 @@ def test_configuration_matrix(M, Ts, P, fmt, nopipe, monkeypatch):
     import dataclasses
     if nopipe:
         monkeypatch.setenv("WENET_RX_NO_PIPE", "1")
+    if fmt == "cu8" and (Ts + P) % 3 != 0:                                   # some of the cu8 cases through the raw-byte ring
+        monkeypatch.setenv("WENET_RX_FORCE_RAW", "1")
     Rs = 48000
     cfg = dataclasses.replace(siggen.config_v1(), name="m", M=M, Fs=Rs * Ts, Rs=Rs, f_low=Rs * 1.0, f_space=float(Rs))
     raw, _ = siggen.make_capture(cfg, 2 if M == 2 else 3, 11.0, seed=100 * M + Ts + P, fmt=fmt, ppm=120.0)
@@ -317,6 +320,7 @@ def test_both_timing_sum_variants(split, monkeypatch):
     """The batch chain picks the lane-split timing sum when there are more captures than CUs and the packed one
     otherwise; both are forced here on a small batch (slips, low SNR and a NaN-free silent capture included)."""
     monkeypatch.setenv("WENET_RX_TSUM_SPLIT", split)
+    monkeypatch.setenv("WENET_RX_FORCE_RAW", "1")                             # what a large batch runs: raw ring + split sum
     caps, cfgs = [], []
     for name, eb, ppm, seed in (("v2", 8.0, 0.0, 1), ("v2", 5.0, 300.0, 2), ("v2", 14.0, -2500.0, 3)):
         cfg = siggen.CONFIGS[name]()
