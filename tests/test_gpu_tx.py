@@ -221,3 +221,28 @@ def test_packet_type_census_is_counted_on_the_gpu():
         assert rx.census(c) == want
     assert sum(rx.census(0)) >= len(types) - 2 and rx.census(0)[5] >= 4 and sum(rx.census(1)) == 0      # 4 dB: nothing valid
     rx.close()
+
+
+def test_error_paths_return_codes():
+    """Illegal arguments give error codes / NULL, never a crash (the reference asserts or segfaults in the same places)."""
+    import ctypes as C
+    from wenet_amd import lib
+    L = lib.load()
+    assert not L.wenet_tx_create(960000, 96000, 3, 2, 1e5, 1e5)              # M
+    assert not L.wenet_tx_create(921600, 96000, 2, 2, 1e5, 1e5)              # Fs % Rs (src/fsk.c:143)
+    assert not L.wenet_tx_create(960000, 96000, 2, 3, 1e5, 1e5)              # framing
+    cfg = siggen.config_v2()
+    tx = Tx.from_config(cfg)
+    assert L.wenet_tx_frame_packets(tx._h, None, 4, None, 0, None) < 0
+    assert L.wenet_tx_frame_packets(tx._h, None, 0, None, 0, None) == 0
+    assert L.wenet_tx_modulate(tx._h, 1, None, None, None, None, None, 7, None, None) < 0      # format
+    tx.close()
+    rx = RxBatch(cfg.Fs, cfg.Rs, cfg.M, framing=cfg.mode)
+    c8 = (C.c_longlong * 8)()
+    assert L.wenet_rx_packet_census(rx._h, 0, c8) < 0                        # nothing processed yet
+    assert L.wenet_rx_process(rx._h, 0, None, None, 2, 0, None) < 0
+    assert L.wenet_rx_collect(rx._h) < 0                                     # nothing pending
+    assert rx.frames(0) < 0 and rx.npackets(0) < 0
+    rx.process([np.zeros(0, np.uint8)], "cu8")                               # one empty capture is legal
+    assert rx.frames(0) == 0 and rx.npackets(0) == 0 and rx.census(0) == [0] * 8
+    rx.close()
