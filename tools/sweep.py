@@ -39,13 +39,30 @@ t0 = time.perf_counter(); rx.enqueue_device(ptrs, ns, "cu8"); rx.collect(); dt =
 sent = nsym // cfg.symbols_per_frame
 print(f"# {a.config}: {a.n} captures x {a.seconds:g} s, Eb/N0 {a.lo}..{a.hi} dB, {sent} packets sent per capture")
 print(f"# batch: {a.n * nsamp / dt / 1e6:.0f} Msamples/s ({dt * 1e3:.1f} ms; demod {rx.last_ms(0):.1f} ms, decode {rx.last_ms(2):.1f} ms)")
-print("| Eb/N0 dB | packets found | CRC-valid | bytes decoded | PER | mean iter | all valid payloads were sent |")
-print("|---|---|---|---|---|---|---|")
+sym_h = sym.cpu().numpy().reshape(a.n, nfr * spp)[:, :nsym]
+print("| Eb/N0 dB | packets found | CRC-valid | bytes decoded | PER | mean iter | BER before FEC | BER after FEC (found packets) | all valid payloads were sent |")
+print("|---|---|---|---|---|---|---|---|---|")
+spf = cfg.symbols_per_frame
+body0 = (16 + 4) * (10 if cfg.mode == 1 else 8)                  # symbols of preamble + unique word ahead of the packet body
 for c, eb in enumerate(ebs):
     p = rx.packets(c)
     ok = [bytes(p["bytes"][i][:256]) for i in range(p["n"]) if p["crc_ok"][i]]
     sset = set(pls[c])
-    print(f"| {eb:5.2f} | {p['n']} | {len(ok)} | {256 * len(ok)} | {1 - len(ok) / max(sent, 1):.3f} | {p['iter'].mean() if p['n'] else 0:.2f} | {all(x in sset for x in ok)} |")
+    # per packet found (CRC-valid or not), against the frame that was sent at that position: channel bit errors in the
+    # collected symbols (before FEC) and payload bit errors in the decoded bytes (after FEC)
+    hard = (rx.soft(c) < 0).astype(np.uint8)
+    nsymb = 323 * (10 if cfg.mode == 1 else 8)
+    nbit = nerr = npre = epre = 0
+    for i in range(p["n"]):
+        st = int(p["start"][i])
+        k = int(round((st - body0) / spf))
+        if not (0 <= k < len(pls[c])) or (k * spf + body0 + nsymb) > nsym or st + nsymb > hard.size or cfg.M != 2:
+            continue
+        epre += int((hard[st:st + nsymb] != sym_h[c][k * spf + body0:k * spf + body0 + nsymb]).sum()); npre += nsymb
+        nerr += int(np.unpackbits(np.frombuffer(pls[c][k], np.uint8) ^ p["bytes"][i][:256]).sum()); nbit += 2048
+    ber_pre = epre / npre if npre else float("nan")
+    print(f"| {eb:5.2f} | {p['n']} | {len(ok)} | {256 * len(ok)} | {1 - len(ok) / max(sent, 1):.3f} | {p['iter'].mean() if p['n'] else 0:.2f} | "
+          f"{ber_pre:.2e} | {nerr / nbit if nbit else float('nan'):.2e} | {all(x in sset for x in ok)} |")
 refdir = os.path.join(ROOT, "oracle", "_ref")
 if a.check_cpu and os.path.exists(os.path.join(refdir, "fsk_demod")):
     l2 = os.path.join(refdir, "drs232_ldpc" if cfg.mode == 1 else "wenet_ldpc")
