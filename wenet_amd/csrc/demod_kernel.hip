@@ -82,6 +82,7 @@ __global__ __launch_bounds__(NT) void wenet_demod_kernel(WrDemodCfg cfg, const W
     float norm_rx_timing_st = hdr->norm_rx_timing;
     float ppm = hdr->ppm;
     int nin = __builtin_amdgcn_readfirstlane(hdr->nin);
+    if (tid == 0) { ((int *)SC)[126] = 0; ((int *)SC)[127] = 0; ((int *)SC)[128] = 0; ((int *)SC)[129] = 0; }      // progress counters of the streamed frame body
     __syncthreads();
 
     long long prof[WR_PROF_PHASES];
@@ -231,175 +232,388 @@ __global__ __launch_bounds__(NT) void wenet_demod_kernel(WrDemodCfg cfg, const W
             for (int m = 0; m < M; m++) fbin_prev[m] = fbin[m];
         }
 
-        PROF_MARK(2);
-        // ---- NCO phasor chain, lanes 0..M-1 (fsk.c:756-764, 781-798, 807-824) ---------------
-        if (tid < M) {
-            // lanes 0..M-1 of wavefront 0 carry one tone each.  Trip counts are wave-uniform (scalar loop control).
-            int bp = fbin_prev[0], bc = fbin[0];
-#pragma unroll
-            for (int m = 1; m < M; m++) if (lane == m) { bp = fbin_prev[m]; bc = fbin[m]; }
-            const int ncase = (nin < N) ? 0 : ((nin > N) ? 2 : 1);
-            const float2 bo = cfg.backoff_tab[ncase * NH + bp];
-            v2f phi = cmul_pk((v2f){bo.x, bo.y}, (v2f){phi_c.x, phi_c.y});   // back the phase off (fsk.c:758-759)
-            float2 dd = dphi_t[bp];                                          // step with the PREVIOUS estimate
-            v2f d = {dd.x, dd.y};
-            // Only every 8th phasor is stored (a store per step doubles the cost of the dependent chain); the
-            // down-conversion threads replay the steps in between with the same instruction sequence.
-            const int ckrow = cfg.ckrow;
-            v2f *ckA = (v2f *)(CKb + (0 * M + lane) * ckrow);
-            v2f *ckB = (v2f *)(CKb + (1 * M + lane) * ckrow);
-            CKD[0 * M + lane] = dd;
-            int s = 0, c = 0;
-            for (; s + 8 <= nold; s += 8, c++) {
-                ckA[c] = phi;
-#pragma unroll
-                for (int u = 0; u < 8; u++) phi = cmul_pk(phi, d);
-            }
-            if (s < nold) { ckA[c] = phi; for (; s < nold; s++) phi = cmul_pk(phi, d); }
-            {                                                              // comp_normalize, new estimate
-                const float av = sqrtf(phi.x * phi.x + phi.y * phi.y);
-                phi = (v2f){phi.x / av, phi.y / av};
-                dd = dphi_t[bc];
-                d = (v2f){dd.x, dd.y};
-            }
-            CKD[1 * M + lane] = dd;
-            c = 0;
-            for (; s + 8 <= L; s += 8, c++) {
-                ckB[c] = phi;
-#pragma unroll
-                for (int u = 0; u < 8; u++) phi = cmul_pk(phi, d);
-            }
-            if (s < L) { ckB[c] = phi; for (; s < L; s++) phi = cmul_pk(phi, d); }
-            phi_c = make_float2(phi.x, phi.y);                             // saved un-normalised (fsk.c:846)
-        }
-#pragma unroll
-        for (int m = 0; m < M; m++) fbin_prev[m] = fbin[m];                // fsk.c:847
-        lds_barrier();
-
-        PROF_MARK(3);
-        // ---- down-convert: sample * conj(phasor) (fsk.c:791,817); one thread per (tone, checkpoint) replays the
-        //      <= 8 chain steps after its checkpoint ----------------------------------------------------------------
-        {
+        float tcr = 0.f, tci = 0.f;
+        if (NT > 64 && cfg.seq_stream) {
+            // ================= streamed frame body (workgroups of eight waves) ===================================
+            // The NCO chain is one dependent recurrence on wave 0 (24 cycles per sample); everything downstream of it
+            // is consumed as it is produced instead of after it: the chain publishes how many samples have their
+            // checkpoint stored, waves 2..7 mix + integrate + form the timing products block by block behind it, and
+            // wave 1 adds the products in order as they appear.  Same arithmetic, same order; the frame costs about
+            // estimator + chain instead of the sum of all stages.
+            volatile int *ctl = (volatile int *)SC + 126;                  // [0] samples mixable, [1] timing products ready, [2] barrier count, [3] samples mixed
+            const bool stamp = (C.prof != nullptr) && frames == 50;            // development: cycle stamps of one frame (WENET_RX_PROFILE=3)
+            if (stamp && tid == 0) C.prof[0] = (long long)__builtin_readcyclecounter();
+            float2 *TP = (float2 *)(smem + cfg.off_TP);
             const float2 *src = X + (nstash - nold);                       // fsk.c:775: old tail then new block, contiguous
-            const int nA = (nold + 7) / 8, nB = (L - nold + 7) / 8;
-            const int per_tone = nA + nB;
-            for (int w = tid; w < M * per_tone; w += NT) {
-                const int m = w / per_tone, c = w - m * per_tone;
-                const bool segB = c >= nA;
-                const int cc = segB ? c - nA : c;
-                const int s0 = segB ? nold + cc * 8 : cc * 8;
-                const int send = segB ? L : nold;
-                const int cnt = (send - s0) < 8 ? (send - s0) : 8;
-                const float2 dd = CKD[(segB ? 1 : 0) * M + m];
-                const v2f d = {dd.x, dd.y};
-                v2f phi = ((const v2f *)(CKb + ((segB ? 1 : 0) * M + m) * cfg.ckrow))[cc];
-                float2 *row = PH + m * Lpad + s0;
-                for (int u = 0; u < cnt; u++) {
-                    row[u] = cmul(src[s0 + u], make_float2(phi.x, -phi.y));
-                    phi = cmul_pk(phi, d);
+            const int nA = (nold + 7) / 8;
+            if (wave == 0) {
+                __builtin_amdgcn_s_setprio(3);                                     // the chain is the frame's critical path
+                if (tid < M) {
+                    int bp = fbin_prev[0], bc = fbin[0];
+#pragma unroll
+                    for (int m = 1; m < M; m++) if (lane == m) { bp = fbin_prev[m]; bc = fbin[m]; }
+                    const int ncase = (nin < N) ? 0 : ((nin > N) ? 2 : 1);
+                    const float2 bo = cfg.backoff_tab[ncase * NH + bp];
+                    v2f phi = cmul_pk((v2f){bo.x, bo.y}, (v2f){phi_c.x, phi_c.y});   // back the phase off (fsk.c:758-759)
+                    float2 dd = dphi_t[bp];                                          // step with the PREVIOUS estimate
+                    v2f d = {dd.x, dd.y};
+                    const int ckrow = cfg.ckrow;
+                    v2f *ckA = (v2f *)(CKb + (0 * M + lane) * ckrow);
+                    v2f *ckB = (v2f *)(CKb + (1 * M + lane) * ckrow);
+                    CKD[0 * M + lane] = dd;
+                    int s = 0, c = 0;
+                    for (; s + 8 <= nold; s += 8, c++) {
+                        ckA[c] = phi;
+#pragma unroll
+                        for (int u = 0; u < 8; u++) phi = cmul_pk(phi, d);
+                    }
+                    if (s < nold) { ckA[c] = phi; for (; s < nold; s++) phi = cmul_pk(phi, d); }
+                    {                                                              // comp_normalize, new estimate
+                        const float av = sqrtf(phi.x * phi.x + phi.y * phi.y);
+                        phi = (v2f){phi.x / av, phi.y / av};
+                        dd = dphi_t[bc];
+                        d = (v2f){dd.x, dd.y};
+                    }
+                    CKD[1 * M + lane] = dd;
+                    asm volatile("" ::: "memory");
+                    ctl[0] = nold;                                                 // (LDS executes a wave's stores in order)
+                    c = 0;
+                    for (; s + 32 <= L; s += 32, c += 4) {                         // four checkpoints per trip, then publish
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            ckB[c + k] = phi;
+#pragma unroll
+                            for (int u = 0; u < 8; u++) phi = cmul_pk(phi, d);
+                        }
+                        asm volatile("" ::: "memory");
+                        ctl[0] = s + 32;
+                    }
+                    for (; s + 8 <= L; s += 8, c++) {
+                        ckB[c] = phi;
+#pragma unroll
+                        for (int u = 0; u < 8; u++) phi = cmul_pk(phi, d);
+                    }
+                    if (s < L) { ckB[c] = phi; for (; s < L; s++) phi = cmul_pk(phi, d); }
+                    asm volatile("" ::: "memory");
+                    ctl[0] = L;
+                    phi_c = make_float2(phi.x, phi.y);                             // saved un-normalised (fsk.c:846)
+                }
+                __builtin_amdgcn_s_setprio(0);
+                if (stamp && tid == 0) C.prof[1] = (long long)__builtin_readcyclecounter();
+            } else if (wave == 1) {
+                __builtin_amdgcn_s_setprio(2);
+                // ordered sum of the timing products (fsk.c:870) as far as they are published
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                v2f acc = {0.f, 0.f};
+                int i = 0;
+                while (i < NI) {
+                    int ready;
+                    while ((ready = ctl[1]) <= i) __builtin_amdgcn_s_sleep(8);
+                    for (; i + 16 <= ready; i += 16) {                             // 16 products per round: loads up front
+                        const v4f *p4 = (const v4f *)(TP + i);
+                        v4f w[8];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) w[u] = p4[u];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) { acc = acc + w[u].xy; acc = acc + w[u].zw; }
+                    }
+                    if (ready >= NI) for (; i < NI; i++) { const float2 v = TP[i]; acc = acc + (v2f){v.x, v.y}; }
+                }
+                if (lane == 0) { SC[124] = acc.x; SC[125] = acc.y; }
+                __builtin_amdgcn_s_setprio(0);
+                if (stamp && lane == 0) C.prof[2] = (long long)__builtin_readcyclecounter();
+            } else if (wave == 2) {
+                // mixer: follows the chain, one lane per (checkpoint, tone), replaying the <= 8 chain steps after the checkpoint
+                // (fsk.c:791,817); items are ordered checkpoint-major so that after every pass all tones are complete up to a
+                // sample position, which is published for the integrators
+                const int ngt = nA + (L - nold + 7) / 8;                           // checkpoints per tone
+                int g = 0;                                                         // checkpoints finished (all tones)
+                while (g < ngt) {
+                    const int gs = g < nA ? g * 8 : nold + (g - nA) * 8;           // first sample of checkpoint g
+                    int avail;
+                    while ((avail = ctl[0]) <= gs) __builtin_amdgcn_s_sleep(4);
+                    int gend = avail >= L ? ngt : (avail >= nold ? nA + (avail - nold) / 8 : avail / 8);     // whole checkpoints the chain has passed
+                    if (gend > g + 64 / M) gend = g + 64 / M;                        // one pass: 64 items
+                    if (gend <= g) { __builtin_amdgcn_s_sleep(4); continue; }
+                    const int w = lane;
+                    if (w < (gend - g) * M) {
+                        const int gg = g + w / M, m = w - (w / M) * M;
+                        const bool segB = gg >= nA;
+                        const int cc = segB ? gg - nA : gg;
+                        const int s0 = segB ? nold + cc * 8 : cc * 8;
+                        const int send = segB ? L : nold;
+                        const int cnt = (send - s0) < 8 ? (send - s0) : 8;
+                        const float2 dd = CKD[(segB ? 1 : 0) * M + m];
+                        const v2f d = {dd.x, dd.y};
+                        v2f phi = ((const v2f *)(CKb + ((segB ? 1 : 0) * M + m) * cfg.ckrow))[cc];
+                        float2 *row = PH + m * Lpad + s0;
+                        for (int u = 0; u < cnt; u++) {
+                            row[u] = cmul(src[s0 + u], make_float2(phi.x, -phi.y));
+                            phi = cmul_pk(phi, d);
+                        }
+                    }
+                    g = gend;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    ctl[3] = (g >= ngt) ? L : (g <= nA ? (g * 8 < nold ? g * 8 : nold) : nold + (g - nA) * 8);     // samples mixed, all tones
+                }
+            } else {
+                constexpr int DW = NT / 64 - 3, DT = DW * 64;                      // integrator waves / threads
+                const int BO = (NI + (NI + DT - 1) / DT - 1) / ((NI + DT - 1) / DT);      // outputs per block: equal blocks of at most one output per thread
+                const int dt = tid - 192;
+                int phase = 0;
+                auto dbar = [&]() {                                                // barrier among the integrator waves (monotone LDS counter)
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (lane == 0) __hip_atomic_fetch_add((int *)&ctl[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    ++phase;
+                    while (__hip_atomic_load((int *)&ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < DW * phase) __builtin_amdgcn_s_sleep(3);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                };
+                for (int i0 = 0; i0 < NI; i0 += BO) {
+                    const int i1 = (i0 + BO < NI) ? i0 + BO : NI;
+                    int need = (i1 - 1) * q + Ts;                                  // samples the block's windows reach
+                    if (need > L) need = L;
+                    while (ctl[3] < need) __builtin_amdgcn_s_sleep(8);
+                    const long long t_blk = stamp ? (long long)__builtin_readcyclecounter() : 0;
+                    // integrate-and-dump of outputs [i0, i1): slot-ordered re-sum (fsk.c:829-840), one thread per output doing all
+                    // tones and the timing product right away (fsk.c:862-870)
+                    for (int i = i0 + dt; i < i1; i += DT) {
+                        const int base = i * q;
+                        const int r = base % Ts;
+                        const int o0 = (r == 0) ? 0 : Ts - r;
+                        float ft1 = 0.f;
+                        v2f acc[M];
+#pragma unroll
+                        for (int m = 0; m < M; m++) acc[m] = (v2f){0.f, 0.f};
+                        if ((Ts & (Ts - 1)) == 0 && Ts >= 8) {                         // power-of-two Ts: the slot wrap is a mask
+                            const int msk = Ts - 1;
+                            for (int j0 = 0; j0 < Ts; j0 += 8) {
+                                v2f v[M][8];
+#pragma unroll
+                                for (int u = 0; u < 8; u++) {
+                                    const int idx = base + ((o0 + j0 + u) & msk);
+#pragma unroll
+                                    for (int m = 0; m < M; m++) v[m][u] = ((const v2f *)PH)[m * Lpad + idx];
+                                }
+#pragma unroll
+                                for (int u = 0; u < 8; u++) {
+#pragma unroll
+                                    for (int m = 0; m < M; m++) acc[m] = acc[m] + v[m][u];
+                                }
+                            }
+                        } else {
+                        int o = o0;
+                        for (int j0 = 0; j0 < Ts; j0 += 8) {                           // 8 slots of all tones at a time: loads first, then the ordered adds
+                            v2f v[M][8];
+                            int oo = o;
+#pragma unroll
+                            for (int u = 0; u < 8; u++) {
+                                const int idx = (j0 + u < Ts) ? base + oo : base;
+#pragma unroll
+                                for (int m = 0; m < M; m++) v[m][u] = ((const v2f *)PH)[m * Lpad + idx];
+                                oo++;
+                                if (oo == Ts) oo = 0;
+                            }
+#pragma unroll
+                            for (int u = 0; u < 8; u++) {
+                                if (j0 + u < Ts) {
+#pragma unroll
+                                    for (int m = 0; m < M; m++) acc[m] = acc[m] + v[m][u];
+                                }
+                            }
+                            o = oo;
+                        }
+                        }
+#pragma unroll
+                        for (int m = 0; m < M; m++) {
+                            FI[m * NI + i] = make_float2(acc[m].x, acc[m].y);
+                            ft1 += (acc[m].x * acc[m].x) + (acc[m].y * acc[m].y);
+                        }
+                        const float2 pf = pft_t[i];
+                        TP[i] = make_float2(ft1 * pf.x, ft1 * pf.y);
+                    }
+                    dbar();
+                    if (dt == 0) ctl[1] = i1;
+                    if (stamp && dt == 0 && i0 / BO < 8) { C.prof[4 + 2 * (i0 / BO)] = t_blk; C.prof[5 + 2 * (i0 / BO)] = (long long)__builtin_readcyclecounter(); }
                 }
             }
-        }
-        lds_barrier();
+#pragma unroll
+            for (int m = 0; m < M; m++) fbin_prev[m] = fbin[m];                // fsk.c:847
+            lds_barrier();
+            for (int i = tid; i < nstash; i += NT) X[i] = X[nstash + nin - nstash + i];     // fsk.c:851
+            tcr = SC[124]; tci = SC[125];
+            if (stamp && tid == 0) C.prof[3] = (long long)__builtin_readcyclecounter();
+            if (tid == 0) { ctl[0] = 0; ctl[1] = 0; ctl[2] = 0; ctl[3] = 0; }  // for the next frame (ordered by the barriers below)
+        } else {
 
-        PROF_MARK(4);
-        // ---- integrate-and-dump: every output re-sums the Ts circular-buffer slots in slot order
-        //      (fsk.c:829-840).  Output i covers samples [i*q, i*q+Ts); sample s sits in slot s % Ts.
-        for (int i = tid; i < NI; i += NT) {
-            const int base = i * q;
-            const int r = base % Ts;
-            int o = (r == 0) ? 0 : Ts - r;                                 // window offset of slot 0
-            v2f acc[M];
-#pragma unroll
-            for (int m = 0; m < M; m++) acc[m] = (v2f){0.f, 0.f};
-            for (int j0 = 0; j0 < Ts; j0 += 8) {                           // 8 slots at a time: loads first, then the ordered adds
-                v2f v[M][8];
-                int oo = o;
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const int idx = (j0 + u < Ts) ? base + oo : base;      // padding reads a valid address, value unused
-#pragma unroll
-                    for (int m = 0; m < M; m++) v[m][u] = ((const v2f *)PH)[m * Lpad + idx];
-                    oo++;
-                    if (oo == Ts) oo = 0;
+            PROF_MARK(2);
+            // ---- NCO phasor chain, lanes 0..M-1 (fsk.c:756-764, 781-798, 807-824) ---------------
+            if (tid < M) {
+                // lanes 0..M-1 of wavefront 0 carry one tone each.  Trip counts are wave-uniform (scalar loop control).
+                int bp = fbin_prev[0], bc = fbin[0];
+    #pragma unroll
+                for (int m = 1; m < M; m++) if (lane == m) { bp = fbin_prev[m]; bc = fbin[m]; }
+                const int ncase = (nin < N) ? 0 : ((nin > N) ? 2 : 1);
+                const float2 bo = cfg.backoff_tab[ncase * NH + bp];
+                v2f phi = cmul_pk((v2f){bo.x, bo.y}, (v2f){phi_c.x, phi_c.y});   // back the phase off (fsk.c:758-759)
+                float2 dd = dphi_t[bp];                                          // step with the PREVIOUS estimate
+                v2f d = {dd.x, dd.y};
+                // Only every 8th phasor is stored (a store per step doubles the cost of the dependent chain); the
+                // down-conversion threads replay the steps in between with the same instruction sequence.
+                const int ckrow = cfg.ckrow;
+                v2f *ckA = (v2f *)(CKb + (0 * M + lane) * ckrow);
+                v2f *ckB = (v2f *)(CKb + (1 * M + lane) * ckrow);
+                CKD[0 * M + lane] = dd;
+                int s = 0, c = 0;
+                for (; s + 8 <= nold; s += 8, c++) {
+                    ckA[c] = phi;
+    #pragma unroll
+                    for (int u = 0; u < 8; u++) phi = cmul_pk(phi, d);
                 }
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    if (j0 + u < Ts) {
-#pragma unroll
-                        for (int m = 0; m < M; m++) acc[m] = acc[m] + v[m][u];
+                if (s < nold) { ckA[c] = phi; for (; s < nold; s++) phi = cmul_pk(phi, d); }
+                {                                                              // comp_normalize, new estimate
+                    const float av = sqrtf(phi.x * phi.x + phi.y * phi.y);
+                    phi = (v2f){phi.x / av, phi.y / av};
+                    dd = dphi_t[bc];
+                    d = (v2f){dd.x, dd.y};
+                }
+                CKD[1 * M + lane] = dd;
+                c = 0;
+                for (; s + 8 <= L; s += 8, c++) {
+                    ckB[c] = phi;
+    #pragma unroll
+                    for (int u = 0; u < 8; u++) phi = cmul_pk(phi, d);
+                }
+                if (s < L) { ckB[c] = phi; for (; s < L; s++) phi = cmul_pk(phi, d); }
+                phi_c = make_float2(phi.x, phi.y);                             // saved un-normalised (fsk.c:846)
+            }
+    #pragma unroll
+            for (int m = 0; m < M; m++) fbin_prev[m] = fbin[m];                // fsk.c:847
+            lds_barrier();
+
+            PROF_MARK(3);
+            // ---- down-convert: sample * conj(phasor) (fsk.c:791,817); one thread per (tone, checkpoint) replays the
+            //      <= 8 chain steps after its checkpoint ----------------------------------------------------------------
+            {
+                const float2 *src = X + (nstash - nold);                       // fsk.c:775: old tail then new block, contiguous
+                const int nA = (nold + 7) / 8, nB = (L - nold + 7) / 8;
+                const int per_tone = nA + nB;
+                for (int w = tid; w < M * per_tone; w += NT) {
+                    const int m = w / per_tone, c = w - m * per_tone;
+                    const bool segB = c >= nA;
+                    const int cc = segB ? c - nA : c;
+                    const int s0 = segB ? nold + cc * 8 : cc * 8;
+                    const int send = segB ? L : nold;
+                    const int cnt = (send - s0) < 8 ? (send - s0) : 8;
+                    const float2 dd = CKD[(segB ? 1 : 0) * M + m];
+                    const v2f d = {dd.x, dd.y};
+                    v2f phi = ((const v2f *)(CKb + ((segB ? 1 : 0) * M + m) * cfg.ckrow))[cc];
+                    float2 *row = PH + m * Lpad + s0;
+                    for (int u = 0; u < cnt; u++) {
+                        row[u] = cmul(src[s0 + u], make_float2(phi.x, -phi.y));
+                        phi = cmul_pk(phi, d);
                     }
                 }
-                o = oo;
             }
-#pragma unroll
-            for (int m = 0; m < M; m++) FI[m * NI + i] = make_float2(acc[m].x, acc[m].y);
-        }
-        lds_barrier();
-
-        PROF_MARK(5);
-        // ---- stash the tail of the new block for the next frame (fsk.c:851) ------------------
-        for (int i = tid; i < nstash; i += NT) X[i] = X[nstash + nin - nstash + i];
-
-        // ---- fine timing: sum_i (sum_m |f_int|^2) * phi_ft[i]  (fsk.c:858-874) ---------------
-        float2 *TP = PH;                                                   // down-converted samples are dead now
-        for (int i = tid; i < NI; i += NT) {
-            float ft1 = 0.f;
-#pragma unroll
-            for (int m = 0; m < M; m++) {
-                const float2 v = FI[m * NI + i];
-                ft1 += (v.x * v.x) + (v.y * v.y);
-            }
-            const float2 pf = pft_t[i];
-            TP[i] = make_float2(ft1 * pf.x, ft1 * pf.y);
-        }
-        lds_barrier();
-        PROF_MARK(6);
-        float tcr = 0.f, tci = 0.f;
-        if (NT == 64 || wave == 0) {
-            // sequential float accumulation in index order (fsk.c:870): one packed add per product
-            // (re and im sums are independent chains); every lane runs the uniform loop, lane 0's value
-            // is used.  The next 8 products are loaded (128-bit LDS reads) before the current 8 are added.
-            typedef float v4f __attribute__((ext_vector_type(4)));
-            const v4f *TP4 = (const v4f *)TP;
-            v2f acc = {0.f, 0.f};
-            v4f bufA[4], bufB[4];                                        // ping-pong: loads of one batch fly while the other is summed
-            int i = 0;
-            if (NI >= 8) {
-#pragma unroll
-                for (int u = 0; u < 4; u++) bufA[u] = TP4[u];
-                for (i = 8; i + 16 <= NI; i += 16) {
-#pragma unroll
-                    for (int u = 0; u < 4; u++) bufB[u] = TP4[(i >> 1) + u];
-#pragma unroll
-                    for (int u = 0; u < 4; u++) { acc = acc + bufA[u].xy; acc = acc + bufA[u].zw; }
-                    asm volatile("" : "+v"(acc) : : "memory");           // keep the reload of A behind its last use (no register copies)
-#pragma unroll
-                    for (int u = 0; u < 4; u++) bufA[u] = TP4[(i >> 1) + 4 + u];
-#pragma unroll
-                    for (int u = 0; u < 4; u++) { acc = acc + bufB[u].xy; acc = acc + bufB[u].zw; }
-                    asm volatile("" : "+v"(acc) : : "memory");
-                }
-                if (i + 8 <= NI) {
-#pragma unroll
-                    for (int u = 0; u < 4; u++) bufB[u] = TP4[(i >> 1) + u];
-#pragma unroll
-                    for (int u = 0; u < 4; u++) { acc = acc + bufA[u].xy; acc = acc + bufA[u].zw; }
-#pragma unroll
-                    for (int u = 0; u < 4; u++) { acc = acc + bufB[u].xy; acc = acc + bufB[u].zw; }
-                    i += 8;
-                } else {
-#pragma unroll
-                    for (int u = 0; u < 4; u++) { acc = acc + bufA[u].xy; acc = acc + bufA[u].zw; }
-                }
-            }
-            for (; i < NI; i++) { const float2 v = TP[i]; acc = acc + (v2f){v.x, v.y}; }
-            tcr = acc.x; tci = acc.y;
-        }
-        if (NT > 64) {                                                     // wavefront 0's sums to everyone
-            if (tid == 0) { SC[124] = tcr; SC[125] = tci; }
             lds_barrier();
-            tcr = SC[124]; tci = SC[125];
+
+            PROF_MARK(4);
+            // ---- integrate-and-dump: every output re-sums the Ts circular-buffer slots in slot order
+            //      (fsk.c:829-840).  Output i covers samples [i*q, i*q+Ts); sample s sits in slot s % Ts.
+            for (int i = tid; i < NI; i += NT) {
+                const int base = i * q;
+                const int r = base % Ts;
+                int o = (r == 0) ? 0 : Ts - r;                                 // window offset of slot 0
+                v2f acc[M];
+    #pragma unroll
+                for (int m = 0; m < M; m++) acc[m] = (v2f){0.f, 0.f};
+                for (int j0 = 0; j0 < Ts; j0 += 8) {                           // 8 slots at a time: loads first, then the ordered adds
+                    v2f v[M][8];
+                    int oo = o;
+    #pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const int idx = (j0 + u < Ts) ? base + oo : base;      // padding reads a valid address, value unused
+    #pragma unroll
+                        for (int m = 0; m < M; m++) v[m][u] = ((const v2f *)PH)[m * Lpad + idx];
+                        oo++;
+                        if (oo == Ts) oo = 0;
+                    }
+    #pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        if (j0 + u < Ts) {
+    #pragma unroll
+                            for (int m = 0; m < M; m++) acc[m] = acc[m] + v[m][u];
+                        }
+                    }
+                    o = oo;
+                }
+    #pragma unroll
+                for (int m = 0; m < M; m++) FI[m * NI + i] = make_float2(acc[m].x, acc[m].y);
+            }
+            lds_barrier();
+
+            PROF_MARK(5);
+            // ---- stash the tail of the new block for the next frame (fsk.c:851) ------------------
+            for (int i = tid; i < nstash; i += NT) X[i] = X[nstash + nin - nstash + i];
+
+            // ---- fine timing: sum_i (sum_m |f_int|^2) * phi_ft[i]  (fsk.c:858-874) ---------------
+            float2 *TP = PH;                                                   // down-converted samples are dead now
+            for (int i = tid; i < NI; i += NT) {
+                float ft1 = 0.f;
+    #pragma unroll
+                for (int m = 0; m < M; m++) {
+                    const float2 v = FI[m * NI + i];
+                    ft1 += (v.x * v.x) + (v.y * v.y);
+                }
+                const float2 pf = pft_t[i];
+                TP[i] = make_float2(ft1 * pf.x, ft1 * pf.y);
+            }
+            lds_barrier();
+            PROF_MARK(6);
+            if (NT == 64 || wave == 0) {
+                // sequential float accumulation in index order (fsk.c:870): one packed add per product
+                // (re and im sums are independent chains); every lane runs the uniform loop, lane 0's value
+                // is used.  The next 8 products are loaded (128-bit LDS reads) before the current 8 are added.
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                const v4f *TP4 = (const v4f *)TP;
+                v2f acc = {0.f, 0.f};
+                v4f bufA[4], bufB[4];                                        // ping-pong: loads of one batch fly while the other is summed
+                int i = 0;
+                if (NI >= 8) {
+    #pragma unroll
+                    for (int u = 0; u < 4; u++) bufA[u] = TP4[u];
+                    for (i = 8; i + 16 <= NI; i += 16) {
+    #pragma unroll
+                        for (int u = 0; u < 4; u++) bufB[u] = TP4[(i >> 1) + u];
+    #pragma unroll
+                        for (int u = 0; u < 4; u++) { acc = acc + bufA[u].xy; acc = acc + bufA[u].zw; }
+                        asm volatile("" : "+v"(acc) : : "memory");           // keep the reload of A behind its last use (no register copies)
+    #pragma unroll
+                        for (int u = 0; u < 4; u++) bufA[u] = TP4[(i >> 1) + 4 + u];
+    #pragma unroll
+                        for (int u = 0; u < 4; u++) { acc = acc + bufB[u].xy; acc = acc + bufB[u].zw; }
+                        asm volatile("" : "+v"(acc) : : "memory");
+                    }
+                    if (i + 8 <= NI) {
+    #pragma unroll
+                        for (int u = 0; u < 4; u++) bufB[u] = TP4[(i >> 1) + u];
+    #pragma unroll
+                        for (int u = 0; u < 4; u++) { acc = acc + bufA[u].xy; acc = acc + bufA[u].zw; }
+    #pragma unroll
+                        for (int u = 0; u < 4; u++) { acc = acc + bufB[u].xy; acc = acc + bufB[u].zw; }
+                        i += 8;
+                    } else {
+    #pragma unroll
+                        for (int u = 0; u < 4; u++) { acc = acc + bufA[u].xy; acc = acc + bufA[u].zw; }
+                    }
+                }
+                for (; i < NI; i++) { const float2 v = TP[i]; acc = acc + (v2f){v.x, v.y}; }
+                tcr = acc.x; tci = acc.y;
+            }
+            if (NT > 64) {                                                     // wavefront 0's sums to everyone
+                if (tid == 0) { SC[124] = tcr; SC[125] = tci; }
+                lds_barrier();
+                tcr = SC[124]; tci = SC[125];
+            }
         }
         tcr = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(tcr)));   // lane 0's sums, as wave-uniform values
         tci = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(tci)));

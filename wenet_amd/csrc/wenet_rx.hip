@@ -236,6 +236,12 @@ struct DemodTables {
         cfg.ckrow = cfg.L / 8 + 2;
         cfg.off_CK = o; o = align16(o + 2 * M * cfg.ckrow * 8);
         cfg.off_CKD = o; o = align16(o + 2 * M * 8);
+        cfg.off_TP = o; o = align16(o + cfg.NI * 8);
+        cfg.seq_stream = getenv("WENET_RX_NO_STREAM") ? 0 : 1;
+        cfg.off_TP = o; o = align16(o + cfg.NI * 8);
+        cfg.seq_stream = getenv("WENET_RX_NO_STREAM") ? 0 : 1;
+        cfg.off_TP = o; o = align16(o + cfg.NI * 8);
+        cfg.seq_stream = getenv("WENET_RX_NO_STREAM") ? 0 : (getenv("WENET_RX_SEQ_WIDE") ? 2 : 1);
         {   // LDS copies of the configuration tables when they fit next to the working set
             int t = o;
             const int o_tw = t;   t = align16(t + Ndft * 8);
@@ -898,7 +904,9 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const lon
     WrDemodCfg launch_cfg = want_raw ? rx->tab.raw_cfg() : rx->tab.cfg;
     // more captures than CUs: SIMD time matters more than the latency of one frame (see tstage in demod_pipe_kernel.hip)
     launch_cfg.p_tsum_split = getenv("WENET_RX_TSUM_SPLIT") ? atoi(getenv("WENET_RX_TSUM_SPLIT")) : ((nchan > wenet_rx_device_info(1)) ? 1 : 0);
-    const int prof = rx->profile ? (getenv("WENET_RX_PROFILE")[0] == '2' ? 2 : 1) : 0;
+    // WENET_RX_PROFILE: 1 = instrumented pipelined kernel, 2 = instrumented one-wave sequential kernel, 3 = production
+    // kernels with the per-channel stamp buffer attached (streamed sequential kernel: cycle stamps of one frame)
+    const int prof = rx->profile ? (getenv("WENET_RX_PROFILE")[0] == '2' ? 2 : (getenv("WENET_RX_PROFILE")[0] == '3' ? 0 : 1)) : 0;
     // host-fed: a first sub-batch of one capture per CU gets the kernels going early, then three per CU (= one full round of
     // the demod kernel) per sub-batch; device-resident input: everything in one go
     const int ncu = wenet_rx_device_info(1) > 0 ? wenet_rx_device_info(1) : 256;
