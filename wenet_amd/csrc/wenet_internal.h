@@ -48,8 +48,6 @@ struct WrDemodCfg {
     // LDS carve-up (bytes)
     int off_X, off_FB, off_PH, off_FI, off_FE, off_FW, off_SD, off_SC, lds_bytes;
     int off_TP, seq_stream;              // sequential kernel: separate timing-product row and the streamed frame body (8 waves)
-    int off_TP, seq_stream;              // sequential kernel: separate timing-product row and the streamed frame body (8 waves)
-    int off_TP, seq_stream;              // sequential kernel: separate timing-product row and the streamed frame body (8 waves)
     int off_CK, off_CKD, ckrow;          // sequential kernel: phasor checkpoints [2 segments][M][ckrow], NCO steps [2][M]
     int tables_in_lds, off_TW, off_HANN, off_SRC, off_PFT, off_DPHI;
     // LDS carve-up of the pipelined kernel (demod_pipe_kernel.hip); pipe_ok = configuration fits

@@ -238,10 +238,6 @@ struct DemodTables {
         cfg.off_CKD = o; o = align16(o + 2 * M * 8);
         cfg.off_TP = o; o = align16(o + cfg.NI * 8);
         cfg.seq_stream = getenv("WENET_RX_NO_STREAM") ? 0 : 1;
-        cfg.off_TP = o; o = align16(o + cfg.NI * 8);
-        cfg.seq_stream = getenv("WENET_RX_NO_STREAM") ? 0 : 1;
-        cfg.off_TP = o; o = align16(o + cfg.NI * 8);
-        cfg.seq_stream = getenv("WENET_RX_NO_STREAM") ? 0 : (getenv("WENET_RX_SEQ_WIDE") ? 2 : 1);
         {   // LDS copies of the configuration tables when they fit next to the working set
             int t = o;
             const int o_tw = t;   t = align16(t + Ndft * 8);
