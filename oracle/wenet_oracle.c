@@ -168,14 +168,19 @@ struct ora_fsk {
     ora_comp *fftin, *fftout, *f_intbuf, *f_int[ORA_M_MAX];
 };
 
-ora_fsk *ora_fsk_create_hbr(int Fs, int Rs, int P, int M) {       /* fsk.c:128-259 */
+/* Both constructors: lbr == 0 is fsk_create_hbr (fsk.c:128-259), lbr != 0 is fsk_create (fsk.c:278-398), which differs in
+ * the frame length (one second, N = Fs), the oversampling (horus_P = 8, fsk.c:35), a fixed 1024-point estimator and the
+ * estimator band (HORUS_MIN/MAX/MIN_SPACING, fsk.c:262-264). */
+static ora_fsk *ora_fsk_new(int Fs, int Rs, int P, int M, int lbr) {
     ora_fsk *f;
     int i, m, Ndft = 0;
-    const int nsyms = 48;                                            /* fsk.c:135 */
-    if (Fs <= 0 || Rs <= 0 || P <= 0) return NULL;                   /* asserts fsk.c:137-141 */
-    if (Fs % Rs != 0) return NULL;                                   /* fsk.c:143 */
-    if ((Fs / Rs) % P != 0) return NULL;                             /* fsk.c:145 */
-    if (M != 2 && M != 4) return NULL;                               /* fsk.c:146 */
+    int nsyms = 48;                                                  /* fsk.c:135 */
+    if (lbr) P = 8;                                                  /* horus_P, fsk.c:35,308 */
+    if (Fs <= 0 || Rs <= 0 || P <= 0) return NULL;                   /* asserts fsk.c:137-141 / 286-290 */
+    if (Fs % Rs != 0) return NULL;                                   /* fsk.c:143 / 292 */
+    if ((Fs / Rs) % P != 0) return NULL;                             /* fsk.c:145 / 294 */
+    if (M != 2 && M != 4) return NULL;                               /* fsk.c:146 / 295 */
+    if (lbr) nsyms = Fs / (Fs / Rs);                                 /* fsk.c:306,309: N = Fs, Nsym = N/Ts */
     f = (ora_fsk *)calloc(1, sizeof(*f));
     f->Fs = Fs; f->Rs = Rs; f->Ts = Fs / Rs;
     f->N = f->Ts * nsyms; f->P = P; f->Nsym = nsyms;
@@ -184,11 +189,16 @@ ora_fsk *ora_fsk_create_hbr(int Fs, int Rs, int P, int M) {       /* fsk.c:128-2
     f->nin = f->N;
     f->mode = M;
     f->Nbits = (M == 2) ? f->Nsym : f->Nsym * 2;
-    for (i = 1; i; i <<= 1) if (f->N & i) Ndft = i;                  /* fsk.c:169-171: highest set bit */
+    if (lbr) {
+        Ndft = 1024;                                                 /* fsk.c:300 */
+        f->est_min = 800; f->est_max = 2500; f->est_space = 100;     /* fsk.c:262-264,317-319 */
+    } else {
+        for (i = 1; i; i <<= 1) if (f->N & i) Ndft = i;              /* fsk.c:169-171: highest set bit */
+        f->est_min = Rs / 4; if (f->est_min < 0) f->est_min = 0;     /* fsk.c:175-176 */
+        f->est_max = (Fs / 2) - Rs / 4;                              /* fsk.c:178 */
+        f->est_space = Rs - (Rs / 5);                                /* fsk.c:180 */
+    }
     f->Ndft = Ndft;
-    f->est_min = Rs / 4; if (f->est_min < 0) f->est_min = 0;         /* fsk.c:175-176 */
-    f->est_max = (Fs / 2) - Rs / 4;                                  /* fsk.c:178 */
-    f->est_space = Rs - (Rs / 5);                                    /* fsk.c:180 */
     for (m = 0; m < M; m++) f->phi_c[m] = c_expj(0);                 /* fsk.c:184-185 */
     f->nstash = 4 * f->Ts;                                           /* fsk.c:187-189 */
     f->samp_old = (ora_comp *)calloc(f->nstash, sizeof(ora_comp));
@@ -218,6 +228,9 @@ ora_fsk *ora_fsk_create_hbr(int Fs, int Rs, int P, int M) {       /* fsk.c:128-2
     for (m = 0; m < M; m++) f->f_int[m] = (ora_comp *)malloc(sizeof(ora_comp) * (nsyms + 1) * P);
     return f;
 }
+
+ora_fsk *ora_fsk_create_hbr(int Fs, int Rs, int P, int M) { return ora_fsk_new(Fs, Rs, P, M, 0); }   /* fsk.c:128-259 */
+ora_fsk *ora_fsk_create(int Fs, int Rs, int M) { return ora_fsk_new(Fs, Rs, 8, M, 1); }             /* fsk.c:278-398 */
 
 void ora_fsk_destroy(ora_fsk *f) {
     int m;
@@ -505,7 +518,7 @@ long ora_demod_capture(int fmt, const void *raw, long nsamples, int Fs, int Rs, 
                        int est_lo, int est_hi, float *sd_out, uint8_t *bits_out, long cap_frames,
                        float *trace) {
     static const int bps[4] = {2, 4, 2, 8};
-    ora_fsk *f = ora_fsk_create_hbr(Fs, Rs, P, M);
+    ora_fsk *f = (P == -1) ? ora_fsk_create(Fs, Rs, M) : ora_fsk_create_hbr(Fs, Rs, P, M);   /* P == -1: the -l/--lbr geometry (fsk_demod.c:210-212) */
     long off = 0, nframes = 0;
     ora_comp *modbuf;
     float *sdbuf;

@@ -29,6 +29,8 @@ typedef struct ora_fsk ora_fsk;
 
 /* src/fsk.c:128-259 (fsk_create_hbr); tx_f1=1200, tx_fs=400 as src/fsk_demod.c:214 */
 ora_fsk *ora_fsk_create_hbr(int Fs, int Rs, int P, int M);
+/* src/fsk.c:278-398 (fsk_create, the -l/--lbr geometry: one-second frames, P = 8, Ndft = 1024, estimator band 800..2500 Hz) */
+ora_fsk *ora_fsk_create(int Fs, int Rs, int M);
 void     ora_fsk_destroy(ora_fsk *f);
 void     ora_fsk_set_est_limits(ora_fsk *f, int est_min, int est_max);   /* fsk.c:522-528 */
 int      ora_fsk_nin(const ora_fsk *f);                                  /* fsk.c:485-487 */

@@ -50,6 +50,8 @@ def oracle():
         L = C.CDLL(path)
         L.ora_fsk_create_hbr.restype = C.c_void_p
         L.ora_fsk_create_hbr.argtypes = [C.c_int] * 4
+        L.ora_fsk_create.restype = C.c_void_p
+        L.ora_fsk_create.argtypes = [C.c_int] * 3
         L.ora_fsk_destroy.argtypes = [C.c_void_p]
         L.ora_fsk_set_est_limits.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.ora_fsk_nin.argtypes = [C.c_void_p]
@@ -88,6 +90,8 @@ def ref():
         L = C.CDLL(os.path.join(REF_DIR, "libwenet_ref.so"))
         L.fsk_create_hbr.restype = C.c_void_p
         L.fsk_create_hbr.argtypes = [C.c_int] * 6
+        L.fsk_create.restype = C.c_void_p
+        L.fsk_create.argtypes = [C.c_int] * 5
         L.fsk_destroy.argtypes = [C.c_void_p]
         L.fsk_set_est_limits.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.fsk_nin.restype = C.c_uint32
@@ -119,16 +123,19 @@ def raw_bytes(raw: np.ndarray) -> np.ndarray:
     return np.ascontiguousarray(raw).view(np.uint8).reshape(-1)
 
 
-def oracle_demod(raw, fmt, Fs, Rs, M, P=0, est=(0, 0), hard=False, want_trace=False):
-    """Whole-capture oracle demod.  Returns (sd or bits, trace or None)."""
+def oracle_demod(raw, fmt, Fs, Rs, M, P=0, est=(0, 0), hard=False, want_trace=False, lbr=False):
+    """Whole-capture oracle demod.  Returns (sd or bits, trace or None).  lbr: the fsk_create geometry (fsk_demod -l)."""
     L = oracle()
     rb = raw_bytes(raw)
     nsamp = rb.size // BYTES_PER_SAMPLE[fmt]
     if P == 0:
         P = Fs // Rs
     Ts = Fs // Rs
-    nbits = 48 * (1 if M == 2 else 2)
-    cap = nsamp // (48 * Ts - Ts // 2) + 2
+    nsym = Rs if lbr else 48
+    if lbr:
+        P = -1
+    nbits = nsym * (1 if M == 2 else 2)
+    cap = nsamp // (nsym * Ts - Ts // 2) + 2
     sd = np.zeros(cap * nbits, np.float32)
     bits = np.zeros(cap * nbits, np.uint8)
     trace = np.zeros((cap, 8), np.float32)

@@ -104,3 +104,45 @@ def test_pipeline_vs_reference_cli():
         assert b"".join(bytes(d["bytes"][i][:256]) for i in range(d["n"]) if d["crc_ok"][i]) == pk
         its = [int(l.split("iter:")[1]) for l in err.decode().splitlines() if "iter:" in l]
         assert its == list(d["iter"])
+
+
+# ---- the low-rate constructor fsk_create (fsk.c:278-398, `fsk_demod -l`) ---------------------------------------
+@pytest.mark.parametrize("M,Fs,Rs,fmt,eb,ppm", [(4, 8000, 100, "s16", 12, 0.0), (2, 8000, 100, "s16", 9, 0.0), (4, 9600, 300, "cs16", 15, 300.0),
+                                               (2, 48000, 1200, "s16", 12, 0.0)])
+def test_lbr_demod_vs_reference_cli(M, Fs, Rs, fmt, eb, ppm):
+    cfg = siggen.config_lbr(M, Fs, Rs)
+    raw, _ = siggen.make_lbr_capture(cfg, 6, eb, seed=40 + M, fmt=fmt, ppm=ppm)
+    for soft in (True, False):
+        ref_out, _ = ol.ref_cli_demod(raw, fmt, Fs, Rs, M, soft=soft, extra=("-l",))
+        ora_out, _ = ol.oracle_demod(raw, fmt, Fs, Rs, M, hard=not soft, lbr=True)
+        assert ref_out.size >= 4 * Rs * (M // 2) and bits_equal(ora_out, ref_out)
+
+
+def test_lbr_geometry_and_state_vs_reference_library():
+    O, R = ol.oracle(), ol.ref()
+    cfg = siggen.config_lbr(4, 8000, 100)
+    raw, _ = siggen.make_lbr_capture(cfg, 5, 10.0, seed=8, fmt="s16", ppm=-400.0)
+    fr = R.fsk_create(cfg.Fs, cfg.Rs, cfg.M, 1200, 400)
+    fo = O.ora_fsk_create(cfg.Fs, cfg.Rs, cfg.M)
+    for k, fn in enumerate(["Ndft", "N", "Ts", "Nmem", "P", "Nsym", "Nbits", "nstash", "mode", "est_min", "est_max", "est_space"]):
+        assert getattr(R, "ref_fsk_" + fn)(fr) == O.ora_fsk_geom(fo, k), fn
+    nb = O.ora_fsk_geom(fo, 6)
+    off = 0
+    for _ in range(4):
+        nin = int(R.fsk_nin(fr))
+        assert nin == O.ora_fsk_nin(fo)
+        comp = np.zeros(2 * nin, np.float32)
+        O.ora_convert_samples(0, raw[off:].ctypes.data, nin, comp)
+        a, b = np.zeros(nb, np.float32), np.zeros(nb, np.float32)
+        R.fsk_demod_sd(fr, a.ctypes.data, comp.ctypes.data)
+        O.ora_fsk_demod_frame(fo, None, b.ctypes.data, comp.ctypes.data)
+        assert bits_equal(a, b)
+        e1, e2 = np.zeros(512, np.float32), np.zeros(512, np.float32)
+        R.ref_fsk_fft_est(fr, e1); O.ora_fsk_get_fft_est(fo, e2)
+        assert bits_equal(e1, e2)
+        for k, fn in enumerate(["norm_rx_timing", "ppm", "EbNodB", "snr_est", "stats_rx_timing", "foff"]):
+            assert getattr(R, "ref_fsk_" + fn)(fr) == O.ora_fsk_get_scalar(fo, k), fn
+        off += nin
+    R.fsk_destroy(fr); O.ora_fsk_destroy(fo)
+    assert not O.ora_fsk_create(8000, 300, 2)          # Fs % Rs (fsk.c:292)
+    assert not O.ora_fsk_create(8000, 2000, 2)         # Ts % 8  (fsk.c:294)

@@ -139,7 +139,25 @@ def config_4fsk():
     return ModemConfig("4fsk", 1, 4, Fs, Rs, 200000.0, float(Rs))
 
 
+def config_lbr(M: int = 4, Fs: int = 8000, Rs: int = 100):
+    # the fsk_create / `fsk_demod -l` geometry (fsk.c:278-398): one-second frames, tones inside the 800..2500 Hz estimator
+    # band and at least 100 Hz apart.  No Wenet framing rides on it (mode is unused).
+    return ModemConfig("lbr", 1, M, Fs, Rs, 1100.0, 270.0)
+
+
 CONFIGS = {"v1": config_v1, "v2": config_v2, "4fsk": config_4fsk}
+
+
+def make_lbr_capture(cfg: ModemConfig, seconds: int, ebno_db: float, seed: int, fmt: str = "s16", ppm: float = 0.0):
+    """Random symbols through modulate/add_noise as real s16 (the audio input `fsk_demod -l` is normally fed), cs16 or cu8."""
+    rng = np.random.default_rng(seed)
+    bits = rng.integers(0, 2, seconds * cfg.Rs * (1 if cfg.M == 2 else 2), dtype=np.uint8)
+    x = add_noise(modulate(bits, cfg, ppm), cfg, ebno_db, rng)
+    if fmt == "s16":
+        return np.round(x.real * 1000.0).astype(np.int16), bits
+    if fmt == "cs16":
+        return to_cs16(x), bits
+    return to_cu8(x), bits
 
 
 def modulate(bits: np.ndarray, cfg: ModemConfig, ppm: float = 0.0) -> np.ndarray:
