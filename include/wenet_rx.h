@@ -45,6 +45,10 @@ typedef struct wenet_fsk wenet_fsk;
 /* fsk_create_hbr (src/fsk.h:113, src/fsk.c:128-259).  Illegal parameters (the reference's
  * asserts at fsk.c:137-146) return NULL instead of aborting. */
 wenet_fsk *wenet_fsk_create_hbr(int Fs, int Rs, int P, int M, int tx_f1, int tx_fs);
+/* fsk_create (src/fsk.h:100, src/fsk.c:278-398): the low-rate geometry `fsk_demod -l` selects (src/fsk_demod.c:210-212) --
+ * one-second frames (N = Fs, Nsym = Rs), P = 8, 1024-point estimator over 800..2500 Hz.  Illegal parameters (the
+ * asserts at fsk.c:286-295) return NULL. */
+wenet_fsk *wenet_fsk_create(int Fs, int Rs, int M, int tx_f1, int tx_fs);
 /* fsk_destroy (src/fsk.h:131) */
 void wenet_fsk_destroy(wenet_fsk *fsk);
 /* fsk_set_est_limits (src/fsk.h:126, src/fsk.c:522-528) */

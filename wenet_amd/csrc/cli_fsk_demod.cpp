@@ -5,8 +5,8 @@
 //   usage: fsk_demod [-l] [-p P] [-s] [(-c|-d)] [-t [r]] [-f] (2|4) SampleRate SymbolRate In Out
 //
 // Differences that cannot be avoided, all outside the data path:
-//   * -l/--lbr (fsk_create, 1-second frames) is not part of the Wenet receive chain:
-//     it exits(1) with a message instead of silently doing something else.
+//   * -l/--lbr (fsk_create, 1-second frames) runs the same kernel with its frame buffers in global memory
+//     (the frame does not fit LDS); like the reference it ignores -p, -b and -u.
 //   * input is read in blocks (whatever the pipe holds, at least one frame) instead of exactly nin
 //     samples per fread; the frames produced, their order and the trailing-partial-frame rule
 //     (src/fsk_demod.c:270) are identical.
@@ -116,12 +116,12 @@ int main(int argc, char *argv[]) {
     if (Rs <= 0 || Fs <= 0) { fprintf(stderr, "Invalid sample/symbol rate\n"); exit(1); }
     if (P == 0) P = Fs / Rs;                                                 /* fsk_demod.c:186-188 */
     if ((M != 2) && (M != 4)) { fprintf(stderr, "Mode %d is not valid. Mode must be 2 or 4.\n", M); usage(argv[0]); }
-    if (!hbr) { fprintf(stderr, "fsk_demod (wenet_rx): --lbr mode is not supported by this build\n"); exit(1); }
 
     FILE *fin = (strcmp(argv[dx + 3], "-") == 0) ? stdin : fopen(argv[dx + 3], "r");
     FILE *fout = (strcmp(argv[dx + 4], "-") == 0) ? stdout : fopen(argv[dx + 4], "w");
-    wenet_fsk *fsk = wenet_fsk_create_hbr(Fs, Rs, P, M, 1200, 400);        /* fsk_demod.c:214 */
-    if (fsk && fsk_lower > 0 && fsk_upper > fsk_lower) {                    /* fsk_demod.c:215-218 */
+    wenet_fsk *fsk = hbr ? wenet_fsk_create_hbr(Fs, Rs, P, M, 1200, 400)    /* fsk_demod.c:214 */
+                         : wenet_fsk_create(Fs, Rs, M, 1200, 400);          /* fsk_demod.c:210-212 (-l: estimator limits are not applied) */
+    if (fsk && hbr && fsk_lower > 0 && fsk_upper > fsk_lower) {             /* fsk_demod.c:215-218 */
         wenet_fsk_set_est_limits(fsk, fsk_lower, fsk_upper);
         fprintf(stderr, "Setting estimator limits to %d to %d Hz.\n", fsk_lower, fsk_upper);
     }

@@ -29,7 +29,13 @@
 
 // NT = threads per capture: 64 (one wavefront) or 512 (eight: the order-free stages are spread over all of them,
 // the ordered recurrences run on wavefront 0) -- used for configurations too large for the pipelined kernel.
-template <int M, bool PROF, bool TLDS, int NT>
+// BIG = the per-frame sample buffers (input block, mixed rows, phasor checkpoints, integrator outputs, timing products) live
+// in a per-capture global scratch block instead of LDS: frame geometries that do not fit 160 KiB, i.e. the one-second
+// frames of fsk_create (fsk.c:278-398, `fsk_demod -l`).  Same statements in the same order; workgroup barriers then also
+// order global memory (one workgroup runs on one CU and shares its vector L1).
+template <bool BIG> __device__ __forceinline__ void wg_barrier() { if constexpr (BIG) __syncthreads(); else lds_barrier(); }
+
+template <int M, bool PROF, bool TLDS, int NT, bool BIG = false>
 __global__ __launch_bounds__(NT) void wenet_demod_kernel(WrDemodCfg cfg, const WrChan *chans, int nchan) {
     const int ch = blockIdx.x;
     if (ch >= nchan) return;
@@ -38,15 +44,16 @@ __global__ __launch_bounds__(NT) void wenet_demod_kernel(WrDemodCfg cfg, const W
     const WrChan C = chans[ch];
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float2 *X  = (float2 *)(smem + cfg.off_X);    // [nstash + N + Ts/2]  old tail | new block
+#define WR_FRAMEBUF(off) ((float2 *)((BIG ? C.big : smem) + (off)))      /* BIG is a compile-time constant: the address space folds */
+    float2 *X  = WR_FRAMEBUF(cfg.off_X);          // [nstash + N + Ts/2]  old tail | new block
     float2 *FB = (float2 *)(smem + cfg.off_FB);   // [Ndft]               FFT work buffer
-    float2 *PH = (float2 *)(smem + cfg.off_PH);   // [M][Lpad]            NCO phasors -> down-converted samples -> timing products
-    float2 *FI = (float2 *)(smem + cfg.off_FI);   // [M][NI]              integrator outputs
+    float2 *PH = WR_FRAMEBUF(cfg.off_PH);         // [M][Lpad]            NCO phasors -> down-converted samples -> timing products
+    float2 *FI = WR_FRAMEBUF(cfg.off_FI);         // [M][NI]              integrator outputs
     float  *FE = (float *)(smem + cfg.off_FE);    // [Ndft/2]             IIR-smoothed spectrum (fsk->fft_est)
     float  *FW = (float *)(smem + cfg.off_FW);    // [Ndft/2]             peak-search working copy
     float  *SDL = (float *)(smem + cfg.off_SD);   // [Nbits]              last soft decisions (kept across a NaN frame)
     float  *SC = (float *)(smem + cfg.off_SC);    // [4*Nsym + 16]        scratch
-    float2 *CKb = (float2 *)(smem + cfg.off_CK);  // [2 segments][M][ckrow] every 8th NCO phasor (checkpoints)
+    float2 *CKb = WR_FRAMEBUF(cfg.off_CK);        // [2 segments][M][ckrow] every 8th NCO phasor (checkpoints)
     float2 *CKD = (float2 *)(smem + cfg.off_CKD); // [2 segments][M]        NCO step of each segment
     // configuration tables: LDS copies (TLDS) or the global originals (configurations too big for LDS)
     const float2 *tw_t   = TLDS ? (const float2 *)(smem + cfg.off_TW) : cfg.tw;
@@ -58,6 +65,8 @@ __global__ __launch_bounds__(NT) void wenet_demod_kernel(WrDemodCfg cfg, const W
     const int Ts = cfg.Ts, N = cfg.N, P = cfg.P, Nmem = cfg.Nmem, nstash = cfg.nstash;
     const int Ndft = cfg.Ndft, NH = cfg.Ndft / 2, L = cfg.L, NI = cfg.NI, q = cfg.q, Lpad = cfg.Lpad;
     const int Nbits = cfg.Nbits;
+    const int nsym_k = BIG ? cfg.Nsym : WR_NSYM;                          // symbols per frame (48 for fsk_create_hbr, N/Ts for fsk_create)
+    const int scc = BIG ? 4 * cfg.Nsym : 120;                             // control slots behind the per-symbol scratch in SC
 
     // ---- load carried state ---------------------------------------------------------------
     WrChanHdr *hdr = (WrChanHdr *)C.state;
@@ -113,7 +122,7 @@ __global__ __launch_bounds__(NT) void wenet_demod_kernel(WrDemodCfg cfg, const W
         } else {
             for (int i = tid; i < nin; i += NT) X[nstash + i] = load_sample(C.raw, C.fmt, off + i);
         }
-        lds_barrier();
+        wg_barrier<BIG>();
         PROF_MARK(0);
 
         // ---- tone estimator (fsk.c:540-677) ------------------------------------------------
@@ -132,7 +141,7 @@ __global__ __launch_bounds__(NT) void wenet_demod_kernel(WrDemodCfg cfg, const W
                 }
                 FB[n] = v;
             }
-            lds_barrier();
+            wg_barrier<BIG>();
             for (int s = cfg.nstages - 1; s >= 0; s--) {               // innermost butterflies first
                 const int m = cfg.mstage[s], p = cfg.radix[s], fs = cfg.fstride[s];
                 const int lgm = 31 - __clz(m);
@@ -160,7 +169,7 @@ __global__ __launch_bounds__(NT) void wenet_demod_kernel(WrDemodCfg cfg, const W
                         F[0] = make_float2(f0.x + t.x, f0.y + t.y);
                     }
                 }
-                lds_barrier();
+                wg_barrier<BIG>();
             }
             // |X|^2, band limits, IIR (fsk.c:612-628)
             for (int i = tid; i < NH; i += NT) {
@@ -172,11 +181,11 @@ __global__ __launch_bounds__(NT) void wenet_demod_kernel(WrDemodCfg cfg, const W
                 FE[i] = e;
                 FW[i] = e;
             }
-            lds_barrier();
+            wg_barrier<BIG>();
         }
         if (fft_loops == 0) {          // not reachable for hbr geometries (nin >= Ndft); defined behaviour anyway
             for (int i = tid; i < NH; i += NT) FW[i] = 0.f;
-            lds_barrier();
+            wg_barrier<BIG>();
         }
         PROF_MARK(1);
         // M peaks: first-maximum argmax, blank +-f_zero, ascending sort (fsk.c:633-667) -- wavefront 0, then shared
@@ -218,13 +227,13 @@ __global__ __launch_bounds__(NT) void wenet_demod_kernel(WrDemodCfg cfg, const W
         }
         if (NT > 64 && lane == 0) {
 #pragma unroll
-            for (int m = 0; m < M; m++) ((int *)SC)[120 + m] = fbin[m];
+            for (int m = 0; m < M; m++) ((int *)SC)[scc + m] = fbin[m];
         }
         }   // wave == 0
         if (NT > 64) {
-            lds_barrier();
+            wg_barrier<BIG>();
 #pragma unroll
-            for (int m = 0; m < M; m++) fbin[m] = __builtin_amdgcn_readfirstlane(((const int *)SC)[120 + m]);
+            for (int m = 0; m < M; m++) fbin[m] = __builtin_amdgcn_readfirstlane(((const int *)SC)[scc + m]);
         }
         // first run: no valid previous estimate (fsk.c:750-753)
         if (cfg.bin_freq[fbin_prev[0]] < 1.0f) {
@@ -233,7 +242,7 @@ __global__ __launch_bounds__(NT) void wenet_demod_kernel(WrDemodCfg cfg, const W
         }
 
         float tcr = 0.f, tci = 0.f;
-        if (NT > 64 && cfg.seq_stream) {
+        if (!BIG && NT > 64 && cfg.seq_stream) {
             // ================= streamed frame body (workgroups of eight waves) ===================================
             // The NCO chain is one dependent recurrence on wave 0 (24 cycles per sample); everything downstream of it
             // is consumed as it is produced instead of after it: the chain publishes how many samples have their
@@ -438,7 +447,7 @@ __global__ __launch_bounds__(NT) void wenet_demod_kernel(WrDemodCfg cfg, const W
             }
 #pragma unroll
             for (int m = 0; m < M; m++) fbin_prev[m] = fbin[m];                // fsk.c:847
-            lds_barrier();
+            wg_barrier<BIG>();
             for (int i = tid; i < nstash; i += NT) X[i] = X[nstash + nin - nstash + i];     // fsk.c:851
             tcr = SC[124]; tci = SC[125];
             if (stamp && tid == 0) C.prof[3] = (long long)__builtin_readcyclecounter();
@@ -488,7 +497,7 @@ __global__ __launch_bounds__(NT) void wenet_demod_kernel(WrDemodCfg cfg, const W
             }
     #pragma unroll
             for (int m = 0; m < M; m++) fbin_prev[m] = fbin[m];                // fsk.c:847
-            lds_barrier();
+            wg_barrier<BIG>();
 
             PROF_MARK(3);
             // ---- down-convert: sample * conj(phasor) (fsk.c:791,817); one thread per (tone, checkpoint) replays the
@@ -514,7 +523,7 @@ __global__ __launch_bounds__(NT) void wenet_demod_kernel(WrDemodCfg cfg, const W
                     }
                 }
             }
-            lds_barrier();
+            wg_barrier<BIG>();
 
             PROF_MARK(4);
             // ---- integrate-and-dump: every output re-sums the Ts circular-buffer slots in slot order
@@ -549,14 +558,14 @@ __global__ __launch_bounds__(NT) void wenet_demod_kernel(WrDemodCfg cfg, const W
     #pragma unroll
                 for (int m = 0; m < M; m++) FI[m * NI + i] = make_float2(acc[m].x, acc[m].y);
             }
-            lds_barrier();
+            wg_barrier<BIG>();
 
             PROF_MARK(5);
             // ---- stash the tail of the new block for the next frame (fsk.c:851) ------------------
             for (int i = tid; i < nstash; i += NT) X[i] = X[nstash + nin - nstash + i];
 
             // ---- fine timing: sum_i (sum_m |f_int|^2) * phi_ft[i]  (fsk.c:858-874) ---------------
-            float2 *TP = PH;                                                   // down-converted samples are dead now
+            float2 *TP = BIG ? WR_FRAMEBUF(cfg.off_TP) : PH;                   // (LDS form: the down-converted samples are dead now)
             for (int i = tid; i < NI; i += NT) {
                 float ft1 = 0.f;
     #pragma unroll
@@ -567,7 +576,7 @@ __global__ __launch_bounds__(NT) void wenet_demod_kernel(WrDemodCfg cfg, const W
                 const float2 pf = pft_t[i];
                 TP[i] = make_float2(ft1 * pf.x, ft1 * pf.y);
             }
-            lds_barrier();
+            wg_barrier<BIG>();
             PROF_MARK(6);
             if (NT == 64 || wave == 0) {
                 // sequential float accumulation in index order (fsk.c:870): one packed add per product
@@ -610,9 +619,9 @@ __global__ __launch_bounds__(NT) void wenet_demod_kernel(WrDemodCfg cfg, const W
                 tcr = acc.x; tci = acc.y;
             }
             if (NT > 64) {                                                     // wavefront 0's sums to everyone
-                if (tid == 0) { SC[124] = tcr; SC[125] = tci; }
-                lds_barrier();
-                tcr = SC[124]; tci = SC[125];
+                if (tid == 0) { SC[scc + 4] = tcr; SC[scc + 5] = tci; }
+                wg_barrier<BIG>();
+                tcr = SC[scc + 4]; tci = SC[scc + 5];
             }
         }
         tcr = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(tcr)));   // lane 0's sums, as wave-uniform values
@@ -644,9 +653,8 @@ __global__ __launch_bounds__(NT) void wenet_demod_kernel(WrDemodCfg cfg, const W
             const int high_sample = (int)ceilf(rx_timing);
             const float omf = 1 - fract;
             tr_rxt = rx_timing;
-            float mymax = 0.f;
-            if (tid < WR_NSYM) {
-                const int st = (lane + 1) * P;
+            for (int sy = tid; sy < nsym_k; sy += NT) {                        // (one trip for the 48-symbol frames: NT >= 64)
+                const int st = (sy + 1) * P;
                 float tmax[M];
 #pragma unroll
                 for (int m = 0; m < M; m++) {
@@ -661,40 +669,39 @@ __global__ __launch_bounds__(NT) void wenet_demod_kernel(WrDemodCfg cfg, const W
                 int sym = 0;
 #pragma unroll
                 for (int m = 0; m < M; m++) if (tmax[m] > mx) { mx = tmax[m]; sym = m; }
-                mymax = mx;
+                if (cfg.stats) { SC[sy] = mx; SC[nsym_k + sy] = sqrtf(mx); }   // Eb/N0 accumulators (fsk.c:984-993)
                 if (C.bits_out) {
                     uint8_t *bo = C.bits_out + frames * Nbits;
-                    if (M == 2) bo[lane] = (uint8_t)(sym == 1);
-                    else { bo[lane * 2 + 1] = (uint8_t)(sym & 1); bo[lane * 2] = (uint8_t)((sym & 2) >> 1); }
+                    if (M == 2) bo[sy] = (uint8_t)(sym == 1);
+                    else { bo[sy * 2 + 1] = (uint8_t)(sym & 1); bo[sy * 2] = (uint8_t)((sym & 2) >> 1); }
                 }
 #pragma unroll
                 for (int m = 0; m < M; m++) tmax[m] = sqrtf(tmax[m]);
                 if (M == 2) {
-                    SDL[lane] = tmax[0] - tmax[1];
+                    SDL[sy] = tmax[0] - tmax[1];
                 } else {                                                   // fsk.c:969-980, same accumulation order
                     float s1 = -tmax[0], s0 = -tmax[0];
                     s1 += tmax[1 % M];  s0 += -tmax[1 % M];
                     s1 += -tmax[2 % M]; s0 += tmax[2 % M];
                     s1 += tmax[3 % M];  s0 += tmax[3 % M];
-                    SDL[lane * 2 + 1] = s1;
-                    SDL[lane * 2] = s0;
+                    SDL[sy * 2 + 1] = s1;
+                    SDL[sy * 2] = s0;
                 }
             }
             if (cfg.stats) {                                               // Eb/N0 accumulators (fsk.c:984-1007)
-                if (tid < WR_NSYM) { SC[lane] = mymax; SC[WR_NSYM + lane] = sqrtf(mymax); }
-                lds_barrier();
+                wg_barrier<BIG>();
                 if (tid == 0) {
                     float stdebno = 0.f, meanebno = 0.f;
-                    for (int i = 0; i < WR_NSYM; i++) { stdebno += SC[i]; meanebno += SC[WR_NSYM + i]; }
+                    for (int i = 0; i < nsym_k; i++) { stdebno += SC[i]; meanebno += SC[nsym_k + i]; }
                     meanebno = meanebno / cfg.nsym_f;
                     stdebno = (stdebno / cfg.nsym_f) - (meanebno * meanebno);
                     if ((double)stdebno > 0.0) stdebno = (float)sqrt((double)stdebno); else stdebno = 0.0f;
-                    SC[2 * WR_NSYM] = meanebno;
-                    SC[2 * WR_NSYM + 1] = stdebno;
+                    SC[2 * nsym_k] = meanebno;
+                    SC[2 * nsym_k + 1] = stdebno;
                 }
-                lds_barrier();
-                tr_mean = SC[2 * WR_NSYM];
-                tr_std = SC[2 * WR_NSYM + 1];
+                wg_barrier<BIG>();
+                tr_mean = SC[2 * nsym_k];
+                tr_std = SC[2 * nsym_k + 1];
             }
             // ---- stats snapshot for the JSON side channel (fsk.c:1037-1066, fsk_demod.c:366-385):
             //      raw eye traces |f_int[m][ind]| and the smoothed spectrum; normalisation is host work
@@ -717,7 +724,7 @@ __global__ __launch_bounds__(NT) void wenet_demod_kernel(WrDemodCfg cfg, const W
                 }
             }
         }
-        lds_barrier();
+        wg_barrier<BIG>();
         PROF_MARK(8);
         // ---- emit the frame's outputs (fsk_demod.c:403-407): a NaN frame re-emits the previous buffer
         if (C.sd_out) {
@@ -738,7 +745,7 @@ __global__ __launch_bounds__(NT) void wenet_demod_kernel(WrDemodCfg cfg, const W
         off += nin;
         nin = nin_next;
         frames++;
-        lds_barrier();
+        wg_barrier<BIG>();
         PROF_MARK(9);
     }
     if (PROF && C.prof && tid == 0) {
@@ -767,18 +774,30 @@ __global__ __launch_bounds__(NT) void wenet_demod_kernel(WrDemodCfg cfg, const W
 extern "C" hipError_t wr_launch_demod_pipe(const WrDemodCfg *cfg, const WrChan *d_chans, int nchan, hipStream_t stream, int prof);
 extern "C" hipError_t wr_launch_demod_ex(const WrDemodCfg *cfg, const WrChan *d_chans, int nchan, hipStream_t stream, int prof) {
     if (nchan <= 0) return hipSuccess;
-    if (cfg->pipe_ok && prof != 2) return wr_launch_demod_pipe(cfg, d_chans, nchan, stream, prof);   // 8 waves per capture, pipelined
+    if (cfg->pipe_ok && !cfg->big && prof != 2) return wr_launch_demod_pipe(cfg, d_chans, nchan, stream, prof);   // 8 waves per capture, pipelined
 #define WR_LAUNCH(MM, PP, TT, NN)                                                                                        \
     do {                                                                                                                   \
         (void)hipFuncSetAttribute((const void *)wenet_demod_kernel<MM, PP, TT, NN>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                   cfg->lds_bytes);                                                                          \
         hipLaunchKernelGGL((wenet_demod_kernel<MM, PP, TT, NN>), dim3(nchan), dim3(NN), cfg->lds_bytes, stream, *cfg, d_chans, nchan); \
     } while (0)
+#define WR_LAUNCH5(MM, PP, TT, NN, BB)                                                                                   \
+    do {                                                                                                                   \
+        (void)hipFuncSetAttribute((const void *)wenet_demod_kernel<MM, PP, TT, NN, BB>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  cfg->lds_bytes);                                                                          \
+        hipLaunchKernelGGL((wenet_demod_kernel<MM, PP, TT, NN, BB>), dim3(nchan), dim3(NN), cfg->lds_bytes, stream, *cfg, d_chans, nchan); \
+    } while (0)
 #define WR_LAUNCH_T(MM, PP, NN) do { if (cfg->tables_in_lds) WR_LAUNCH(MM, PP, true, NN); else WR_LAUNCH(MM, PP, false, NN); } while (0)
+    if (cfg->big) {                                                    // frame buffers in global memory (fsk_create geometries); never profiled
+        if (cfg->M == 2) { if (cfg->tables_in_lds) WR_LAUNCH5(2, false, true, 512, true); else WR_LAUNCH5(2, false, false, 512, true); }
+        else             { if (cfg->tables_in_lds) WR_LAUNCH5(4, false, true, 512, true); else WR_LAUNCH5(4, false, false, 512, true); }
+        return hipGetLastError();
+    }
     // profiling (prof) keeps the one-wavefront form whose phase timings the instrumentation was written for
     if (cfg->M == 2) { if (prof) WR_LAUNCH_T(2, true, 64); else WR_LAUNCH_T(2, false, 512); }
     else             { if (prof) WR_LAUNCH_T(4, true, 64); else WR_LAUNCH_T(4, false, 512); }
 #undef WR_LAUNCH_T
+#undef WR_LAUNCH5
 #undef WR_LAUNCH
     return hipGetLastError();
 }

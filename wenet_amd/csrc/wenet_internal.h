@@ -50,6 +50,8 @@ struct WrDemodCfg {
     int off_TP, seq_stream;              // sequential kernel: separate timing-product row and the streamed frame body (8 waves)
     int off_CK, off_CKD, ckrow;          // sequential kernel: phasor checkpoints [2 segments][M][ckrow], NCO steps [2][M]
     int tables_in_lds, off_TW, off_HANN, off_SRC, off_PFT, off_DPHI;
+    int big, big_bytes;                  // sequential kernel, frame geometries beyond LDS: off_X/off_PH/off_FI/off_CK/off_TP are offsets into
+                                         // the capture's global scratch block (WrChan::big, big_bytes each)
     // LDS carve-up of the pipelined kernel (demod_pipe_kernel.hip); pipe_ok = configuration fits
     int pipe_ok, p_ring, p_lds_bytes, chain_prio;
     int p_tsum_split;                    // timing sum with re/im in separate lanes and plain adds (less SIMD time, more latency): batch launches
@@ -88,6 +90,7 @@ struct WrChan {
     long long   dump_first, dump_period, dump_cap;
     long long  *prof;           // development: per-phase cycle totals (profiling instantiation only)
     long long  *prof2;          // development: sub-phase totals of the pipelined kernel's D/T wave
+    unsigned char *big;         // frame scratch of WrDemodCfg::big_bytes (only when WrDemodCfg::big)
 };
 
 // ---- deframer ----

@@ -138,13 +138,16 @@ struct DemodTables {
         return c;
     }
 
-    bool build(int Fs, int Rs, int P, int M) {
+    // lbr = false: fsk_create_hbr (fsk.c:128-259); lbr = true: fsk_create (fsk.c:278-398) -- one-second frames (N = Fs,
+    // Nsym = Rs), P = horus_P = 8, a 1024-point estimator over 800..2500 Hz with 100 Hz tone spacing
+    bool build(int Fs, int Rs, int P, int M, bool lbr = false) {
         memset(&cfg, 0, sizeof(cfg));
+        if (lbr) P = 8;                                                 // fsk.c:35,308
         if (Fs <= 0 || Rs <= 0 || P <= 0) return false;                 // fsk.c:137-141
         if (Fs % Rs != 0) return false;                                 // fsk.c:143
         if ((Fs / Rs) % P != 0) return false;                           // fsk.c:145
         if (M != 2 && M != 4) return false;                             // fsk.c:146
-        const int nsyms = WR_NSYM;
+        const int nsyms = lbr ? Rs : WR_NSYM;                           // fsk.c:135 / fsk.c:306,309 (N = Fs, Nsym = N/Ts)
         cfg.Fs = Fs; cfg.Rs = Rs; cfg.Ts = Fs / Rs; cfg.P = P; cfg.M = M; cfg.Nsym = nsyms;
         cfg.N = cfg.Ts * nsyms;
         cfg.Nmem = cfg.N + 2 * cfg.Ts;
@@ -152,6 +155,7 @@ struct DemodTables {
         cfg.nstash = 4 * cfg.Ts;
         int Ndft = 0;
         for (int i = 1; i; i <<= 1) if (cfg.N & i) Ndft = i;            // fsk.c:169-171
+        if (lbr) Ndft = 1024;                                           // fsk.c:300
         cfg.Ndft = Ndft;
         if (Ndft < 64 || Ndft / 2 > 2048) { fprintf(stderr, "libwenet_rx: unsupported Ndft %d\n", Ndft); return false; }
         cfg.q = cfg.Ts / P;
@@ -162,9 +166,14 @@ struct DemodTables {
         cfg.nsym_f = (float)nsyms;
         cfg.tc = (float)(0.95 * Ndft / Fs);                             // fsk.c:573
         cfg.one_minus_tc = 1 - cfg.tc;                                  // fsk.c:626 "(1-tc)"
-        est_space = Rs - (Rs / 5);                                      // fsk.c:180
-        int emin = Rs / 4; if (emin < 0) emin = 0;                      // fsk.c:175-176
-        set_band(emin, (Fs / 2) - Rs / 4);                              // fsk.c:178
+        if (lbr) {
+            est_space = 100;                                            // HORUS_MIN_SPACING, fsk.c:264,319
+            set_band(800, 2500);                                        // HORUS_MIN/MAX, fsk.c:262-263,317-318
+        } else {
+            est_space = Rs - (Rs / 5);                                  // fsk.c:180
+            int emin = Rs / 4; if (emin < 0) emin = 0;                  // fsk.c:175-176
+            set_band(emin, (Fs / 2) - Rs / 4);                          // fsk.c:178
+        }
         cfg.eye_dec = (int)ceil(((float)P * 2) / 160);                  // fsk.c:1037
         cfg.neyesamp = (P * 2) / cfg.eye_dec;
         cfg.eye_traces = 8 / M;
@@ -259,6 +268,28 @@ struct DemodTables {
             cfg.pipe_ok = (fits && cfg.p_lds_bytes <= 80 * 1024 && getenv("WENET_RX_NO_PIPE") == nullptr) ? 1 : 0;
         }
         cfg.lds_bytes = o;
+        if (lbr || o > 160 * 1024) {
+            // Frame geometry beyond LDS (always for the one-second frames of fsk_create): the per-frame sample buffers move to a
+            // per-capture global scratch block, LDS keeps the estimator and the per-symbol scratch.
+            size_t g = 0;
+            auto gplace = [&](size_t sz) { size_t at = g; g = (g + sz + 255) & ~(size_t)255; return (int)at; };
+            cfg.big = 1; cfg.pipe_ok = 0; cfg.seq_stream = 0; cfg.tables_in_lds = 0;
+            cfg.off_X = gplace((size_t)(cfg.nstash + cfg.N + cfg.Ts / 2) * 8);
+            cfg.off_PH = gplace((size_t)M * cfg.Lpad * 8);
+            cfg.off_FI = gplace((size_t)M * cfg.NI * 8);
+            cfg.off_CK = gplace((size_t)2 * M * cfg.ckrow * 8);
+            cfg.off_TP = gplace((size_t)cfg.NI * 8);
+            if (g > (size_t)1 << 30) { fprintf(stderr, "libwenet_rx: frame scratch of %zu bytes per capture is not supported\n", g); return false; }
+            cfg.big_bytes = (int)g;
+            int l = 0;
+            cfg.off_FB = l; l = align16(l + Ndft * 8);
+            cfg.off_FE = l; l = align16(l + NH * 4);
+            cfg.off_FW = l; l = align16(l + NH * 4);
+            cfg.off_SD = l; l = align16(l + cfg.Nbits * 4);
+            cfg.off_SC = l; l = align16(l + (4 * nsyms + 16) * 4);
+            cfg.off_CKD = l; l = align16(l + 2 * M * 8);
+            cfg.lds_bytes = o = l;
+        }
         if (o > 160 * 1024) { fprintf(stderr, "libwenet_rx: configuration needs %d bytes of LDS (>160 KiB)\n", o); return false; }
         // state block
         cfg.st_fft_est = 24;                                            // sizeof(WrChanHdr)=88 -> 24 floats
@@ -426,7 +457,7 @@ void fill_decode_tables(WrDecodeArgs &a, const LdpcTables *t) {
 // ================================================================================================
 struct wenet_fsk {
     DemodTables tab;
-    DevBuf d_state, d_chan, d_raw, d_out, d_trace, d_dump;
+    DevBuf d_state, d_chan, d_raw, d_out, d_trace, d_dump, d_big;
     WrChanHdr hdr;                 // host copy after the last launch
     long long frames_total = 0;
     long stats_first = -1, stats_period = 0;
@@ -450,6 +481,16 @@ extern "C" wenet_fsk *wenet_fsk_create_hbr(int Fs, int Rs, int P, int M, int tx_
     if (!device_ready()) return nullptr;
     wenet_fsk *f = new wenet_fsk();
     if (!f->tab.build(Fs, Rs, P, M)) { delete f; return nullptr; }
+    f->tab.tx_f1 = tx_f1; f->tab.tx_fs = tx_fs;
+    if (!fsk_reset_state(f) || !f->d_chan.reserve(sizeof(WrChan))) { delete f; return nullptr; }
+    return f;
+}
+
+extern "C" wenet_fsk *wenet_fsk_create(int Fs, int Rs, int M, int tx_f1, int tx_fs) {           // fsk.c:278-398
+    if (tx_f1 <= 0 || tx_fs <= 0) return nullptr;                       // fsk.c:288-289
+    if (!device_ready()) return nullptr;
+    wenet_fsk *f = new wenet_fsk();
+    if (!f->tab.build(Fs, Rs, 8, M, true)) { delete f; return nullptr; }
     f->tab.tx_f1 = tx_f1; f->tab.tx_fs = tx_fs;
     if (!fsk_reset_state(f) || !f->d_chan.reserve(sizeof(WrChan))) { delete f; return nullptr; }
     return f;
@@ -505,6 +546,7 @@ extern "C" long wenet_fsk_demod_stream(wenet_fsk *f, int fmt, const void *raw, l
     memset(&ch, 0, sizeof(ch));
     ch.raw = f->d_raw.p; ch.nsamples = nsamples; ch.fmt = fmt;
     ch.state = f->d_state.as<float>();
+    if (c.big) { if (!f->d_big.reserve((size_t)c.big_bytes)) return -2; ch.big = f->d_big.as<unsigned char>(); }
     ch.sd_out = soft ? f->d_out.as<float>() : nullptr;
     ch.bits_out = soft ? nullptr : f->d_out.as<uint8_t>();
     ch.cap_frames = max_frames;
@@ -758,7 +800,7 @@ struct wenet_rx {
     bool want_trace = false, want_llr = false;
     int nchan = 0, max_pk = 0;
     std::vector<long long> sd_off, cap_frames;           // per channel: float offset into d_sd, frame capacity
-    DevBuf d_states, d_chans, d_dchans, d_dstates, d_sd, d_starts, d_out, d_trace, d_llr, d_raw, d_prof, d_esn0, d_census;
+    DevBuf d_states, d_chans, d_dchans, d_dstates, d_sd, d_starts, d_out, d_trace, d_llr, d_raw, d_prof, d_esn0, d_census, d_big;
     std::vector<unsigned> h_census;
     bool profile = false;
     std::vector<float> h_states;
@@ -851,6 +893,7 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const lon
     if (rx->want_llr && !rx->d_llr.reserve((size_t)nchan * max_pk * WR_NCODE * 4)) return -2;
     rx->profile = getenv("WENET_RX_PROFILE") != nullptr;
     if (rx->profile && !rx->d_prof.reserve((size_t)nchan * 32 * 8)) return -2;
+    if (c.big && !rx->d_big.reserve((size_t)nchan * c.big_bytes)) return -2;           // frame scratch, geometries beyond LDS
     // fresh modem + deframer state per capture
     std::vector<float> st0;
     rx->tab.init_state(st0);
@@ -871,6 +914,7 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const lon
         ch.trace = rx->want_trace ? rx->d_trace.as<float>() + (rx->sd_off[i] / c.Nbits) * WR_TRACE_FLOATS : nullptr;
         ch.prof = rx->profile ? rx->d_prof.as<long long>() + (size_t)i * 32 : nullptr;
         ch.prof2 = rx->profile ? rx->d_prof.as<long long>() + (size_t)i * 32 + 16 : nullptr;
+        ch.big = c.big ? rx->d_big.as<unsigned char>() + (size_t)i * c.big_bytes : nullptr;
         WrDeframeChan &d = dch[i];
         memset(&d, 0, sizeof(d));
         d.sd = ch.sd_out;

@@ -19,13 +19,17 @@ TRACE_FLOATS = 10
 class Fsk:
     """struct FSK* handle."""
 
-    def __init__(self, Fs, Rs, P, M, tx_f1=1200, tx_fs=400):
+    def __init__(self, Fs, Rs, P, M, tx_f1=1200, tx_fs=400, lbr=False):
+        """fsk_create_hbr(Fs, Rs, P, M, tx_f1, tx_fs); lbr=True: fsk_create(Fs, Rs, M, tx_f1, tx_fs) (P is 8 there)."""
         self._L = _lib.load()
-        self._h = self._L.wenet_fsk_create_hbr(Fs, Rs, P, M, tx_f1, tx_fs)
+        if lbr:
+            self._h = self._L.wenet_fsk_create(Fs, Rs, M, tx_f1, tx_fs)
+        else:
+            self._h = self._L.wenet_fsk_create_hbr(Fs, Rs, P, M, tx_f1, tx_fs)
         if not self._h:
-            raise RuntimeError("fsk_create_hbr failed (illegal parameters or no GPU)")
-        self.Fs, self.Rs, self.P, self.M = Fs, Rs, P, M
+            raise RuntimeError("fsk_create%s failed (illegal parameters or no GPU)" % ("" if lbr else "_hbr"))
         info = lambda k: self._L.wenet_fsk_info(self._h, k)
+        self.Fs, self.Rs, self.P, self.M = Fs, Rs, info(4), M
         self.Ndft, self.N, self.Ts, self.Nmem = info(0), info(1), info(2), info(3)
         self.Nsym, self.Nbits, self.nstash = info(5), info(6), info(7)
 

@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libwenet_rx.so")
 
 # every symbol include/wenet_rx.h declares
 EXPORTS = [
-    "wenet_fsk_create_hbr", "wenet_fsk_destroy", "wenet_fsk_set_est_limits", "wenet_fsk_nin",
+    "wenet_fsk_create_hbr", "wenet_fsk_create", "wenet_fsk_destroy", "wenet_fsk_set_est_limits", "wenet_fsk_nin",
     "wenet_fsk_demod", "wenet_fsk_demod_sd", "wenet_fsk_info", "wenet_fsk_demod_stream",
     "wenet_fsk_enable_stats", "wenet_fsk_get_stats",
     "wenet_run_ldpc_decoder", "wenet_sd_to_llr", "wenet_ldpc_decode_batch",
@@ -66,6 +66,7 @@ def load():
     L = C.CDLL(LIB_PATH)
     vp, i, l, ll, f = C.c_void_p, C.c_int, C.c_long, C.c_longlong, C.c_float
     L.wenet_fsk_create_hbr.restype = vp; L.wenet_fsk_create_hbr.argtypes = [i] * 6
+    L.wenet_fsk_create.restype = vp; L.wenet_fsk_create.argtypes = [i] * 5
     L.wenet_fsk_destroy.argtypes = [vp]
     L.wenet_fsk_set_est_limits.argtypes = [vp, i, i]
     L.wenet_fsk_nin.restype = C.c_uint32; L.wenet_fsk_nin.argtypes = [vp]

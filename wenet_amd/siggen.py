@@ -142,7 +142,7 @@ def config_4fsk():
 def config_lbr(M: int = 4, Fs: int = 8000, Rs: int = 100):
     # the fsk_create / `fsk_demod -l` geometry (fsk.c:278-398): one-second frames, tones inside the 800..2500 Hz estimator
     # band and at least 100 Hz apart.  No Wenet framing rides on it (mode is unused).
-    return ModemConfig("lbr", 1, M, Fs, Rs, 1100.0, 270.0)
+    return ModemConfig("lbr", 1, M, Fs, Rs, 1100.0, float(max(270, Rs)))
 
 
 CONFIGS = {"v1": config_v1, "v2": config_v2, "4fsk": config_4fsk}
