@@ -42,22 +42,22 @@ enum { WENET_FRAMING_DRS232 = 1, WENET_FRAMING_WENET_V2 = 2 };
  * ------------------------------------------------------------------------------------------ */
 typedef struct wenet_fsk wenet_fsk;
 
-/* fsk_create_hbr (src/fsk.h:113, src/fsk.c:128-259).  Illegal parameters (the reference's
+/* fsk_create_hbr (src/fsk.h:110, src/fsk.c:128-259).  Illegal parameters (the reference's
  * asserts at fsk.c:137-146) return NULL instead of aborting. */
 wenet_fsk *wenet_fsk_create_hbr(int Fs, int Rs, int P, int M, int tx_f1, int tx_fs);
 /* fsk_create (src/fsk.h:100, src/fsk.c:278-398): the low-rate geometry `fsk_demod -l` selects (src/fsk_demod.c:210-212) --
  * one-second frames (N = Fs, Nsym = Rs), P = 8, 1024-point estimator over 800..2500 Hz.  Illegal parameters (the
  * asserts at fsk.c:286-295) return NULL. */
 wenet_fsk *wenet_fsk_create(int Fs, int Rs, int M, int tx_f1, int tx_fs);
-/* fsk_destroy (src/fsk.h:131) */
+/* fsk_destroy (src/fsk.h:137) */
 void wenet_fsk_destroy(wenet_fsk *fsk);
-/* fsk_set_est_limits (src/fsk.h:126, src/fsk.c:522-528) */
+/* fsk_set_est_limits (src/fsk.h:120, src/fsk.c:522-528) */
 void wenet_fsk_set_est_limits(wenet_fsk *fsk, int fmin, int fmax);
-/* fsk_nin (src/fsk.h:159, src/fsk.c:485-487) */
+/* fsk_nin (src/fsk.h:173, src/fsk.c:485-487) */
 uint32_t wenet_fsk_nin(wenet_fsk *fsk);
-/* fsk_demod (src/fsk.h:175): one modem frame of exactly wenet_fsk_nin() samples -> Nbits hard bits */
+/* fsk_demod (src/fsk.h:184): one modem frame of exactly wenet_fsk_nin() samples -> Nbits hard bits */
 void wenet_fsk_demod(wenet_fsk *fsk, uint8_t rx_bits[], const wenet_comp fsk_in[]);
-/* fsk_demod_sd (src/fsk.h:186): -> Nbits float32 soft decisions */
+/* fsk_demod_sd (src/fsk.h:194): -> Nbits float32 soft decisions */
 void wenet_fsk_demod_sd(wenet_fsk *fsk, float rx_sd[], const wenet_comp fsk_in[]);
 
 /* struct FSK fields the callers read (src/fsk.h:43-90): 0 Ndft 1 N 2 Ts 3 Nmem 4 P 5 Nsym 6 Nbits
@@ -73,7 +73,7 @@ int wenet_fsk_info(wenet_fsk *fsk, int what);
 long wenet_fsk_demod_stream(wenet_fsk *fsk, int fmt, const void *raw, long nsamples, int soft,
                             void *out, long cap_frames, long *consumed, float *trace);
 
-/* modem statistics of the last demodulated frame = fsk_get_demod_stats (src/fsk.h:202,
+/* modem statistics of the last demodulated frame = fsk_get_demod_stats (src/fsk.h:130,
  * src/fsk.c:496-517) reduced to what src/fsk_demod.c:351-392 prints. */
 typedef struct {
     float snr_est;              /* "EbNodB" */
