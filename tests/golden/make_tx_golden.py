@@ -5,6 +5,7 @@ Run in the development container (needs /root/reference):
 
   * parity     tx/ldpc_enc.c `encode` -- compiled unmodified into oracle/_ref/ldpc_enc.so by
                `make -C oracle ref` exactly as its own header says -- on random 258-byte blocks
+  * hrow_txt   tx/Hrow2064.txt, the encoder's table of the parity-check rows (data file of the reference)
   * noise      benchmarking/generate_lowsnr.py `calculate_variance` + `add_noise`, imported as a module,
                driven by numpy's legacy global generator with a fixed seed
 
@@ -56,7 +57,10 @@ def main():
     var = gl.calculate_variance(x, -100.0)
     np.random.seed(777)
     y = gl.add_noise(x, variance=var, baud_rate=cfg.Rs, ebno=8.0, fs=cfg.Fs)
-    np.savez_compressed(os.path.join(HERE, "tx_golden.npz"), blocks=blocks, parity=par,
+    # the encoder's own table of the code (tx/Hrow2064.txt: 516 rows x 12 one-based column indices, row-major), to be held
+    # against the decoder's H_rows that the kernels were built from
+    hrow = np.array([int(t) for t in open(os.path.join(REF, "tx", "Hrow2064.txt")).read().replace(",", " ").split()], np.int16).reshape(516, 12)
+    np.savez_compressed(os.path.join(HERE, "tx_golden.npz"), blocks=blocks, parity=par, hrow_txt=hrow,
                         noise_bits=bits, noise_in=x, noise_var=np.float64(var), noise_seed=np.int32(777),
                         noise_ebno=np.float64(8.0), noise_out=y)
     print("parity ones per block:", par.sum(axis=1), "noise var", var, "max|y|", np.abs(y).max())

@@ -65,6 +65,13 @@ def test_parity_matches_reference_encoder_golden():
         assert (pb == par).all()
 
 
+def test_encoder_table_equals_decoder_table():
+    """tx/Hrow2064.txt (encoder, row-major) == src/H2064_516_sparse.h H_rows (decoder, column-major) == the table the
+    kernels and the transmitter of this repository use."""
+    g = np.load(GOLD)
+    assert (g["hrow_txt"].astype(np.int64) - 1 == siggen.h_rows()).all()
+
+
 def test_parity_matches_reference_encoder_live():
     path = os.path.join(ol.REF_DIR, "ldpc_enc.so")
     if not os.path.exists(path):
