@@ -136,3 +136,28 @@ def test_testframe_mode_matches_reference(flags, tmp_path):
     if "--stats=50" in flags:
         last = json.loads([l for l in my_err.splitlines() if l.startswith("{")][-1])
         assert last["frames"] >= 40 and last["bits"] == 100 * last["frames"]
+
+
+def test_sigterm_exits_zero():
+    """src/fsk_demod.c:47-52,264: SIGTERM while waiting for input ends the process with exit status 0; what was
+    demodulated before has been written (stdout is flushed per block)."""
+    import signal
+    import time
+    cfg = siggen.config_v2()
+    raw, _ = siggen.make_capture(cfg, 2, 12.0, seed=3)
+    p = subprocess.Popen([f"{BIN}/fsk_demod", "--cu8", "-s", str(cfg.M), str(cfg.Fs), str(cfg.Rs), "-", "-"],
+                         stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+    p.stdin.write(raw.tobytes()); p.stdin.flush()
+    want = ol.oracle_demod(raw, "cu8", cfg.Fs, cfg.Rs, cfg.M)[0].tobytes()
+    got = b""
+    t0 = time.time()
+    os.set_blocking(p.stdout.fileno(), False)
+    while len(got) < len(want) and time.time() - t0 < 60:
+        chunk = p.stdout.read()
+        if chunk:
+            got += chunk
+        else:
+            time.sleep(0.05)
+    p.send_signal(signal.SIGTERM)                         # stdin still open: the process is blocked in read()
+    assert p.wait(timeout=30) == 0
+    assert got == want

@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_sq -o s -- python $GRAFT_REPO_ROOT/bench.py --captures 512 --steps 1 --warmup 0 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/pmc_sq.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_sq -o s -- python $GRAFT_REPO_ROOT/bench.py --captures ${1:-3072} --steps 1 --warmup 0 --no-cpu-baseline --no-single-stream > $GRAFT_REPO_ROOT/gpurun_out/pmc_sq.log 2>&1
 python - <<'PY'
 import csv, glob, os
 root = os.environ["GRAFT_REPO_ROOT"] + "/gpurun_out"
