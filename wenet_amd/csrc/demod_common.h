@@ -46,6 +46,21 @@ __device__ __forceinline__ float2 load_sample(const void *raw, int fmt, long lon
 // packed-f32 forms (v_pk_mul_f32 / v_pk_add_f32): two independent IEEE operations per instruction,
 // no fusion -- a lone wavefront is instruction-issue bound, so halving the instruction count matters.
 typedef float v2f __attribute__((ext_vector_type(2)));
+// One NCO step with the real and imaginary parts of a phasor in neighbouring lanes (even lane: re, odd lane: im):
+//   re' = re*d.x - im*d.y      im' = im*d.x + re*d.y     ==  own*k1 + partner*k2,  k1 = d.x,  k2 = -d.y (re lane) / +d.y (im lane)
+// -- the same two products and one sum per component as cmul_pk, each rounded on its own (x - y == x + (-y) exactly).
+// Three plain VALU operations, the partner's value read through a DPP operand; s_nop 0 fills the second wait state a
+// DPP read needs after a VALU write of the same register.  Half the SIMD time of the packed form, but a longer dependent path.
+__device__ __forceinline__ float nco_step_split(float own, float k1, float k2) {
+    float r, t1, t2;
+    asm("v_mul_f32 %1, %3, %4\n\t"
+        "s_nop 0\n\t"
+        "v_mul_f32_dpp %2, %3, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32 %0, %1, %2"
+        : "=v"(r), "=&v"(t1), "=&v"(t2)
+        : "v"(own), "v"(k1), "v"(k2));
+    return r;
+}
 __device__ __forceinline__ v2f cmul_pk(v2f a, v2f b) {
     // (a.x*b.x - a.y*b.y, a.x*b.y + a.y*b.x), each product and each sum rounded separately (no FMA):
     //   t1 = (a.x*b.x, a.y*b.x)   t2 = (a.y*b.y, a.x*b.y)   r = (t1.x - t2.x, t1.y + t2.y)

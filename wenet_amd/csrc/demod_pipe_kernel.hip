@@ -46,6 +46,65 @@ __device__ __forceinline__ void dsp_barrier(int *cnt, int target, int lane) {
 
 enum { CT_NIN_NEXT = 0, CT_CNT = 1, CT_FBIN = 4 /* [4 frames][4 tones] */, CT_INTS = 24 };
 
+
+// NCO chain of one frame with the real / imaginary part of tone m in lanes 2m / 2m+1 (nco_step_split): the batch form of
+// C(j) below -- same statements, half the SIMD time per step, a longer dependent path.  Out of line so that the kernel's
+// register allocation (80 VGPRs in the three-captures-per-CU variant) is not disturbed by it.
+typedef __attribute__((address_space(3))) float lds_f32;
+typedef __attribute__((address_space(3))) int lds_i32;
+__device__ __forceinline__ void nco_chain_split(int j, int nin_j, int lane, int M, int N, int NH, int Nmem, int L, lds_i32 *CT, lds_f32 *PHE,
+                                             lds_f32 *CKb, lds_f32 *CKD, const lds_f32 *dphi_t, const float *bin_freq, const float2 *backoff_tab) {
+    if (lane >= 2 * M) return;
+    const int m = lane >> 1, part = lane & 1;
+    const int nold = Nmem - nin_j;
+    int bc = CT[CT_FBIN + (j & 3) * 4 + m];
+    int bp = CT[CT_FBIN + ((j + 3) & 3) * 4 + m];
+    const int bp0 = CT[CT_FBIN + ((j + 3) & 3) * 4 + 0];
+    if (bin_freq[bp0] < 1.0f) bp = bc;                                   // first run (fsk.c:750-753)
+    const int ncase = (nin_j < N) ? 0 : ((nin_j > N) ? 2 : 1);
+    const float2 bo = backoff_tab[ncase * NH + bp];
+    const lds_f32 *pc = PHE + (((j + 2) % 3) * 4 + m) * 2;
+    const v2f phi0 = cmul_pk((v2f){bo.x, bo.y}, (v2f){pc[0], pc[1]});    // fsk.c:758-759 (both lanes of the pair)
+    float own = part ? phi0.y : phi0.x;
+    float dx = dphi_t[2 * bp], dy = dphi_t[2 * bp + 1];
+    float k1 = dx, k2 = part ? dy : -dy;
+    lds_f32 *ckA = CKb + ((((j & 1) * 2 + 0) * M + m) * WP_CKROW) * 2 + part;
+    lds_f32 *ckB = CKb + ((((j & 1) * 2 + 1) * M + m) * WP_CKROW) * 2 + part;
+    CKD[(((j & 1) * 2 + 0) * M + m) * 2 + part] = part ? dy : dx;
+    int s = 0, c = 0;
+    for (; s + WP_CK <= nold; s += WP_CK, c++) {
+        ckA[2 * c] = own;
+#pragma unroll
+        for (int u = 0; u < WP_CK; u++) own = nco_step_split(own, k1, k2);
+    }
+    if (s < nold) { ckA[2 * c] = own; for (; s < nold; s++) own = nco_step_split(own, k1, k2); }
+    {
+        const float oth = __shfl_xor(own, 1, 64);
+        const float re = part ? oth : own, im = part ? own : oth;
+        const float av = sqrtf(re * re + im * im);                       // comp_normalize (fsk.c:787)
+        own = own / av;
+        dx = dphi_t[2 * bc]; dy = dphi_t[2 * bc + 1];
+        k1 = dx; k2 = part ? dy : -dy;
+    }
+    CKD[(((j & 1) * 2 + 1) * M + m) * 2 + part] = part ? dy : dx;
+    c = 0;
+    for (; s + 4 * WP_CK <= L; s += 4 * WP_CK, c += 4) {                     // four checkpoints per trip: a taken branch costs ~16 cycles
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            ckB[2 * (c + k)] = own;
+#pragma unroll
+            for (int u = 0; u < WP_CK; u++) own = nco_step_split(own, k1, k2);
+        }
+    }
+    for (; s + WP_CK <= L; s += WP_CK, c++) {
+        ckB[2 * c] = own;
+#pragma unroll
+        for (int u = 0; u < WP_CK; u++) own = nco_step_split(own, k1, k2);
+    }
+    if (s < L) { ckB[2 * c] = own; for (; s < L; s++) own = nco_step_split(own, k1, k2); }
+    PHE[((j % 3) * 4 + m) * 2 + part] = own;                             // un-normalised (fsk.c:846)
+}
+
 }  // namespace
 
 // RAW: every capture of the launch is cu8 -> the sample ring keeps the raw byte pairs (2 B instead of 8 B per
@@ -230,6 +289,12 @@ __global__ __launch_bounds__(WP_THREADS, RAW ? 6 : 5) void wenet_demod_pipe_kern
 
     // C(j): NCO phasor chain of frame j (one wavefront, lanes 0..M-1 carry one tone each)
     auto chain = [&](int j, int nin_j) {
+        if constexpr (RAW) {                                             // the raw-ring variant only runs batches: lane-split form (less SIMD time)
+            nco_chain_split(j, nin_j, lane, M, N, NH, Nmem, L, (lds_i32 *)CT, (lds_f32 *)PHE, (lds_f32 *)CKb, (lds_f32 *)CKD,
+                            (const lds_f32 *)dphi_t, cfg.bin_freq, cfg.backoff_tab);
+            wave_sync();
+            return;
+        } else {
         if (lane < M) {
             const int nold = Nmem - nin_j;
             int bc = CT[CT_FBIN + (j & 3) * 4 + lane];
@@ -279,6 +344,7 @@ __global__ __launch_bounds__(WP_THREADS, RAW ? 6 : 5) void wenet_demod_pipe_kern
             PHE[(j % 3) * 4 + lane] = make_float2(phi.x, phi.y);        // un-normalised (fsk.c:846)
         }
         wave_sync();
+        }
     };
 
     // D(j): mix + integrate + timing products of frame j.  Waves 3..7 (t = D thread index).
@@ -339,7 +405,7 @@ __global__ __launch_bounds__(WP_THREADS, RAW ? 6 : 5) void wenet_demod_pipe_kern
                 for (int j = lane; j < NI / TS; j += 64) {
                     const int i = j * TS + r;
                     float ft1 = 0.f;
-#pragma unroll
+#pragma unroll 1
                     for (int m = 0; m < M; m++) {
                         constexpr int R = (TS - O) % TS;                    // this residue class (wave-uniform, == r)
                         constexpr bool PAD = (TS == 8);                     // rows padded by one element per TS samples (see the mix stage)
@@ -666,12 +732,19 @@ __global__ __launch_bounds__(WP_THREADS, RAW ? 6 : 5) void wenet_demod_pipe_kern
     while (off + nin <= C.nsamples && frames < C.cap_frames) {
         if (PROF) pr_t0 = (long long)__builtin_readcyclecounter();
         const long long off1 = off + nin;                                // true start of frame k+1
+#ifdef WR_DBG_SKIP                                                       // development build only (tools/gpu_stage_cost.sh): leave stages out
+        const int skip = cfg.dbg_skip;                                   // 1 chain, 2 estimator, 4 D, 8 T -- results are garbage by construction
+#else
+        constexpr int skip = 0;
+#endif
         if (wave == 0) {
-            chain(kf + 2, N);                                            // C(k+2), speculative
+            if (!(skip & 1)) chain(kf + 2, N);                           // C(k+2), speculative
         } else if (wave == 1) {
-            estimate(kf + 3, off1 + 2LL * N, N);                         // E(k+3), speculative
+            if (!(skip & 2)) estimate(kf + 3, off1 + 2LL * N, N);        // E(k+3), speculative
         } else if (wave == 2) {
-            tstage(kf, frames, nin);                                     // T(k)
+            if (!(skip & 8)) tstage(kf, frames, nin);                    // T(k)
+            else if (lane == 0) CT[CT_NIN_NEXT] = N;
+        } else if (skip & 4) {
         } else {
             // stage the next nin samples into the ring, issue the following prefetch
 #pragma unroll

@@ -50,10 +50,13 @@ struct WrDemodCfg {
     int off_TP, seq_stream;              // sequential kernel: separate timing-product row and the streamed frame body (8 waves)
     int off_CK, off_CKD, ckrow;          // sequential kernel: phasor checkpoints [2 segments][M][ckrow], NCO steps [2][M]
     int tables_in_lds, off_TW, off_HANN, off_SRC, off_PFT, off_DPHI;
+    int dbg_skip;                        // development only (WENET_RX_DBG_SKIP): stages of the pipelined kernel left out to count the others' instructions
     int big, big_bytes;                  // sequential kernel, frame geometries beyond LDS: off_X/off_PH/off_FI/off_CK/off_TP are offsets into
                                          // the capture's global scratch block (WrChan::big, big_bytes each)
     // LDS carve-up of the pipelined kernel (demod_pipe_kernel.hip); pipe_ok = configuration fits
     int pipe_ok, p_ring, p_lds_bytes, chain_prio;
+    int p_chain_split;                   // NCO chain with re/im in separate lanes (plain mul/add + one DPP operand per step instead of three packed ops:
+                                         // half the SIMD time, more latency): batch launches
     int p_tsum_split;                    // timing sum with re/im in separate lanes and plain adds (less SIMD time, more latency): batch launches
     int p_raw;                           // this copy of the configuration carries the raw-cu8-ring layout (3 captures per CU)
     int p_off_CK, p_off_CKD, p_off_TP;

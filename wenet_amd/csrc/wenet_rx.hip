@@ -264,6 +264,7 @@ struct DemodTables {
             // s_setprio of the serial waves: chain | T << 2 | estimator << 4 (0..3 each); default: all three one step above the
             // parallel D waves, so that they win VALU arbitration on the SIMDs they share (-10 % at two captures per CU;
             // ranking the three against each other measured no better)
+            cfg.dbg_skip = getenv("WENET_RX_DBG_SKIP") ? atoi(getenv("WENET_RX_DBG_SKIP")) : 0;   // development: results are garbage when set
             cfg.chain_prio = getenv("WENET_RX_CHAIN_PRIO") ? atoi(getenv("WENET_RX_CHAIN_PRIO")) : (1 | 1 << 2 | 1 << 4);
             cfg.pipe_ok = (fits && cfg.p_lds_bytes <= 80 * 1024 && getenv("WENET_RX_NO_PIPE") == nullptr) ? 1 : 0;
         }
@@ -943,6 +944,7 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const lon
     const bool want_raw = (fmt == WENET_FMT_CU8) && (nchan > 2 * wenet_rx_device_info(1) || getenv("WENET_RX_FORCE_RAW") != nullptr);
     WrDemodCfg launch_cfg = want_raw ? rx->tab.raw_cfg() : rx->tab.cfg;
     // more captures than CUs: SIMD time matters more than the latency of one frame (see tstage in demod_pipe_kernel.hip)
+    launch_cfg.p_chain_split = getenv("WENET_RX_CHAIN_SPLIT") ? atoi(getenv("WENET_RX_CHAIN_SPLIT")) : ((nchan > wenet_rx_device_info(1)) ? 1 : 0);
     launch_cfg.p_tsum_split = getenv("WENET_RX_TSUM_SPLIT") ? atoi(getenv("WENET_RX_TSUM_SPLIT")) : ((nchan > wenet_rx_device_info(1)) ? 1 : 0);
     // WENET_RX_PROFILE: 1 = instrumented pipelined kernel, 2 = instrumented one-wave sequential kernel, 3 = production
     // kernels with the per-channel stamp buffer attached (streamed sequential kernel: cycle stamps of one frame)
