@@ -1,6 +1,7 @@
 # development aid: instruction counts of the pipelined demod kernel with one stage left out at a time (WENET_RX_DBG_SKIP:
 # 1 chain, 2 estimator, 4 mix+integrate waves, 8 timing/decision wave).  Results of those runs are garbage by construction;
-# the differences to the full run are the stages' shares.
+# the differences to the full run are the stages' shares.  Needs a development build of the library:
+#   make -C wenet_amd/csrc clean all EXTRA=-DWR_DBG_SKIP   (production builds compile the switch out)
 cd /tmp && export TMPDIR=/tmp
 for skip in 0 1 2 4 8 15; do
   export WENET_RX_DBG_SKIP=$skip
