@@ -126,7 +126,9 @@ __global__ __launch_bounds__(WP_THREADS, RAW ? 6 : 5) void wenet_demod_pipe_kern
     float2 *CKb = (float2 *)(smem + cfg.p_off_CK);    // [2 frames][2 segments][M][WP_CKROW] phasor checkpoints
     float2 *CKD = (float2 *)(smem + cfg.p_off_CKD);   // [2 frames][2 segments][M] NCO step of each segment
     float2 *FIb = (float2 *)(smem + cfg.p_off_FI);    // [2][M][NI]    integrator outputs of frame j in slot j&1
-    float2 *TPb = (float2 *)(smem + cfg.p_off_TP);    // [2][NI]       timing products of frame j in slot j&1
+    float2 *TPb = (float2 *)(smem + cfg.p_off_TP);    // [2][NIq]      timing products of frame j in slot j&1: (re, im) pairs, or -- for the
+                                                      //               lane-split timing sum of batch launches -- a row of re and a row of im
+    const int NIq = (cfg.NI + 3) & ~3;                // products per row (16-byte rows), pairs per slot
     float2 *FB = (float2 *)(smem + cfg.p_off_FB);     // [Ndft]
     float  *FEr = (float *)(smem + cfg.p_off_FE);     // [4][Ndft/2]   smoothed spectrum after frame j in slot j&3
     float  *FW = (float *)(smem + cfg.p_off_FW);      // [Ndft/2]
@@ -354,7 +356,8 @@ __global__ __launch_bounds__(WP_THREADS, RAW ? 6 : 5) void wenet_demod_pipe_kern
         const int nold = Nmem - nin_j;
         float2 *PH = DCb;
         float2 *FI = FIb + (j & 1) * M * NI;
-        float2 *TP = TPb + (j & 1) * NI;
+        float2 *TP = TPb + (j & 1) * NIq;
+        float *TPs = (float *)TP;                                        // split layout: TPs[i] = re, TPs[NIq + i] = im
         const long long src0 = off_j - nold;                             // chain step s <-> absolute sample src0 + s
         const bool fastI = (q == 1 && (Ts == 10 || Ts == 8) && NI % Ts == 0);                // fast integrator path
         const int padTs = (fastI && Ts == 8) ? 8 : 0;                                          // ... with padded rows (Ts = 8 only: at Ts = 10
@@ -420,7 +423,8 @@ __global__ __launch_bounds__(WP_THREADS, RAW ? 6 : 5) void wenet_demod_pipe_kern
                         ft1 += (acc.x * acc.x) + (acc.y * acc.y);           // fsk.c:862-868
                     }
                     const float2 pf = RAW ? cfg.phi_ft[i] : pft_t[i];
-                    TP[i] = make_float2(ft1 * pf.x, ft1 * pf.y);
+                    if (cfg.p_tsum_split) { TPs[i] = ft1 * pf.x; TPs[NIq + i] = ft1 * pf.y; }
+                    else TP[i] = make_float2(ft1 * pf.x, ft1 * pf.y);
                 }
             };
             auto classes = [&](auto TSC) {
@@ -480,7 +484,8 @@ __global__ __launch_bounds__(WP_THREADS, RAW ? 6 : 5) void wenet_demod_pipe_kern
                 ft1 += (v.x * v.x) + (v.y * v.y);
             }
             const float2 pf = RAW ? cfg.phi_ft[i] : pft_t[i];
-            TP[i] = make_float2(ft1 * pf.x, ft1 * pf.y);
+            if (cfg.p_tsum_split) { TPs[i] = ft1 * pf.x; TPs[NIq + i] = ft1 * pf.y; }
+            else TP[i] = make_float2(ft1 * pf.x, ft1 * pf.y);
         }
         wave_sync();
     };
@@ -490,45 +495,41 @@ __global__ __launch_bounds__(WP_THREADS, RAW ? 6 : 5) void wenet_demod_pipe_kern
     float ppm = hdr->ppm;
     auto tstage = [&](int kf, long long frames, int nin_cur) {
         const float2 *FI = FIb + (kf & 1) * M * NI;
-        const float2 *TP = TPb + (kf & 1) * NI;
+        const float2 *TP = TPb + (kf & 1) * NIq;
         float tcr, tci;
         {
             if (cfg.p_tsum_split) {
                 // Real part in even lanes, imaginary part in odd lanes: 490 dependent PLAIN adds per frame instead of packed
                 // ones (a packed-f32 op occupies the SIMD twice as long, and this wave shares its SIMD with other captures).
-                const float *TPf = (const float *)TP + (lane & 1);
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                const float *TPf = (const float *)TP + (lane & 1) * NIq;    // this lane's row (re or im), four products per 128-bit LDS read
+                const v4f *T4 = (const v4f *)TPf;
                 float acc = 0.f;
-                float bufA[8], bufB[8];                                      // ping-pong: loads of one batch fly while the other is summed
+                v4f bufA[2], bufB[2];                                        // ping-pong: loads of one batch fly while the other is summed
                 int i = 0;
+#define WP_ADD8(buf) do { acc = acc + buf[0].x; acc = acc + buf[0].y; acc = acc + buf[0].z; acc = acc + buf[0].w; \
+                          acc = acc + buf[1].x; acc = acc + buf[1].y; acc = acc + buf[1].z; acc = acc + buf[1].w; } while (0)
                 if (NI >= 8) {
-#pragma unroll
-                    for (int u = 0; u < 8; u++) bufA[u] = TPf[2 * u];
+                    bufA[0] = T4[0]; bufA[1] = T4[1];
                     for (i = 8; i + 16 <= NI; i += 16) {
-#pragma unroll
-                        for (int u = 0; u < 8; u++) bufB[u] = TPf[2 * (i + u)];
-#pragma unroll
-                        for (int u = 0; u < 8; u++) acc = acc + bufA[u];
+                        bufB[0] = T4[(i >> 2)]; bufB[1] = T4[(i >> 2) + 1];
+                        WP_ADD8(bufA);
                         asm volatile("" : "+v"(acc) : : "memory");           // keep the reload of A behind its last use (else the
-#pragma unroll                                                           // scheduler hoists it and pays register copies per round)
-                        for (int u = 0; u < 8; u++) bufA[u] = TPf[2 * (i + 8 + u)];
-#pragma unroll
-                        for (int u = 0; u < 8; u++) acc = acc + bufB[u];
+                        bufA[0] = T4[(i >> 2) + 2]; bufA[1] = T4[(i >> 2) + 3];   // scheduler hoists it and pays register copies per round)
+                        WP_ADD8(bufB);
                         asm volatile("" : "+v"(acc) : : "memory");
                     }
                     if (i + 8 <= NI) {
-#pragma unroll
-                        for (int u = 0; u < 8; u++) bufB[u] = TPf[2 * (i + u)];
-#pragma unroll
-                        for (int u = 0; u < 8; u++) acc = acc + bufA[u];
-#pragma unroll
-                        for (int u = 0; u < 8; u++) acc = acc + bufB[u];
+                        bufB[0] = T4[(i >> 2)]; bufB[1] = T4[(i >> 2) + 1];
+                        WP_ADD8(bufA);
+                        WP_ADD8(bufB);
                         i += 8;
                     } else {
-#pragma unroll
-                        for (int u = 0; u < 8; u++) acc = acc + bufA[u];
+                        WP_ADD8(bufA);
                     }
                 }
-                for (; i < NI; i++) acc = acc + TPf[2 * i];
+#undef WP_ADD8
+                for (; i < NI; i++) acc = acc + TPf[i];
                 tcr = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(acc), 0));
                 tci = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(acc), 1));
             } else {

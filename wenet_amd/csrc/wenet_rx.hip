@@ -112,7 +112,7 @@ struct DemodTables {
             c.p_off_CK = t;   t = align16(t + 2 * 2 * M * 80 * 8);      // WP_CKROW = 80
             c.p_off_CKD = t;  t = align16(t + 2 * 2 * M * 8);
             c.p_off_FI = t;   t = align16(t + 2 * M * c.NI * 8);
-            c.p_off_TP = t;   t = align16(t + 2 * c.NI * 8);
+            c.p_off_TP = t;   t = align16(t + 2 * 2 * ((c.NI + 3) & ~3) * 4);   // [2 frames][re row | im row], rows padded to 16 bytes (lane-split timing sum)
             c.p_off_FB = t;   t = align16(t + Ndft * 8);
             c.p_off_FE = t;   t = align16(t + 4 * NH * 4);
             c.p_off_FW = t;   t = align16(t + NH * 4);
