@@ -395,7 +395,13 @@ __global__ __launch_bounds__(WP_THREADS, RAW ? 6 : 5) void wenet_demod_pipe_kern
                 }
             }
                 };
+#ifdef WR_DBG_SKIP
+        if (!(cfg.dbg_skip & 16)) {
+#endif
         if (padTs) mix(std::integral_constant<int, 8>()); else mix(std::integral_constant<int, 0>());
+#ifdef WR_DBG_SKIP
+        }
+#endif
         dsp_barrier(&CT[CT_CNT], WP_DSP_WAVES * (++dsp_phase), lane);
         if (fastI) {
             // Fast path (one sample per integrator step).  The Ts circular-buffer slots are summed in SLOT order
@@ -437,6 +443,9 @@ __global__ __launch_bounds__(WP_THREADS, RAW ? 6 : 5) void wenet_demod_pipe_kern
                     }
                 }
             };
+#ifdef WR_DBG_SKIP
+            if (!(cfg.dbg_skip & 32))
+#endif
             if (Ts == 10) classes(std::integral_constant<int, 10>()); else classes(std::integral_constant<int, 8>());
             wave_sync();
             return;
@@ -748,6 +757,9 @@ __global__ __launch_bounds__(WP_THREADS, RAW ? 6 : 5) void wenet_demod_pipe_kern
         } else if (skip & 4) {
         } else {
             // stage the next nin samples into the ring, issue the following prefetch
+#ifdef WR_DBG_SKIP
+            if (!(cfg.dbg_skip & 64)) {
+#endif
 #pragma unroll
             for (int k = 0; k < WP_KP; k++) { const int i = t + WP_DSP_THREADS * k; if (i < nin) ring_put_raw(RIDX(filled + i), pre[k], C.fmt); }
             {
@@ -755,6 +767,9 @@ __global__ __launch_bounds__(WP_THREADS, RAW ? 6 : 5) void wenet_demod_pipe_kern
 #pragma unroll
                 for (int k = 0; k < WP_KP; k++) { long long i = nf + t + WP_DSP_THREADS * k; pre[k] = load_raw(C.raw, C.fmt, i < last ? i : last); }
             }
+#ifdef WR_DBG_SKIP
+            }
+#endif
             dstage(kf + 1, off1, N);                                     // D(k+1), speculative
         }
         if (PROF) pr_busy += (long long)__builtin_readcyclecounter() - pr_t0;
