@@ -55,8 +55,6 @@ struct WrDemodCfg {
                                          // the capture's global scratch block (WrChan::big, big_bytes each)
     // LDS carve-up of the pipelined kernel (demod_pipe_kernel.hip); pipe_ok = configuration fits
     int pipe_ok, p_ring, p_lds_bytes, chain_prio;
-    int p_chain_split;                   // NCO chain with re/im in separate lanes (plain mul/add + one DPP operand per step instead of three packed ops:
-                                         // half the SIMD time, more latency): batch launches
     int p_tsum_split;                    // timing sum with re/im in separate lanes and plain adds (less SIMD time, more latency): batch launches
     int p_raw;                           // this copy of the configuration carries the raw-cu8-ring layout (3 captures per CU)
     int p_off_CK, p_off_CKD, p_off_TP;

@@ -944,7 +944,6 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const lon
     const bool want_raw = (fmt == WENET_FMT_CU8) && (nchan > 2 * wenet_rx_device_info(1) || getenv("WENET_RX_FORCE_RAW") != nullptr);
     WrDemodCfg launch_cfg = want_raw ? rx->tab.raw_cfg() : rx->tab.cfg;
     // more captures than CUs: SIMD time matters more than the latency of one frame (see tstage in demod_pipe_kernel.hip)
-    launch_cfg.p_chain_split = getenv("WENET_RX_CHAIN_SPLIT") ? atoi(getenv("WENET_RX_CHAIN_SPLIT")) : ((nchan > wenet_rx_device_info(1)) ? 1 : 0);
     launch_cfg.p_tsum_split = getenv("WENET_RX_TSUM_SPLIT") ? atoi(getenv("WENET_RX_TSUM_SPLIT")) : ((nchan > wenet_rx_device_info(1)) ? 1 : 0);
     // WENET_RX_PROFILE: 1 = instrumented pipelined kernel, 2 = instrumented one-wave sequential kernel, 3 = production
     // kernels with the per-channel stamp buffer attached (streamed sequential kernel: cycle stamps of one frame)
