@@ -118,6 +118,7 @@ __global__ __launch_bounds__(WP_THREADS, RAW ? 6 : 5) void wenet_demod_pipe_kern
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const WrChan C = chans[ch];
+    const int fmt_k = RAW ? (int)WR_FMT_CU8 : C.fmt;                  // the raw-ring variant only ever sees cu8: the format switches fold away
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float2 *XR = (float2 *)(smem + cfg.p_off_XR);     // [ring]        sample ring, index (abs + nstash) & mask
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(WP_THREADS, RAW ? 6 : 5) void wenet_demod_pipe_kern
     {
         const long long last = C.nsamples - 1;
         for (long long i = tid; i < 4LL * Nmax; i += WP_THREADS)
-            if (C.nsamples > 0) ring_put_raw(RIDX(i), load_raw(C.raw, C.fmt, i < last ? i : last), C.fmt);
+            if (C.nsamples > 0) ring_put_raw(RIDX(i), load_raw(C.raw, fmt_k, i < last ? i : last), fmt_k);
             else ring_put_f(RIDX(i), make_float2(0.f, 0.f));
     }
     long long filled = 4LL * Nmax;                    // ring holds absolute samples [off - nstash, filled)
@@ -733,7 +734,7 @@ __global__ __launch_bounds__(WP_THREADS, RAW ? 6 : 5) void wenet_demod_pipe_kern
     if (any && wave >= 3) {
         const long long last = C.nsamples - 1;
 #pragma unroll
-        for (int k = 0; k < WP_KP; k++) { long long i = filled + t + WP_DSP_THREADS * k; pre[k] = load_raw(C.raw, C.fmt, i < last ? i : last); }
+        for (int k = 0; k < WP_KP; k++) { long long i = filled + t + WP_DSP_THREADS * k; pre[k] = load_raw(C.raw, fmt_k, i < last ? i : last); }
     }
 
     // ================================ frame loop ===============================================
@@ -798,10 +799,10 @@ __global__ __launch_bounds__(WP_THREADS, RAW ? 6 : 5) void wenet_demod_pipe_kern
                        if (!(skip & 64)) {
                            // stage the next nin samples into the ring, issue the following prefetch
 #pragma unroll
-                           for (int k = 0; k < WP_KP; k++) { const int i = t + WP_DSP_THREADS * k; if (i < nin) ring_put_raw(RIDX(filled + i), pre[k], C.fmt); }
+                           for (int k = 0; k < WP_KP; k++) { const int i = t + WP_DSP_THREADS * k; if (i < nin) ring_put_raw(RIDX(filled + i), pre[k], fmt_k); }
                            const long long nf = filled + nin, last = C.nsamples - 1;
 #pragma unroll
-                           for (int k = 0; k < WP_KP; k++) { long long i = nf + t + WP_DSP_THREADS * k; pre[k] = load_raw(C.raw, C.fmt, i < last ? i : last); }
+                           for (int k = 0; k < WP_KP; k++) { long long i = nf + t + WP_DSP_THREADS * k; pre[k] = load_raw(C.raw, fmt_k, i < last ? i : last); }
                        }
                        dstage(kf + 1, off1, N);                          // D(k+1), speculative
                    },
@@ -826,11 +827,11 @@ __global__ __launch_bounds__(WP_THREADS, RAW ? 6 : 5) void wenet_demod_pipe_kern
             if (!(cfg.dbg_skip & 64)) {
 #endif
 #pragma unroll
-            for (int k = 0; k < WP_KP; k++) { const int i = t + WP_DSP_THREADS * k; if (i < nin) ring_put_raw(RIDX(filled + i), pre[k], C.fmt); }
+            for (int k = 0; k < WP_KP; k++) { const int i = t + WP_DSP_THREADS * k; if (i < nin) ring_put_raw(RIDX(filled + i), pre[k], fmt_k); }
             {
                 const long long nf = filled + nin, last = C.nsamples - 1;
 #pragma unroll
-                for (int k = 0; k < WP_KP; k++) { long long i = nf + t + WP_DSP_THREADS * k; pre[k] = load_raw(C.raw, C.fmt, i < last ? i : last); }
+                for (int k = 0; k < WP_KP; k++) { long long i = nf + t + WP_DSP_THREADS * k; pre[k] = load_raw(C.raw, fmt_k, i < last ? i : last); }
             }
 #ifdef WR_DBG_SKIP
             }
