@@ -361,8 +361,8 @@ __global__ __launch_bounds__(WP_THREADS, RAW ? 6 : 5) void wenet_demod_pipe_kern
         float *TPs = (float *)TP;                                        // split layout: TPs[i] = re, TPs[NIq + i] = im
         const long long src0 = off_j - nold;                             // chain step s <-> absolute sample src0 + s
         const bool fastI = (q == 1 && (Ts == 10 || Ts == 8) && NI % Ts == 0);                // fast integrator path
-        const int padTs = (fastI && Ts == 8) ? 8 : 0;                                          // ... with padded rows (Ts = 8 only: at Ts = 10
-                                                                                               // the conflicts are mild and the padding arithmetic costs more)
+        const int padTs = fastI ? Ts : 0;                                          // ... with padded rows: one element after every Ts samples, so that the
+                                                                                   // integrator's lane stride is Ts+1 elements (odd: all LDS banks) instead of Ts
         auto mix = [&](auto PADC) {
             constexpr int PADTS = decltype(PADC)::value;             // 0: rows unpadded; 8: one pad element after every 8 samples
             // one D thread per (tone, checkpoint): replay the <= WP_CK chain steps that follow the checkpoint
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(WP_THREADS, RAW ? 6 : 5) void wenet_demod_pipe_kern
 #ifdef WR_DBG_SKIP
         if (!(cfg.dbg_skip & 16)) {
 #endif
-        if (padTs) mix(std::integral_constant<int, 8>()); else mix(std::integral_constant<int, 0>());
+        if (padTs == 8) mix(std::integral_constant<int, 8>()); else if (padTs == 10) mix(std::integral_constant<int, 10>()); else mix(std::integral_constant<int, 0>());
 #ifdef WR_DBG_SKIP
         }
 #endif
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(WP_THREADS, RAW ? 6 : 5) void wenet_demod_pipe_kern
 #pragma unroll 1
                     for (int m = 0; m < M; m++) {
                         constexpr int R = (TS - O) % TS;                    // this residue class (wave-uniform, == r)
-                        constexpr bool PAD = (TS == 8);                     // rows padded by one element per TS samples (see the mix stage)
+                        constexpr bool PAD = true;                          // rows padded by one element per TS samples (see the mix stage)
                         const v2f *row = (const v2f *)PH + m * Lpad + (PAD ? j * (TS + 1) + R : i);
                         v2f v[TS];
 #pragma unroll
