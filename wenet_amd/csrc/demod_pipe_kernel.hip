@@ -369,6 +369,41 @@ __global__ __launch_bounds__(WP_THREADS, RAW ? 6 : 5) void wenet_demod_pipe_kern
             // (the same cmul_pk sequence the chain wave ran) and mix each sample with its conjugate phasor
             const int nA = (nold + WP_CK - 1) / WP_CK, nB = (L - nold + WP_CK - 1) / WP_CK;
             const int per_tone = nA + nB;
+            if (RAW && M == 2) {
+                // batch variant: one D thread per checkpoint does ALL tones of its samples -- each raw sample is read from the ring
+                // and converted once instead of once per tone (fewer instructions; one stream prefers the finer split below)
+                for (int c = t; c < per_tone; c += WP_DSP_THREADS) {
+                    const bool segB = c >= nA;
+                    const int cc = segB ? c - nA : c;
+                    const int s0 = segB ? nold + cc * WP_CK : cc * WP_CK;
+                    const int send = segB ? L : nold;
+                    const int cnt = (send - s0) < WP_CK ? (send - s0) : WP_CK;
+                    v2f d[M], phi[M];
+#pragma unroll
+                    for (int m = 0; m < M; m++) {
+                        const float2 dd = CKD[((j & 1) * 2 + (segB ? 1 : 0)) * M + m];
+                        d[m] = (v2f){dd.x, dd.y};
+                        phi[m] = ((const v2f *)(CKb + (((j & 1) * 2 + (segB ? 1 : 0)) * M + m) * WP_CKROW))[cc];
+                    }
+                    const int pq0 = PADTS ? s0 / (PADTS ? PADTS : 1) : 0, pr0 = s0 - pq0 * PADTS;
+                    float2 *row = PH + s0 + pq0;
+                    float2 *dump = PH + M * Lpad;                        // steps past the end of a segment land here (no branches)
+                    const int rbase = RIDX(src0 + s0);
+                    float2 x[WP_CK];
+#pragma unroll
+                    for (int u = 0; u < WP_CK; u++) x[u] = ring_get((rbase + (u < cnt ? u : 0)) & rmask);
+#pragma unroll
+                    for (int u = 0; u < WP_CK; u++) {
+                        float2 *dst = (u < cnt) ? row + u + ((PADTS && pr0 + u >= PADTS) ? 1 : 0) : dump;  // (WP_CK <= Ts: at most one pad crossed)
+#pragma unroll
+                        for (int m = 0; m < M; m++) {
+                            dst[(u < cnt) ? m * Lpad : 0] = cmul(x[u], make_float2(phi[m].x, -phi[m].y));
+                            phi[m] = cmul_pk(phi[m], d[m]);
+                        }
+                    }
+                }
+                return;
+            }
             for (int w = t; w < M * per_tone; w += WP_DSP_THREADS) {
                 const int m = w / per_tone, c = w - m * per_tone;
                 const bool segB = c >= nA;
