@@ -131,3 +131,22 @@ def test_hbr_geometry_beyond_lds_vs_oracle(M, Fs, Rs, P):
     sd, _, _ = f.demod_stream(raw, "cu8")
     assert sd.size == ref.size > 20 * 48 and bits_equal(sd, ref)
     f.close()
+
+
+def test_batch_path_with_geometry_beyond_lds():
+    """The many-captures entry (wenet_rx_process) on a geometry whose frame lives in global scratch: every capture gets its
+    own scratch block; soft decisions and packets equal the oracle's, captures of different length side by side."""
+    from wenet_amd.rx import RxBatch
+    Fs, Rs, M = 960000, 9600, 2
+    cfg = siggen.ModemConfig("wide", 1, M, Fs, Rs, Fs * 0.2, 2.0 * Rs)
+    caps = [siggen.make_capture(cfg, n, eb, seed=300 + n)[0] for n, eb in ((3, 12.0), (2, 12.0), (4, 10.0))]
+    rx = RxBatch(Fs, Rs, M, framing=cfg.mode)
+    rx.process(caps, "cu8")
+    for c, raw in enumerate(caps):
+        ref, _ = ol.oracle_demod(raw, "cu8", Fs, Rs, M)
+        assert bits_equal(rx.soft(c), ref)
+        d = ol.oracle_deframe(ref, cfg.mode)
+        p = rx.packets(c)
+        assert p["n"] == d["n"] and (p["crc_ok"] == d["crc_ok"]).all() and (p["bytes"] == d["bytes"]).all()
+    assert sum(int(rx.packets(c)["crc_ok"].sum()) for c in range(3)) >= 5          # (the first packet of a capture is lost to acquisition)
+    rx.close()
