@@ -135,6 +135,16 @@ def main():
     ns = [nsamp] * B
 
     rx = RxBatch(cfg.Fs, cfg.Rs, cfg.M, framing=cfg.mode, max_iter=args.max_iter)
+    # which demod kernel the library picks for this launch (wenet_rx.hip rx_enqueue / demod_kernel.hip wr_launch_demod_ex):
+    # geometries that fit the pipelined kernel run it -- three captures per workgroup from three captures per CU on (cu8),
+    # one per workgroup below; wider geometries run the sequential kernel
+    ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+    if cfg.Ts * 48 + cfg.Ts // 2 > 640:
+        demod_kernel_name = "wenet_demod_kernel"
+    elif B >= 3 * ncu and "WENET_RX_NO_TRI" not in os.environ and cfg.Ts * 48 + cfg.Ts // 2 <= 576:
+        demod_kernel_name = "wenet_demod_tri_kernel"
+    else:
+        demod_kernel_name = "wenet_demod_pipe_kernel"
 
     def step():
         rx.enqueue_device(ptrs, ns, "cu8")
@@ -205,7 +215,7 @@ def main():
             "packets_valid_per_step_rank0": npk_valid, "packets_found_per_step_rank0": npk_all,
             "kernel_ms": {"demod": round(k_ms[0], 3), "deframe": round(k_ms[1], 3), "decode": round(k_ms[2], 3),
                           "gpu_total": round(k_ms[3], 3)},
-            "roofline": {"bound": "hbm", "kernel": "wenet_demod_pipe_kernel" if cfg.Ts * 48 + cfg.Ts // 2 <= 640 else "wenet_demod_kernel", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": demod_kernel_name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "traffic_source": "rocprofv3 PMC profile of this kernel (profiles/), per-sample bytes x samples in launch",
                          "algorithmic_bytes_per_launch": round(ALGO_BYTES_PER_SAMPLE * B * nsamp),

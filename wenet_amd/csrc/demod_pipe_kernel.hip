@@ -3,6 +3,7 @@
 #include "demod_pipe_impl.h"
 
 extern "C" hipError_t wr_launch_demod_pipe_raw(const WrDemodCfg *cfg, const WrChan *d_chans, int nchan, hipStream_t stream);    // demod_pipe_raw.hip
+extern "C" hipError_t wr_launch_demod_tri(const WrDemodCfg *cfg, const WrChan *d_chans, int nchan, hipStream_t stream);          // demod_pipe_tri.hip
 extern "C" hipError_t wr_launch_demod_pipe_prof(const WrDemodCfg *cfg, const WrChan *d_chans, int nchan, hipStream_t stream);   // demod_pipe_prof.hip
 
 #define WP_LAUNCH(MM, PP, RR)                                                                                                    \
@@ -16,6 +17,7 @@ extern "C" hipError_t wr_launch_demod_pipe(const WrDemodCfg *cfg, const WrChan *
     if (prof) return wr_launch_demod_pipe_prof(cfg, d_chans, nchan, stream);
     // cfg->p_raw: the caller guarantees every capture is cu8 (and carried samples came from cu8) and has put the
     // raw-ring LDS layout into cfg->p_off_*
+    if (cfg->p_tri) return wr_launch_demod_tri(cfg, d_chans, nchan, stream);
     if (cfg->p_raw) return wr_launch_demod_pipe_raw(cfg, d_chans, nchan, stream);
     if (cfg->M == 2) WP_LAUNCH(2, false, false); else WP_LAUNCH(4, false, false);
     return hipGetLastError();

@@ -56,6 +56,7 @@ struct WrDemodCfg {
     // LDS carve-up of the pipelined kernel (demod_pipe_kernel.hip); pipe_ok = configuration fits
     int pipe_ok, p_ring, p_lds_bytes, chain_prio;
     int p_tsum_split;                    // timing sum with re/im in separate lanes and plain adds (less SIMD time, more latency): batch launches
+    int p_tri, p_cap_stride;             // three captures per workgroup (demod_tri_impl.h): this copy carries that layout; bytes between the captures' LDS blocks
     int p_raw;                           // this copy of the configuration carries the raw-cu8-ring layout (3 captures per CU)
     int p_off_CK, p_off_CKD, p_off_TP;
     int p_off_XR, p_off_PH, p_off_FI, p_off_FB, p_off_FE, p_off_FW, p_off_SD, p_off_SC, p_off_PHE, p_off_CT;

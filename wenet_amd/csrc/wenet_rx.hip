@@ -140,6 +140,22 @@ struct DemodTables {
 
     // lbr = false: fsk_create_hbr (fsk.c:128-259); lbr = true: fsk_create (fsk.c:278-398) -- one-second frames (N = Fs,
     // Nsym = Rs), P = horus_P = 8, a 1024-point estimator over 800..2500 Hz with 100 Hz tone spacing
+    // configuration copy for the three-captures-per-workgroup kernel (raw cu8 ring, one shared NCO-chain wave), or p_tri == 0 in it
+    // if that form does not apply: per-capture blocks of the raw-ring layout without the tables, the tables once behind them
+    WrDemodCfg tri_cfg() const {
+        WrDemodCfg c = raw_cfg();
+        if (!c.p_raw || getenv("WENET_RX_NO_TRI") != nullptr) return c;
+        const int stride = (c.p_off_TW + 255) & ~255;                   // the tables are the tail of the one-capture layout
+        const int tab = c.p_lds_bytes - c.p_off_TW;
+        const int total = 3 * stride + tab;
+        if (total > 160 * 1024 || 3 * 192 < c.N + c.Ts / 2) return c;
+        const int shift = 3 * stride - c.p_off_TW;
+        c.p_off_TW += shift; c.p_off_HANN += shift; c.p_off_SRC += shift; c.p_off_PFT += shift; c.p_off_DPHI += shift;
+        c.p_cap_stride = stride; c.p_lds_bytes = total;
+        c.p_tri = 1;
+        return c;
+    }
+
     bool build(int Fs, int Rs, int P, int M, bool lbr = false) {
         memset(&cfg, 0, sizeof(cfg));
         if (lbr) P = 8;                                                 // fsk.c:35,308
@@ -942,9 +958,15 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const lon
     // ... when a third capture per CU is worth having; up to two per CU the float-ring variant (96 registers, no spills)
     // is 7 % faster per frame.  WENET_RX_FORCE_RAW=1 selects the raw ring regardless (tests).
     const bool want_raw = (fmt == WENET_FMT_CU8) && (nchan > 2 * wenet_rx_device_info(1) || getenv("WENET_RX_FORCE_RAW") != nullptr);
-    WrDemodCfg launch_cfg = want_raw ? rx->tab.raw_cfg() : rx->tab.cfg;
+    // three captures per workgroup (one shared NCO-chain wave, demod_tri_impl.h) for big cu8 batches; WENET_RX_TRI=1 forces it on
+    // any cu8 batch (tests), WENET_RX_NO_TRI turns it off
+    const bool want_tri = (fmt == WENET_FMT_CU8) && !rx->profile &&
+                          (getenv("WENET_RX_TRI") != nullptr || nchan >= 3 * wenet_rx_device_info(1));
+    WrDemodCfg launch_cfg = want_tri ? rx->tab.tri_cfg() : (want_raw ? rx->tab.raw_cfg() : rx->tab.cfg);
+    if (want_tri && !launch_cfg.p_tri) launch_cfg = want_raw ? rx->tab.raw_cfg() : rx->tab.cfg;     // geometry does not fit three blocks
     // more captures than CUs: SIMD time matters more than the latency of one frame (see tstage in demod_pipe_kernel.hip)
     launch_cfg.p_tsum_split = getenv("WENET_RX_TSUM_SPLIT") ? atoi(getenv("WENET_RX_TSUM_SPLIT")) : ((nchan > wenet_rx_device_info(1)) ? 1 : 0);
+    if (launch_cfg.p_tri) launch_cfg.p_tsum_split = 1;                  // (the batch form throughout)
     // WENET_RX_PROFILE: 1 = instrumented pipelined kernel, 2 = instrumented one-wave sequential kernel, 3 = production
     // kernels with the per-channel stamp buffer attached (streamed sequential kernel: cycle stamps of one frame)
     const int prof = rx->profile ? (getenv("WENET_RX_PROFILE")[0] == '2' ? 2 : (getenv("WENET_RX_PROFILE")[0] == '3' ? 0 : 1)) : 0;
