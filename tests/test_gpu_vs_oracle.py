@@ -220,6 +220,39 @@ def test_batch_ragged_and_slot_invariance():
     rx.close()
 
 
+@pytest.mark.parametrize("name", ["v2", "v1"])
+def test_three_captures_per_workgroup_kernel(name, monkeypatch):
+    """The batch kernel that carries three captures per workgroup with one shared NCO-chain wave (demod_tri_impl.h; picked by
+    itself from three captures per CU on, forced here): captures of different length and SNR, heavy clock error (slips of one
+    capture re-run its two neighbours' barriers), an empty one, a count that is not a multiple of three -- every capture equals
+    the oracle, in any slot."""
+    monkeypatch.setenv("WENET_RX_TRI", "1")
+    cfg = siggen.CONFIGS[name]()
+    spec = ((3, 8.0, 0.0), (1, 20.0, 0.0), (5, 6.0, 900.0), (2, 9.0, -1400.0), (4, 7.0, 3000.0), (1, 12.0, 0.0), (6, 8.5, -250.0))
+    caps = [siggen.make_capture(cfg, n, eb, seed=500 + i, ppm=ppm)[0] for i, (n, eb, ppm) in enumerate(spec)]
+    caps.insert(4, np.zeros(0, np.uint8))                   # an empty capture inside a group
+    caps.append(caps[0][:2 * cfg.Ts * 48 * 7 + 10])          # a ragged tail; 9 captures... and one more for a lone last group
+    caps.append(caps[2][:2 * cfg.Ts * 48 * 40])
+    rx = RxBatch(cfg.Fs, cfg.Rs, cfg.M, framing=cfg.mode)
+    rx.enable_trace()
+    rx.process(caps, "cu8")
+    res, slips = [], 0
+    for i, c in enumerate(caps):
+        sd, _ = ol.oracle_demod(c, "cu8", cfg.Fs, cfg.Rs, cfg.M) if c.size else (np.zeros(0, np.float32), None)
+        assert bits_equal(rx.soft(i), sd), i
+        ref = ol.oracle_deframe(sd, cfg.mode) if sd.size else dict(n=0)
+        assert rx.npackets(i) == ref["n"]
+        if ref["n"]:
+            assert (rx.packets(i)["bytes"] == ref["bytes"]).all() and (rx.packets(i)["iter"] == ref["iter"]).all()
+        if c.size:
+            slips += int((rx.trace(i)[:, 4] != cfg.Ts * 48).sum())
+        res.append(rx.valid_payloads(i))
+    assert slips > 20                                       # the re-run path was exercised
+    rx.process(caps[::-1], "cu8")                           # same captures, other slots and other neighbours: identical results
+    assert [rx.valid_payloads(i) for i in range(len(caps))] == res[::-1]
+    rx.close()
+
+
 def test_full_size_properties_10s_8dB():
     """BASELINE config 2 size (10 s, 9.6 M samples, Eb/N0 8 dB): encode -> channel -> decode round trip.
     Every CRC-valid packet is one of the transmitted payloads, in order; most packets are recovered;
