@@ -136,12 +136,12 @@ def main():
 
     rx = RxBatch(cfg.Fs, cfg.Rs, cfg.M, framing=cfg.mode, max_iter=args.max_iter)
     # which demod kernel the library picks for this launch (wenet_rx.hip rx_enqueue / demod_kernel.hip wr_launch_demod_ex):
-    # geometries that fit the pipelined kernel run it -- three captures per workgroup from three captures per CU on (cu8),
+    # geometries that fit the pipelined kernel run it -- three captures per workgroup from 1.5 captures per CU on (cu8),
     # one per workgroup below; wider geometries run the sequential kernel
     ncu = torch.cuda.get_device_properties(dev).multi_processor_count
     if cfg.Ts * 48 + cfg.Ts // 2 > 640:
         demod_kernel_name = "wenet_demod_kernel"
-    elif B >= 3 * ncu and "WENET_RX_NO_TRI" not in os.environ and cfg.Ts * 48 + cfg.Ts // 2 <= 576:
+    elif 2 * B >= 3 * ncu and "WENET_RX_NO_TRI" not in os.environ and cfg.Ts * 48 + cfg.Ts // 2 <= 576:
         demod_kernel_name = "wenet_demod_tri_kernel"
     else:
         demod_kernel_name = "wenet_demod_pipe_kernel"

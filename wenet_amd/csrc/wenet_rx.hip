@@ -961,7 +961,7 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const lon
     // three captures per workgroup (one shared NCO-chain wave, demod_tri_impl.h) for big cu8 batches; WENET_RX_TRI=1 forces it on
     // any cu8 batch (tests), WENET_RX_NO_TRI turns it off
     const bool want_tri = (fmt == WENET_FMT_CU8) && !rx->profile &&
-                          (getenv("WENET_RX_TRI") != nullptr || nchan >= 3 * wenet_rx_device_info(1));
+                          (getenv("WENET_RX_TRI") != nullptr || 2 * nchan >= 3 * wenet_rx_device_info(1));   // from 1.5 captures per CU on it wins (measured 384..3072)
     WrDemodCfg launch_cfg = want_tri ? rx->tab.tri_cfg() : (want_raw ? rx->tab.raw_cfg() : rx->tab.cfg);
     if (want_tri && !launch_cfg.p_tri) launch_cfg = want_raw ? rx->tab.raw_cfg() : rx->tab.cfg;     // geometry does not fit three blocks
     // more captures than CUs: SIMD time matters more than the latency of one frame (see tstage in demod_pipe_kernel.hip)
