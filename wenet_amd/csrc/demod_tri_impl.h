@@ -207,7 +207,7 @@ __global__ __launch_bounds__(WP_THREADS, 4) void wenet_demod_tri_kernel(WrDemodC
             CT[CT_FBIN + 3 * 4 + ctid] = present ? hdr->f_bin[ctid] : 0;                                   // frame -1 -> slots 2 / 3
         }
         nin = present ? __builtin_amdgcn_readfirstlane(hdr->nin) : N;
-        if (ctid == 0) { CT[CT_CNT] = 0; CT[CT_NIN_NEXT] = nin; CT[CT_CONT] = (present && (long long)nin <= C.nsamples && C.cap_frames > 0) ? 1 : 0; }
+        if (ctid == 0) { CT[CT_CNT] = 0; CT[30] = 0; CT[CT_NIN_NEXT] = nin; CT[CT_CONT] = (present && (long long)nin <= C.nsamples && C.cap_frames > 0) ? 1 : 0; }
         // first 4*Nmax samples into the ring
         const long long last = C.nsamples - 1;
         for (long long i = ctid; i < 4LL * Nmax; i += WT_CTHREADS)
@@ -515,16 +515,22 @@ __global__ __launch_bounds__(WP_THREADS, 4) void wenet_demod_tri_kernel(WrDemodC
     // T(k): ordered sum, timing, nin, decisions (fsk.c:870-993).  Wave 2.  kf = frame index in this launch.
     float norm_rx_timing_st = hdr->norm_rx_timing;                       // T-wave private carried scalars
     float ppm = hdr->ppm;
-    auto tstage = [&](int kf, long long frames, int nin_cur) {
+    auto tstage = [&](int kf, long long frames, int nin_cur, int act_caps) {
         const float2 *FI = FIb + (kf & 1) * M * NI;
         const float2 *TP = TPb + (kf & 1) * NIq;
         float tcr, tci;
         {
-            if (cfg.p_tsum_split) {
-                // Real part in even lanes, imaginary part in odd lanes: 490 dependent PLAIN adds per frame instead of packed
-                // ones (a packed-f32 op occupies the SIMD twice as long, and this wave shares its SIMD with other captures).
+            // ONE timing wave adds the products of all active captures: lanes 2c / 2c+1 carry the real / imaginary row of capture c
+            // (490 dependent plain adds per frame, issued once for the three captures instead of once each); the sums go through
+            // capture 0's control block, the other timing waves wait for the frame's flag.
+            float *G = (float *)(smem_all + cfg.p_off_CT) + 24;              // [3 captures][re, im] sums, then the flag at [6]
+            volatile int *gflag = (volatile int *)(smem_all + cfg.p_off_CT) + 30;
+            const int summer = __builtin_ctz(act_caps);                      // the lowest capture that still runs does the adding
+            if (cap == summer) {
                 typedef float v4f __attribute__((ext_vector_type(4)));
-                const float *TPf = (const float *)TP + (lane & 1) * NIq;    // this lane's row (re or im), four products per 128-bit LDS read
+                int sc = lane >> 1;                                          // capture of this lane
+                if (sc >= WT_CAPS || !((act_caps >> sc) & 1)) sc = cap;      // idle lanes add the wave's own capture again (result unused)
+                const float *TPf = (const float *)((const unsigned char *)TP + (sc - cap) * cfg.p_cap_stride) + (lane & 1) * NIq;
                 const v4f *T4 = (const v4f *)TPf;
                 float acc = 0.f;
                 v4f bufA[2], bufB[2];                                        // ping-pong: loads of one batch fly while the other is summed
@@ -536,8 +542,8 @@ __global__ __launch_bounds__(WP_THREADS, 4) void wenet_demod_tri_kernel(WrDemodC
                     for (i = 8; i + 16 <= NI; i += 16) {
                         bufB[0] = T4[(i >> 2)]; bufB[1] = T4[(i >> 2) + 1];
                         WP_ADD8(bufA);
-                        asm volatile("" : "+v"(acc) : : "memory");           // keep the reload of A behind its last use (else the
-                        bufA[0] = T4[(i >> 2) + 2]; bufA[1] = T4[(i >> 2) + 3];   // scheduler hoists it and pays register copies per round)
+                        asm volatile("" : "+v"(acc) : : "memory");
+                        bufA[0] = T4[(i >> 2) + 2]; bufA[1] = T4[(i >> 2) + 3];
                         WP_ADD8(bufB);
                         asm volatile("" : "+v"(acc) : : "memory");
                     }
@@ -552,46 +558,14 @@ __global__ __launch_bounds__(WP_THREADS, 4) void wenet_demod_tri_kernel(WrDemodC
                 }
 #undef WP_ADD8
                 for (; i < NI; i++) acc = acc + TPf[i];
-                tcr = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(acc), 0));
-                tci = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(acc), 1));
-            } else {
-                typedef float v4f __attribute__((ext_vector_type(4)));
-                const v4f *TP4 = (const v4f *)TP;
-                v2f acc = {0.f, 0.f};
-                v4f bufA[4], bufB[4];                                        // ping-pong: loads of one batch fly while the other is summed
-                int i = 0;
-                if (NI >= 8) {
-#pragma unroll
-                    for (int u = 0; u < 4; u++) bufA[u] = TP4[u];
-                    for (i = 8; i + 16 <= NI; i += 16) {
-#pragma unroll
-                        for (int u = 0; u < 4; u++) bufB[u] = TP4[(i >> 1) + u];
-#pragma unroll
-                        for (int u = 0; u < 4; u++) { acc = acc + bufA[u].xy; acc = acc + bufA[u].zw; }
-                        asm volatile("" : "+v"(acc) : : "memory");           // keep the reload of A behind its last use (else the
-#pragma unroll                                                           // scheduler hoists it and pays 8 register copies per round)
-                        for (int u = 0; u < 4; u++) bufA[u] = TP4[(i >> 1) + 4 + u];
-#pragma unroll
-                        for (int u = 0; u < 4; u++) { acc = acc + bufB[u].xy; acc = acc + bufB[u].zw; }
-                        asm volatile("" : "+v"(acc) : : "memory");
-                    }
-                    if (i + 8 <= NI) {
-#pragma unroll
-                        for (int u = 0; u < 4; u++) bufB[u] = TP4[(i >> 1) + u];
-#pragma unroll
-                        for (int u = 0; u < 4; u++) { acc = acc + bufA[u].xy; acc = acc + bufA[u].zw; }
-#pragma unroll
-                        for (int u = 0; u < 4; u++) { acc = acc + bufB[u].xy; acc = acc + bufB[u].zw; }
-                        i += 8;
-                    } else {
-#pragma unroll
-                        for (int u = 0; u < 4; u++) { acc = acc + bufA[u].xy; acc = acc + bufA[u].zw; }
-                    }
-                }
-                for (; i < NI; i++) { const float2 v = TP[i]; acc = acc + (v2f){v.x, v.y}; }
-                tcr = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(acc.x)));
-                tci = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(acc.y)));
+                if (lane < 2 * WT_CAPS) G[lane] = acc;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) *gflag = kf + 1;
             }
+            while (*gflag != kf + 1) __builtin_amdgcn_s_sleep(1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            tcr = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(G[2 * cap])));
+            tci = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(G[2 * cap + 1])));
         }
         int nin_next = nin_cur;
         float tr_mean = 0.f, tr_std = 0.f, tr_rxt = 0.f;
@@ -816,7 +790,7 @@ __global__ __launch_bounds__(WP_THREADS, 4) void wenet_demod_tri_kernel(WrDemodC
     } else if (is_t) {
         frame_loop([&](long long off1, bool mine) {
                        if (!mine) return;
-                       tstage(kf, frames, nin);                          // T(k): leaves nin(k+1) in CT_NIN_NEXT
+                       tstage(kf, frames, nin, act);                     // T(k): leaves nin(k+1) in CT_NIN_NEXT
                        if (lane == 0) {                                  // does this capture have a frame k+1?
                            const int nn = CT[CT_NIN_NEXT];
                            CT[CT_CONT] = (off1 + nn <= C.nsamples && frames + 1 < C.cap_frames) ? 1 : 0;
