@@ -61,6 +61,17 @@ __device__ __forceinline__ float nco_step_split(float own, float k1, float k2) {
         : "v"(own), "v"(k1), "v"(k2));
     return r;
 }
+// Eight NCO steps in one asm block: between separate asm statements hipcc pads a wait state (s_nop) it cannot prove unnecessary,
+// one issue slot in five on the chain wave.  The only hazard inside is the one handled above (DPP read after VALU write).
+__device__ __forceinline__ float nco_step_split8(float own, float k1, float k2) {
+    float t1, t2;
+#define WR_NCO1 "v_mul_f32 %1, %0, %3\n\ts_nop 0\n\tv_mul_f32_dpp %2, %0, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_add_f32 %0, %1, %2\n\t"
+    asm(WR_NCO1 WR_NCO1 WR_NCO1 WR_NCO1 WR_NCO1 WR_NCO1 WR_NCO1 WR_NCO1
+        : "+v"(own), "=&v"(t1), "=&v"(t2)
+        : "v"(k1), "v"(k2));
+#undef WR_NCO1
+    return own;
+}
 __device__ __forceinline__ v2f cmul_pk(v2f a, v2f b) {
     // (a.x*b.x - a.y*b.y, a.x*b.y + a.y*b.x), each product and each sum rounded separately (no FMA):
     //   t1 = (a.x*b.x, a.y*b.x)   t2 = (a.y*b.y, a.x*b.y)   r = (t1.x - t2.x, t1.y + t2.y)

@@ -90,8 +90,7 @@ __device__ __forceinline__ void nco_chain_split(int j, int nin_j, int lane, int 
     int s = 0, c = 0;
     for (; s + WP_CK <= nold; s += WP_CK, c++) {
         ckA[2 * c] = own;
-#pragma unroll
-        for (int u = 0; u < WP_CK; u++) own = nco_step_split(own, k1, k2);
+        static_assert(WP_CK == 8, "nco_step_split8"); own = nco_step_split8(own, k1, k2);
     }
     if (s < nold) { ckA[2 * c] = own; for (; s < nold; s++) own = nco_step_split(own, k1, k2); }
     {
@@ -108,14 +107,12 @@ __device__ __forceinline__ void nco_chain_split(int j, int nin_j, int lane, int 
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             ckB[2 * (c + k)] = own;
-#pragma unroll
-            for (int u = 0; u < WP_CK; u++) own = nco_step_split(own, k1, k2);
+            own = nco_step_split8(own, k1, k2);
         }
     }
     for (; s + WP_CK <= L; s += WP_CK, c++) {
         ckB[2 * c] = own;
-#pragma unroll
-        for (int u = 0; u < WP_CK; u++) own = nco_step_split(own, k1, k2);
+        static_assert(WP_CK == 8, "nco_step_split8"); own = nco_step_split8(own, k1, k2);
     }
     if (s < L) { ckB[2 * c] = own; for (; s < L; s++) own = nco_step_split(own, k1, k2); }
     PHE[((j % 3) * 4 + m) * 2 + part] = own;                             // un-normalised (fsk.c:846)
