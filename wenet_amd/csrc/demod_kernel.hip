@@ -766,6 +766,7 @@ __global__ __launch_bounds__(NT) void wenet_demod_kernel(WrDemodCfg cfg, const W
         hdr->nin = nin;
         hdr->frames_total += frames;
         hdr->frames_call = frames;
+        hdr->slips_call = 0;                                               // (no speculation in this kernel)
         hdr->consumed_call = off;
     }
 }

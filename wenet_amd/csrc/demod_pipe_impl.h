@@ -779,6 +779,7 @@ __global__ __launch_bounds__(WP_THREADS, RAW ? 6 : 5) void wenet_demod_pipe_kern
     // captures per CU).  One stream is 8 % faster with the single loop for all roles (the timing wave is its critical path
     // and comes out 1.2 k cycles per frame slower in the split form), so the float-ring variant keeps that.
     int kf = 0;                                                          // frame index within this launch
+    int nslip = 0;                                                       // frames with nin(k+1) != N (reported to the host: batch kernel choice)
     long long pr_busy = 0, pr_iter = 0, pr_redo = 0, pr_t0 = 0;          // PROF: per-role busy ticks
 #ifdef WR_DBG_SKIP                                                       // development build only (tools/gpu_stage_cost.sh): leave stages out
     const int skip = cfg.dbg_skip;                                       // 1 chain, 2 estimator, 4 D, 8 T, 16 mix, 32 integrate, 64 staging -- results are garbage
@@ -811,6 +812,7 @@ __global__ __launch_bounds__(WP_THREADS, RAW ? 6 : 5) void wenet_demod_pipe_kern
             }
             off = off1;
             nin = nin_next;
+            nslip += (nin_next != N) ? 1 : 0;
             frames++;
             kf++;
         }
@@ -896,6 +898,7 @@ __global__ __launch_bounds__(WP_THREADS, RAW ? 6 : 5) void wenet_demod_pipe_kern
         }
         off = off1;
         nin = nin_next;
+        nslip += (nin_next != N) ? 1 : 0;
         frames++;
         kf++;
     }
@@ -924,6 +927,7 @@ __global__ __launch_bounds__(WP_THREADS, RAW ? 6 : 5) void wenet_demod_pipe_kern
         hdr->nin = nin;
         hdr->frames_total += frames;
         hdr->frames_call = frames;
+        hdr->slips_call = nslip;
         hdr->consumed_call = off;
     }
 #undef RIDX

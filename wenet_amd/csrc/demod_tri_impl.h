@@ -741,6 +741,7 @@ __global__ __launch_bounds__(WP_THREADS, 4) void wenet_demod_tri_kernel(WrDemodC
     // (CT_CONT, written by each capture's T wave) and which slipped (nin(k+1) != N): a slip of any capture makes all waves
     // pass the three re-run barriers, only that capture's waves (and its lanes of the chain wave) do work in them.
     int kf = 0;                                                          // frame index within this launch (common: lock-step)
+    int nslip = 0;                                                       // this capture's frames with nin(k+1) != N
     auto frame_loop = [&](auto work, auto redo1, auto redo2, auto redo3) {
         while (act) {
             const bool mine = !is_chain && ((act >> cap) & 1);
@@ -765,7 +766,7 @@ __global__ __launch_bounds__(WP_THREADS, 4) void wenet_demod_tri_kernel(WrDemodC
                 redo3(off1, nin_next, redo, slip, nn);
                 lds_barrier();
             }
-            if (mine) { off = off1; nin = nin_next; frames++; }
+            if (mine) { off = off1; nin = nin_next; frames++; nslip += (nin_next != N) ? 1 : 0; }
             kf++;
             act = cont_mask();                                           // (written by the T waves before the first barrier of this iteration)
         }
@@ -826,6 +827,7 @@ __global__ __launch_bounds__(WP_THREADS, 4) void wenet_demod_tri_kernel(WrDemodC
             hdr->nin = nin;
             hdr->frames_total += frames;
             hdr->frames_call = frames;
+            hdr->slips_call = nslip;
             hdr->consumed_call = off;
         }
     }

@@ -72,7 +72,7 @@ struct WrChanHdr {
     float  norm_rx_timing;      // fsk.h:64
     float  ppm;                 // fsk.h:80
     int    nin;                 // fsk.h:83
-    int    pad0;
+    int    slips_call;          // frames of the last launch whose nin differed from N (pipelined kernels: speculation misses)
     long long frames_total;     // frames demodulated since create
     long long frames_call;      // frames produced by the last launch
     long long consumed_call;    // samples consumed by the last launch

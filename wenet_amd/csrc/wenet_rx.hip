@@ -820,6 +820,7 @@ struct wenet_rx {
     DevBuf d_states, d_chans, d_dchans, d_dstates, d_sd, d_starts, d_out, d_trace, d_llr, d_raw, d_prof, d_esn0, d_census, d_big;
     std::vector<unsigned> h_census;
     bool profile = false;
+    double slip_rate = 0.0;                              // share of frames with nin != N in the last collected batch
     std::vector<float> h_states;
     std::vector<WrDeframeState> h_dstates;
     // results land in ONE pinned host block with two async copies (states | deframer states, then packet slots | starts)
@@ -960,8 +961,12 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const lon
     const bool want_raw = (fmt == WENET_FMT_CU8) && (nchan > 2 * wenet_rx_device_info(1) || getenv("WENET_RX_FORCE_RAW") != nullptr);
     // three captures per workgroup (one shared NCO-chain wave, demod_tri_impl.h) for big cu8 batches; WENET_RX_TRI=1 forces it on
     // any cu8 batch (tests), WENET_RX_NO_TRI turns it off
+    // ... unless the previous batch of this handle slipped on more than 5 % of its frames (symbol-clock error: the timing estimate
+    // ping-pongs at its thresholds): a slip stalls all three captures of a workgroup, and the one-capture kernel wins
+    // (tools/gpu_slip_batch.py: 100 ppm = 11 % slips: 34.5 vs 30.5 ms)
+    const bool slippy = rx->slip_rate > 0.05 && getenv("WENET_RX_TRI") == nullptr;
     const bool want_tri = (fmt == WENET_FMT_CU8) && !rx->profile &&
-                          (getenv("WENET_RX_TRI") != nullptr || 2 * nchan >= 3 * wenet_rx_device_info(1));   // from 1.5 captures per CU on it wins (measured 384..3072)
+                          (getenv("WENET_RX_TRI") != nullptr || (2 * nchan >= 3 * wenet_rx_device_info(1) && !slippy));   // from 1.5 captures per CU on it wins (measured 384..3072)
     WrDemodCfg launch_cfg = want_tri ? rx->tab.tri_cfg() : (want_raw ? rx->tab.raw_cfg() : rx->tab.cfg);
     if (want_tri && !launch_cfg.p_tri) launch_cfg = want_raw ? rx->tab.raw_cfg() : rx->tab.cfg;     // geometry does not fit three blocks
     // more captures than CUs: SIMD time matters more than the latency of one frame (see tstage in demod_pipe_kernel.hip)
@@ -1019,6 +1024,14 @@ extern "C" int wenet_rx_collect(wenet_rx *rx) {
     rx->h_dstates.resize(nchan);
     WR_CHECK(hipMemcpy(rx->h_states.data(), rx->d_states.p, (size_t)c.st_floats * 4 * nchan, hipMemcpyDeviceToHost), -3);
     WR_CHECK(hipMemcpy(rx->h_dstates.data(), rx->d_dstates.p, sizeof(WrDeframeState) * nchan, hipMemcpyDeviceToHost), -3);
+    {   // share of frames with a timing slip in this batch: the next launch of this handle picks its batch kernel by it
+        long long fr = 0, sl = 0;
+        for (int i = 0; i < nchan; i++) {
+            const WrChanHdr *h = (const WrChanHdr *)&rx->h_states[(size_t)i * c.st_floats];
+            fr += h->frames_call; sl += h->slips_call;
+        }
+        rx->slip_rate = fr > 0 ? (double)sl / (double)fr : 0.0;
+    }
     rx->h_census.resize((size_t)nchan * WR_CENSUS_CLASSES);
     WR_CHECK(hipMemcpy(rx->h_census.data(), rx->d_census.p, rx->h_census.size() * 4, hipMemcpyDeviceToHost), -3);
     // packet slots + start offsets: one contiguous device->pinned-host copy each (per-capture copies of only the
