@@ -295,6 +295,7 @@ __global__ __launch_bounds__(WR_DEC_THREADS) void wenet_decode_kernel(WrDecodeAr
     float    *msg  = (float *)smem;
     uint4    *lut  = (uint4 *)(smem + WR_DEC_OFF_LUT);
     uint8_t  *bitbuf = (uint8_t *)(smem + WR_DEC_OFF_BITS);                        // [2580] decoded bits, then [258] bytes
+    int      *red = (int *)(smem + WR_DEC_OFF_RED);                                // [parity of the iteration][0: satisfied checks, 1: any data bit set]
 
     float llr[WR_VARS_PER_THREAD];
     WrPacketOut *out = A.out ? &A.out[slot] : nullptr;
@@ -339,6 +340,7 @@ __global__ __launch_bounds__(WR_DEC_THREADS) void wenet_decode_kernel(WrDecodeAr
 #pragma unroll
         for (int k = 0; k < 3; k++) if (t < 3 || k < deg[t]) msg[ea[t][k]] = m0;
     }
+    if (tid < 4) red[tid] = 0;
     __syncthreads();
 
     int result = A.max_iter, pcc = 0, pcc_written = 0;
@@ -369,7 +371,17 @@ __global__ __launch_bounds__(WR_DEC_THREADS) void wenet_decode_kernel(WrDecodeAr
             }
             if (tid == 0) msg[13 * WR_NPAR] = 0.f;
         }
-        const int ssum = __syncthreads_count(ok);
+        // Two workgroup barriers per iteration (check pass | variable pass); the two counts ride on them: every wave adds its ballot
+        // to the cell of this iteration's parity before the barrier, everyone reads it after, and the cell of the other parity is
+        // cleared for the next iteration.  (__syncthreads_count / __syncthreads_or cost three barriers each.)
+        const int par = iter & 1;
+        {
+            const unsigned long long bal = __ballot(ok);
+            if ((tid & 63) == 0 && bal) atomicAdd(&red[par * 2 + 0], __popcll(bal));
+        }
+        __syncthreads();
+        const int ssum = red[par * 2 + 0];
+        if (tid == 0) { red[(par ^ 1) * 2 + 0] = 0; red[(par ^ 1) * 2 + 1] = 0; }
         // ---- update q: thread = variable (mpdecode_core.c:439-464) ---------------------------
         int any_data = 0;
         bits = 0;
@@ -398,7 +410,9 @@ __global__ __launch_bounds__(WR_DEC_THREADS) void wenet_decode_kernel(WrDecodeAr
                 }
             }
         }
-        const int any = __syncthreads_or(any_data);
+        if (__ballot(any_data) && (tid & 63) == 0) red[par * 2 + 1] = 1;
+        __syncthreads();
+        const int any = red[par * 2 + 1];
         // ---- stop rules (mpdecode_core.c:466-483) --------------------------------------------
         if (!any) { result = iter + 1; break; }                 // "zero bit errors" against the all-zero data[]
         pcc = ssum; pcc_written = 1;

@@ -196,4 +196,5 @@ static const float WR_PHI0_LT1_V[27] = {  // value when x > T[k] (and x <= T[k-1
 // LDS carve-up of wenet_decode_kernel: float msg[14][516] | uint4 lut[] | bits[2592] + bytes[272]
 #define WR_DEC_OFF_LUT  (14 * WR_NPAR * 4)
 #define WR_DEC_OFF_BITS (WR_DEC_OFF_LUT + WR_PHI0_LUT_ENTRIES * 16)
-#define WR_DEC_LDS_BYTES (WR_DEC_OFF_BITS + 2592 + 272)
+#define WR_DEC_OFF_RED  (WR_DEC_OFF_BITS + 2592 + 272)                 // [2][2] reduction cells: satisfied checks / any data bit set, by iteration parity
+#define WR_DEC_LDS_BYTES (WR_DEC_OFF_RED + 16)
