@@ -12,7 +12,7 @@ import csv, glob
 acc = {}
 for f in glob.glob("/tmp/pmc_st/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "demod_pipe" in r.get("Kernel_Name", ""):
+        if "demod_pipe" in r.get("Kernel_Name", "") or "demod_tri" in r.get("Kernel_Name", ""):
             acc[r["Counter_Name"]] = max(acc.get(r["Counter_Name"], 0), float(r["Counter_Value"]))
 fr = ${1:-768} * 20000.0          # v2: 10 s x 96000 symbols/s / 48 symbols per modem frame
 print("skip=$skip", " ".join(f"{k}={v / fr:.0f}/frame" for k, v in sorted(acc.items())))

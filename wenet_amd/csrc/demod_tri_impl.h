@@ -129,11 +129,13 @@ __global__ __launch_bounds__(WP_THREADS, 4) void wenet_demod_tri_kernel(WrDemodC
     constexpr bool RAW = true;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // role of this wavefront and the capture it works for (the chain wave works for all three; its `cap` is 0 for the per-capture
-    // bookkeeping it does not use)
-    const bool is_chain = (wave == 0), is_e = (wave >= 1 && wave <= 3), is_t = (wave >= 4 && wave <= 6), is_d = (wave >= 7);
-    const int cap = is_chain ? 0 : is_e ? wave - 1 : is_t ? wave - 4 : (wave - 7) / 3;
-    const int dwave = is_d ? (wave - 7) - cap * 3 : 0;                 // D wave index within its capture
+    // Role and capture of each of the 16 wavefronts: host-built tables (DemodTables::tri_cfg), two bits per wave -- consecutive waves sit on
+    // consecutive SIMDs, and which waves share a SIMD is worth up to 25 % (the long serial waves want mix/integrate waves beside them).
+    //   role: 0 chain, 1 estimator, 2 timing, 3 mix/integrate
+    const int role  = (int)((cfg.tri_role >> (2 * wave)) & 3u);
+    const int cap   = (int)((cfg.tri_cap >> (2 * wave)) & 3u);
+    const int dwave = (int)((cfg.tri_dw >> (2 * wave)) & 3u);                // D wave index within its capture
+    const bool is_chain = role == 0, is_e = role == 1, is_t = role == 2, is_d = role == 3;
     const int ctid = is_e ? lane : is_t ? 64 + lane : is_d ? 128 + dwave * 64 + lane : WT_CTHREADS;    // thread index within the capture's 320
     const int ch = blockIdx.x * WT_CAPS + cap;
     const bool present = ch < nchan;                                   // (the last workgroup may carry fewer than three captures)
@@ -513,6 +515,7 @@ __global__ __launch_bounds__(WP_THREADS, 4) void wenet_demod_tri_kernel(WrDemodC
     float norm_rx_timing_st = hdr->norm_rx_timing;                       // T-wave private carried scalars
     float ppm = hdr->ppm;
     auto tstage = [&](int kf, long long frames, int nin_cur, int act_caps) {
+        if (C.prof && lane == 0) C.prof[12] = (long long)__builtin_readcyclecounter();
         const float2 *FI = FIb + (kf & 1) * M * NI;
         const float2 *TP = TPb + (kf & 1) * NIq;
         float tcr, tci;
@@ -564,6 +567,7 @@ __global__ __launch_bounds__(WP_THREADS, 4) void wenet_demod_tri_kernel(WrDemodC
             tcr = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(G[2 * cap])));
             tci = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(G[2 * cap + 1])));
         }
+        if (C.prof && lane == 0) C.prof[8] += (long long)__builtin_readcyclecounter() - C.prof[12];     // development: sum (or wait for it)
         int nin_next = nin_cur;
         float tr_mean = 0.f, tr_std = 0.f, tr_rxt = 0.f;
         const bool nan_frame = (tcr != tcr) || (tci != tci);             // fsk.c:878-880
@@ -582,6 +586,7 @@ __global__ __launch_bounds__(WP_THREADS, 4) void wenet_demod_tri_kernel(WrDemodC
             else nin_next = N;
             nin_next = __builtin_amdgcn_readfirstlane(nin_next);
             if (lane == 0) CT[CT_NIN_NEXT] = nin_next;                   // published early; read after the frame barrier
+            if (C.prof && lane == 0) C.prof[9] += (long long)__builtin_readcyclecounter() - C.prof[12];   // development: ... + atan2f, nin
             const int low_sample = (int)floorf(rx_timing);
             const float fract = rx_timing - (float)low_sample;
             const int high_sample = (int)ceilf(rx_timing);
@@ -672,6 +677,7 @@ __global__ __launch_bounds__(WP_THREADS, 4) void wenet_demod_tri_kernel(WrDemodC
             CT[CT_NIN_NEXT] = nin_next;
         }
         wave_sync();
+        if (C.prof && lane == 0) C.prof[10] += (long long)__builtin_readcyclecounter() - C.prof[12];      // development: ... + resample/decide
         if (C.sd_out) {
             float *so = C.sd_out + frames * Nbits;
             for (int i = lane; i < Nbits; i += 64) so[i] = SDL[i];
@@ -742,12 +748,17 @@ __global__ __launch_bounds__(WP_THREADS, 4) void wenet_demod_tri_kernel(WrDemodC
     // pass the three re-run barriers, only that capture's waves (and its lanes of the chain wave) do work in them.
     int kf = 0;                                                          // frame index within this launch (common: lock-step)
     int nslip = 0;                                                       // this capture's frames with nin(k+1) != N
+    long long pr_busy = 0, pr_iter = 0, pr_t0 = 0;                       // development (WENET_RX_PROFILE=3): busy / total ticks of this wave's role
+    const bool pp = C.prof != nullptr;
     auto frame_loop = [&](auto work, auto redo1, auto redo2, auto redo3) {
         while (act) {
             const bool mine = !is_chain && ((act >> cap) & 1);
             const long long off1 = off + nin;                            // true start of frame k+1 (this wave's capture)
+            if (pp) pr_t0 = (long long)__builtin_readcyclecounter();
             work(off1, mine);
+            if (pp) pr_busy += (long long)__builtin_readcyclecounter() - pr_t0;
             lds_barrier();
+            if (pp) pr_iter += (long long)__builtin_readcyclecounter() - pr_t0;
             // ---- commit frame k; verify the speculation nin(k+1) == N ------------------------------
             int nn[WT_CAPS], slip = 0;
 #pragma unroll
@@ -772,8 +783,13 @@ __global__ __launch_bounds__(WP_THREADS, 4) void wenet_demod_tri_kernel(WrDemodC
         }
     };
     auto nothing = [&](long long, int, bool, int, const int *) {};
+#ifdef WR_DBG_SKIP                                                       // development build only (tools/gpu_stage_cost.sh): leave stages out
+    const int skip = cfg.dbg_skip;                                       // 1 chain, 2 estimator, 4 D -- results are garbage by construction
+#else
+    constexpr int skip = 0;
+#endif
     if (is_chain) {
-        frame_loop([&](long long, bool) { chain(kf + 2, N, act); },                                     // C(k+2), speculative, all captures at once
+        frame_loop([&](long long, bool) { if (!(skip & 1)) chain(kf + 2, N, act); },                                     // C(k+2), speculative, all captures at once
                    nothing,
                    [&](long long, int, bool, int slip, const int *nn) {
 #pragma unroll
@@ -781,7 +797,7 @@ __global__ __launch_bounds__(WP_THREADS, 4) void wenet_demod_tri_kernel(WrDemodC
                    },
                    [&](long long, int, bool, int slip, const int *) { chain(kf + 2, N, slip); });
     } else if (is_e) {
-        frame_loop([&](long long off1, bool mine) { if (mine) estimate(kf + 3, off1 + 2LL * N, N); },  // E(k+3), speculative
+        frame_loop([&](long long off1, bool mine) { if (mine && !(skip & 2)) estimate(kf + 3, off1 + 2LL * N, N); },  // E(k+3), speculative
                    [&](long long off1, int nn, bool redo, int, const int *) { if (redo) estimate(kf + 1, off1, nn); },
                    [&](long long off1, int nn, bool redo, int, const int *) { if (redo) estimate(kf + 2, off1 + nn, N); },
                    [&](long long off1, int nn, bool redo, int, const int *) { if (redo) estimate(kf + 3, off1 + nn + N, N); });
@@ -797,7 +813,7 @@ __global__ __launch_bounds__(WP_THREADS, 4) void wenet_demod_tri_kernel(WrDemodC
                    nothing, nothing, nothing);
     } else {
         frame_loop([&](long long off1, bool mine) {
-                       if (!mine) return;
+                       if (!mine || (skip & 4)) return;
                        // stage the next nin samples into the ring, issue the following prefetch
 #pragma unroll
                        for (int k = 0; k < WP_KP; k++) { const int i = t + WP_DSP_THREADS * k; if (i < nin) ring_put_raw(RIDX(filled + i), pre[k], fmt_k); }
@@ -810,6 +826,13 @@ __global__ __launch_bounds__(WP_THREADS, 4) void wenet_demod_tri_kernel(WrDemodC
                    [&](long long off1, int nn, bool redo, int, const int *) { if (redo) dstage(kf + 1, off1, nn); });
     }
 
+    if (pp && lane == 0) {   // [0] chain busy  [1] estimator busy  [2] T busy  [3] D busy (first D wave)  [4] iteration total  [6] frames  (capture 0's buffer: chain)
+        if (is_chain) C.prof[0] = pr_busy;
+        if (is_e) C.prof[1] = pr_busy;
+        if (is_t) { C.prof[2] = pr_busy; C.prof[4] = pr_iter; C.prof[5] = nslip; C.prof[6] = frames; }
+        if (is_d && dwave == 0) C.prof[3] = pr_busy;
+        if (is_d && dwave == 1) C.prof[7] = pr_busy;
+    }
     // ================================ save carried state =======================================
     lds_barrier();
     if (!is_chain && present) {

@@ -56,6 +56,7 @@ struct WrDemodCfg {
     // LDS carve-up of the pipelined kernel (demod_pipe_kernel.hip); pipe_ok = configuration fits
     int pipe_ok, p_ring, p_lds_bytes, chain_prio;
     int p_tsum_split;                    // timing sum with re/im in separate lanes and plain adds (less SIMD time, more latency): batch launches
+    unsigned tri_role, tri_cap, tri_dw;  // three-capture kernel: role (0 chain, 1 estimator, 2 timing, 3 mix/integrate), capture and D-wave index of each of the 16 wavefronts, two bits each
     int p_tri, p_cap_stride;             // three captures per workgroup (demod_tri_impl.h): this copy carries that layout; bytes between the captures' LDS blocks
     int p_raw;                           // this copy of the configuration carries the raw-cu8-ring layout (3 captures per CU)
     int p_off_CK, p_off_CKD, p_off_TP;

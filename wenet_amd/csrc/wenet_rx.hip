@@ -153,6 +153,13 @@ struct DemodTables {
         c.p_off_TW += shift; c.p_off_HANN += shift; c.p_off_SRC += shift; c.p_off_PFT += shift; c.p_off_DPHI += shift;
         c.p_cap_stride = stride; c.p_lds_bytes = total;
         c.p_tri = 1;
+        // wave -> (role, capture, D wave) tables, two bits per wave.  Consecutive waves of a workgroup sit on consecutive SIMDs, so the
+        // table decides who shares a SIMD.  Measured best of a dozen placements (424 ms against 436 for the plain order chain |
+        // estimators | timing | D, up to 563 for bad ones): SIMD0: chain, D00, D11, D22 | SIMD1: T0 (adds for all), D10, D21, D02 |
+        // SIMD2: E0, E1, T1, D12 | SIMD3: E2, D20, T2, D01   (Dcd = capture c, D wave d; wave = SIMD + 4 * row).
+        // WENET_RX_TRI_MAP="role cap dw" (hex) overrides them (placement experiments).
+        c.tri_role = 0xffafdf58u; c.tri_cap = 0x12999480u; c.tri_dw = 0x6a050000u;
+        if (const char *m = getenv("WENET_RX_TRI_MAP")) sscanf(m, "%x %x %x", &c.tri_role, &c.tri_cap, &c.tri_dw);
         return c;
     }
 
@@ -965,7 +972,7 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const lon
     // ping-pongs at its thresholds): a slip stalls all three captures of a workgroup, and the one-capture kernel wins
     // (tools/gpu_slip_batch.py: 100 ppm = 11 % slips: 34.5 vs 30.5 ms)
     const bool slippy = rx->slip_rate > 0.05 && getenv("WENET_RX_TRI") == nullptr;
-    const bool want_tri = (fmt == WENET_FMT_CU8) && !rx->profile &&
+    const bool want_tri = (fmt == WENET_FMT_CU8) && (!rx->profile || getenv("WENET_RX_PROFILE")[0] == '3') &&
                           (getenv("WENET_RX_TRI") != nullptr || (2 * nchan >= 3 * wenet_rx_device_info(1) && !slippy));   // from 1.5 captures per CU on it wins (measured 384..3072)
     WrDemodCfg launch_cfg = want_tri ? rx->tab.tri_cfg() : (want_raw ? rx->tab.raw_cfg() : rx->tab.cfg);
     if (want_tri && !launch_cfg.p_tri) launch_cfg = want_raw ? rx->tab.raw_cfg() : rx->tab.cfg;     // geometry does not fit three blocks
