@@ -551,30 +551,31 @@ __global__ __launch_bounds__(WP_THREADS, RAW ? 6 : 5) void wenet_demod_pipe_kern
                 const float *TPf = (const float *)TP + (lane & 1) * NIq;    // this lane's row (re or im), four products per 128-bit LDS read
                 const v4f *T4 = (const v4f *)TPf;
                 float acc = 0.f;
-                v4f bufA[2], bufB[2];                                        // ping-pong: loads of one batch fly while the other is summed
-                int i = 0;
-#define WP_ADD8(buf) do { acc = acc + buf[0].x; acc = acc + buf[0].y; acc = acc + buf[0].z; acc = acc + buf[0].w; \
-                          acc = acc + buf[1].x; acc = acc + buf[1].y; acc = acc + buf[1].z; acc = acc + buf[1].w; } while (0)
-                if (NI >= 8) {
-                    bufA[0] = T4[0]; bufA[1] = T4[1];
-                    for (i = 8; i + 16 <= NI; i += 16) {
-                        bufB[0] = T4[(i >> 2)]; bufB[1] = T4[(i >> 2) + 1];
-                        WP_ADD8(bufA);
-                        asm volatile("" : "+v"(acc) : : "memory");           // keep the reload of A behind its last use (else the
-                        bufA[0] = T4[(i >> 2) + 2]; bufA[1] = T4[(i >> 2) + 3];   // scheduler hoists it and pays register copies per round)
-                        WP_ADD8(bufB);
+                v4f bufA[4], bufB[4];                                        // ping-pong in batches of 16 products: under load an LDS read takes
+                int i = 0;                                                   // longer than eight dependent adds, so the next batch is asked for 16 ahead
+#define WP_ADD16(buf) do { _Pragma("unroll") for (int u = 0; u < 4; u++) { acc = acc + buf[u].x; acc = acc + buf[u].y; acc = acc + buf[u].z; acc = acc + buf[u].w; } } while (0)
+#define WP_LD16(buf, at) do { _Pragma("unroll") for (int u = 0; u < 4; u++) buf[u] = T4[((at) >> 2) + u]; } while (0)
+                if (NI >= 16) {
+                    WP_LD16(bufA, 0);
+                    for (i = 16; i + 32 <= NI; i += 32) {
+                        WP_LD16(bufB, i);
+                        WP_ADD16(bufA);
+                        asm volatile("" : "+v"(acc) : : "memory");           // keep the reload of A behind its last use
+                        WP_LD16(bufA, i + 16);
+                        WP_ADD16(bufB);
                         asm volatile("" : "+v"(acc) : : "memory");
                     }
-                    if (i + 8 <= NI) {
-                        bufB[0] = T4[(i >> 2)]; bufB[1] = T4[(i >> 2) + 1];
-                        WP_ADD8(bufA);
-                        WP_ADD8(bufB);
-                        i += 8;
+                    if (i + 16 <= NI) {
+                        WP_LD16(bufB, i);
+                        WP_ADD16(bufA);
+                        WP_ADD16(bufB);
+                        i += 16;
                     } else {
-                        WP_ADD8(bufA);
+                        WP_ADD16(bufA);
                     }
                 }
-#undef WP_ADD8
+#undef WP_ADD16
+#undef WP_LD16
                 for (; i < NI; i++) acc = acc + TPf[i];
                 tcr = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(acc), 0));
                 tci = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(acc), 1));
