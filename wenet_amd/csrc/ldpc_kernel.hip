@@ -110,9 +110,9 @@ namespace {
 // clamped key also covers y < 1, negatives and NaN/Inf/overflow (x86 cvttss2si -> INT_MIN -> 10.0).  No branches.
 __device__ __forceinline__ float phi0_dev(float xf, const uint4 *lut) {
     const int b = __float_as_int(xf * 65536.0f);
-    int key = (b >> 18) - WR_PHI0_KEY_BIAS;
-    key = min(max(key, 0), WR_PHI0_LUT_ENTRIES - 1);
-    const uint4 e = lut[key];
+    // clamp the raw key (one v_med3_i32) and fold the bias into the table base: four instructions to the LDS read instead of six
+    const int key = min(max(b >> 18, WR_PHI0_KEY_BIAS), WR_PHI0_KEY_BIAS + WR_PHI0_LUT_ENTRIES - 1);
+    const uint4 e = *(const uint4 *)((const char *)lut + (key - WR_PHI0_KEY_BIAS) * 16);
     return __uint_as_float((b >= (int)e.x) ? e.z : e.y);
 }
 
