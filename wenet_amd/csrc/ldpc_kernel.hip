@@ -109,7 +109,7 @@ namespace {
 // within one table cell phi0 steps at most once, so one ordered compare of the raw bits finishes the job.  The
 // clamped key also covers y < 1, negatives and NaN/Inf/overflow (x86 cvttss2si -> INT_MIN -> 10.0).  No branches.
 __device__ __forceinline__ float phi0_dev(float xf, const uint4 *lut) {
-    const int b = __float_as_int(xf * 65536.0f);
+    const int b = __float_as_int(xf);                           // (thresholds and keys carry the 2^16 of x = (int)(xf*65536), phi0.c:10,14)
     // clamp the raw key (one v_med3_i32) and fold the bias into the table base: four instructions to the LDS read instead of six
     const int key = min(max(b >> 18, WR_PHI0_KEY_BIAS), WR_PHI0_KEY_BIAS + WR_PHI0_LUT_ENTRIES - 1);
     const uint4 e = *(const uint4 *)((const char *)lut + (key - WR_PHI0_KEY_BIAS) * 16);

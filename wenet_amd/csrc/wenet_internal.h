@@ -193,7 +193,10 @@ static const float WR_PHI0_LT1_V[27] = {  // value when x > T[k] (and x <= T[k-1
 #define WR_PHI0_CELLS 32
 #define WR_PHI0_BINADES 20
 #define WR_PHI0_LUT_ENTRIES (WR_PHI0_BINADES * WR_PHI0_CELLS + 2)
-#define WR_PHI0_KEY_BIAS ((0x3f800000 >> 18) - 1)   // key = (bits >> 18) - bias: y = 1.0 -> 1
+#define WR_PHI0_KEY_BIAS ((0x3f800000 >> 18) - 1 - 512)   // key = (bits(xf) >> 18) - bias: y = xf*65536 = 1.0 -> 1.  The table is built on the bits of y and
+                                                         // then moved by the exponent offset of the factor 2^16 (0x08000000 = 512 << 18), so the kernel reads
+                                                         // the bits of xf itself: no multiply (exact for every xf whose y is a normal float; zero, denormals,
+                                                         // negatives, Inf and NaN land in the two catch-all entries either way)
 // LDS carve-up of wenet_decode_kernel: float msg[14][516] | uint4 lut[] | bits[2592] + bytes[272]
 #define WR_DEC_OFF_LUT  (14 * WR_NPAR * 4)
 #define WR_DEC_OFF_BITS (WR_DEC_OFF_LUT + WR_PHI0_LUT_ENTRIES * 16)

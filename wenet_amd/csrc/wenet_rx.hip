@@ -377,8 +377,8 @@ float phi0_linear_int(int x) {                                          // phi0.
     return 10.0f;
 }
 inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
-float phi0_lut_eval(const uint32_t *lut, float y) {                     // host twin of phi0_dev: y = xf * 65536
-    int32_t b; memcpy(&b, &y, 4);
+float phi0_lut_eval(const uint32_t *lut, float xf) {                    // host twin of phi0_dev
+    int32_t b; memcpy(&b, &xf, 4);
     int key = (b >> 18) - WR_PHI0_KEY_BIAS;
     key = key < 0 ? 0 : (key > WR_PHI0_LUT_ENTRIES - 1 ? WR_PHI0_LUT_ENTRIES - 1 : key);
     const uint32_t *e = lut + key * 4;
@@ -429,17 +429,20 @@ struct LdpcTables {
                 if (steps > 1) { fprintf(stderr, "libwenet_rx: phi0 table: %d steps in cell %d\n", steps, k); return false; }
             }
         }
+        // the kernel keys on the bits of xf, not of y = xf * 2^16: move every real threshold by the exponent offset (the keys move
+        // through WR_PHI0_KEY_BIAS)
+        for (int k = 0; k < WR_PHI0_LUT_ENTRIES; k++) if (lut[k * 4] != 0x7fffffffu) lut[k * 4] -= 0x08000000u;
         // self-check against the reference form, every integer part and arguments in between, plus the odd cases
         for (int x = 0; x <= 1100000; x++)
             for (float fr : {0.0f, 0.5f}) {
                 const float y = (float)x + fr, xf = y / 65536.0f;
-                if (f2u(phi0_lut_eval(lut.data(), xf * 65536.0f)) != f2u(phi0_x86(xf))) {
+                if (f2u(phi0_lut_eval(lut.data(), xf)) != f2u(phi0_x86(xf))) {
                     fprintf(stderr, "libwenet_rx: phi0 table self-check failed at y=%g\n", (double)y);
                     return false;
                 }
             }
         for (float xf : {-0.0f, -1.0f, -1e30f, 1e-30f, 1.5e-5f, 16.0f, 32767.0f, 32767.99f, 32768.0f, 1e9f, 3e38f, INFINITY, -INFINITY, NAN, -NAN})
-            if (f2u(phi0_lut_eval(lut.data(), xf * 65536.0f)) != f2u(phi0_x86(xf))) {
+            if (f2u(phi0_lut_eval(lut.data(), xf)) != f2u(phi0_x86(xf))) {
                 fprintf(stderr, "libwenet_rx: phi0 table self-check failed at xf=%g\n", (double)xf);
                 return false;
             }
