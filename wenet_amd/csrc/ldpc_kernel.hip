@@ -350,24 +350,24 @@ __global__ __launch_bounds__(WR_DEC_THREADS) void wenet_decode_kernel(WrDecodeAr
         //      the phantom 14th edge of check 0 adds +0.0 LAST to phi_sum (no change) and contributes no sign.
         int ok = 0;
         if (tid < WR_NPAR) {
-            float mv[14];
-            unsigned sgn = 0, sbits = 0;
+            // messages stay signed in their registers: |m| is a free source modifier of the adds, the parity of the signs is the
+            // top bit of the XOR of the raw words, and an edge's new sign is its own sign XOR that parity
+            float mr[14];
+            unsigned px = 0;
 #pragma unroll
             for (int k = 0; k < 14; k++) {
-                const unsigned m = __float_as_uint(msg[k * WR_NPAR + tid]);
-                sbits |= (m >> 31) << k;
-                mv[k] = __uint_as_float(m & 0x7fffffffu);
+                mr[k] = msg[k * WR_NPAR + tid];
+                px ^= __float_as_uint(mr[k]);
             }
-            sgn = __popc(sbits) & 1u;
-            float phi_sum = mv[0];
+            const unsigned par_bit = px & 0x80000000u;
+            float phi_sum = fabsf(mr[0]);
 #pragma unroll
-            for (int k = 1; k < 14; k++) phi_sum = phi_sum + mv[k];
-            ok = (sgn == 0);
-            const unsigned flip = sgn ? ~sbits : sbits;         // sign of edge k = check parity XOR its own sign
+            for (int k = 1; k < 14; k++) phi_sum = phi_sum + fabsf(mr[k]);
+            ok = (par_bit == 0);
 #pragma unroll
             for (int k = 0; k < 14; k++) {
-                const float r = phi0_dev(phi_sum - mv[k], lut);
-                msg[k * WR_NPAR + tid] = __uint_as_float(__float_as_uint(r) | (((flip >> k) & 1u) << 31));
+                const float r = phi0_dev(phi_sum - fabsf(mr[k]), lut);
+                msg[k * WR_NPAR + tid] = __uint_as_float(__float_as_uint(r) | ((__float_as_uint(mr[k]) ^ par_bit) & 0x80000000u));
             }
             if (tid == 0) msg[13 * WR_NPAR] = 0.f;
         }
