@@ -15,7 +15,7 @@
 // while a packet is collected the window is frozen, so the search resumes on the stream with the
 // collected span excised.
 //
-// Decoder: one 576-thread workgroup per packet.  The graph is static (built once on the host,
+// Decoder: one 512-thread workgroup (eight wavefronts) per packet, four workgroups per CU.  The graph is static (built once on the host,
 // the reference rebuilds it per packet).  Edge messages live in LDS in slot-major order
 // msg[slot*516 + check]: the check pass (thread = check) is bank-conflict free, the variable pass
 // (thread = variable) reaches its 1..3 edges through a 16-bit address table.  A message carries
@@ -318,9 +318,9 @@ __global__ __launch_bounds__(WR_DEC_THREADS) void wenet_decode_kernel(WrDecodeAr
     }
     if (A.stop_after_llr) return;
 
-    // ---- tables: phi0 LUT into LDS; this thread's edge addresses into registers (the same five variables
-    //      every iteration).  Variables tid + 576 t, t = 0..2, are data bits of degree 3 for every thread;
-    //      t = 3 straddles the data/parity boundary at 2064 and t = 4 is parity (degree 2, the last one 1) or nothing.
+    // ---- tables: phi0 LUT into LDS; this thread's edge addresses into registers (the same six variables at
+    //      most, every iteration).  Variables tid + 512 t, t = 0..3, are data bits of degree 3 for every thread;
+    //      t = 4 straddles the data/parity boundary at 2064 and t = 5 is parity (degree 2, the last one 1) or nothing.
     for (int i = tid; i < WR_PHI0_LUT_ENTRIES; i += WR_DEC_THREADS) lut[i] = A.phi0_lut[i];
     int ea[WR_VARS_PER_THREAD][3], deg[WR_VARS_PER_THREAD];
 #pragma unroll
@@ -338,46 +338,46 @@ __global__ __launch_bounds__(WR_DEC_THREADS) void wenet_decode_kernel(WrDecodeAr
     for (int t = 0; t < WR_VARS_PER_THREAD; t++) {
         const float m0 = with_sign(phi0_dev(fabsf(llr[t]), lut), llr[t] < 0.f);
 #pragma unroll
-        for (int k = 0; k < 3; k++) if (t < 3 || k < deg[t]) msg[ea[t][k]] = m0;
+        for (int k = 0; k < 3; k++) if (t < WR_VARS_ALLDATA || k < deg[t]) msg[ea[t][k]] = m0;
     }
     if (tid < 4) red[tid] = 0;
     __syncthreads();
 
     int result = A.max_iter, pcc = 0, pcc_written = 0;
-    unsigned bits = 0;                                          // bit t = hard decision of variable tid+t*576
+    unsigned bits = 0;                                          // bit t = hard decision of variable tid+t*512
     for (int iter = 0; iter < A.max_iter; iter++) {
         // ---- update r: thread = check (mpdecode_core.c:414-436).  All 14 slots are processed for every check:
         //      the phantom 14th edge of check 0 adds +0.0 LAST to phi_sum (no change) and contributes no sign.
         int ok = 0;
-        if (tid < WR_NPAR) {
+        for (int chk = tid; chk < WR_NPAR; chk += WR_DEC_THREADS) {   // (516 checks on 512 threads: lanes 0..3 go round twice)
             // messages stay signed in their registers: |m| is a free source modifier of the adds, the parity of the signs is the
             // top bit of the XOR of the raw words, and an edge's new sign is its own sign XOR that parity
             float mr[14];
             unsigned px = 0;
 #pragma unroll
             for (int k = 0; k < 14; k++) {
-                mr[k] = msg[k * WR_NPAR + tid];
+                mr[k] = msg[k * WR_NPAR + chk];
                 px ^= __float_as_uint(mr[k]);
             }
             const unsigned par_bit = px & 0x80000000u;
             float phi_sum = fabsf(mr[0]);
 #pragma unroll
             for (int k = 1; k < 14; k++) phi_sum = phi_sum + fabsf(mr[k]);
-            ok = (par_bit == 0);
+            ok += (par_bit == 0) ? 1 : 0;
 #pragma unroll
             for (int k = 0; k < 14; k++) {
                 const float r = phi0_dev(phi_sum - fabsf(mr[k]), lut);
-                msg[k * WR_NPAR + tid] = __uint_as_float(__float_as_uint(r) | ((__float_as_uint(mr[k]) ^ par_bit) & 0x80000000u));
+                msg[k * WR_NPAR + chk] = __uint_as_float(__float_as_uint(r) | ((__float_as_uint(mr[k]) ^ par_bit) & 0x80000000u));
             }
-            if (tid == 0) msg[13 * WR_NPAR] = 0.f;
+            if (chk == 0) msg[13 * WR_NPAR] = 0.f;
         }
         // Two workgroup barriers per iteration (check pass | variable pass); the two counts ride on them: every wave adds its ballot
         // to the cell of this iteration's parity before the barrier, everyone reads it after, and the cell of the other parity is
         // cleared for the next iteration.  (__syncthreads_count / __syncthreads_or cost three barriers each.)
         const int par = iter & 1;
         {
-            const unsigned long long bal = __ballot(ok);
-            if ((tid & 63) == 0 && bal) atomicAdd(&red[par * 2 + 0], __popcll(bal));
+            const unsigned long long bal = __ballot(ok & 1), bal2 = __ballot(ok & 2);     // ok = number of satisfied checks of this thread (0..2)
+            if ((tid & 63) == 0 && (bal | bal2)) atomicAdd(&red[par * 2 + 0], __popcll(bal) + 2 * __popcll(bal2));
         }
         __syncthreads();
         const int ssum = red[par * 2 + 0];
@@ -387,22 +387,22 @@ __global__ __launch_bounds__(WR_DEC_THREADS) void wenet_decode_kernel(WrDecodeAr
         bits = 0;
 #pragma unroll
         for (int t = 0; t < WR_VARS_PER_THREAD; t++) {
-            if (t < 3 || deg[t] > 0) {
+            if (t < WR_VARS_ALLDATA || deg[t] > 0) {
                 float cm[3];
                 float Qi = llr[t];
 #pragma unroll
                 for (int k = 0; k < 3; k++) {
-                    if (t < 3 || k < deg[t]) {
+                    if (t < WR_VARS_ALLDATA || k < deg[t]) {
                         cm[k] = msg[ea[t][k]];
                         Qi += cm[k];
                     }
                 }
                 const int b = Qi < 0.f;
                 bits |= (unsigned)b << t;
-                if (b && (t < 3 || tid + t * WR_DEC_THREADS < WR_NDATA)) any_data = 1;
+                if (b && (t < WR_VARS_ALLDATA || tid + t * WR_DEC_THREADS < WR_NDATA)) any_data = 1;
 #pragma unroll
                 for (int k = 0; k < 3; k++) {
-                    if (t < 3 || k < deg[t]) {
+                    if (t < WR_VARS_ALLDATA || k < deg[t]) {
                         const float temp_sum = Qi - cm[k];
                         const float mag = phi0_dev(fabsf(temp_sum), lut);
                         msg[ea[t][k]] = with_sign(mag, !(temp_sum > 0.f));

@@ -121,8 +121,9 @@ struct WrDeframeChan {
 #define WR_NDATA  2064
 #define WR_NCODE  2580
 #define WR_ROWW   12
-#define WR_DEC_THREADS 576
-#define WR_VARS_PER_THREAD 5   // ceil(2580/576)
+#define WR_DEC_THREADS 512          // eight wavefronts: four workgroups per CU = all 32 wave slots (576 threads: three workgroups, 27)
+#define WR_VARS_PER_THREAD 6   // ceil(2580/512)
+#define WR_VARS_ALLDATA 4      // variables tid + 512 t, t < 4, are data bits (degree 3) for every thread: 4 * 512 <= 2064
 
 struct WrPacketOut {            // one per packet slot
     uint8_t bytes[258];         // 256 payload + 2 CRC bytes as decoded (drs232_ldpc.c:234-239)
@@ -199,6 +200,6 @@ static const float WR_PHI0_LT1_V[27] = {  // value when x > T[k] (and x <= T[k-1
                                                          // negatives, Inf and NaN land in the two catch-all entries either way)
 // LDS carve-up of wenet_decode_kernel: float msg[14][516] | uint4 lut[] | bits[2592] + bytes[272]
 #define WR_DEC_OFF_LUT  (14 * WR_NPAR * 4)
-#define WR_DEC_OFF_BITS (WR_DEC_OFF_LUT + WR_PHI0_LUT_ENTRIES * 16)
-#define WR_DEC_OFF_RED  (WR_DEC_OFF_BITS + 2592 + 272)                 // [2][2] reduction cells: satisfied checks / any data bit set, by iteration parity
+#define WR_DEC_OFF_BITS 0                                                   // bit / byte staging overlays the messages (dead after the last iteration)
+#define WR_DEC_OFF_RED  (WR_DEC_OFF_LUT + WR_PHI0_LUT_ENTRIES * 16)                 // [2][2] reduction cells: satisfied checks / any data bit set, by iteration parity
 #define WR_DEC_LDS_BYTES (WR_DEC_OFF_RED + 16)
