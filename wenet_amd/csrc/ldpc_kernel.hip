@@ -349,7 +349,8 @@ __global__ __launch_bounds__(WR_DEC_THREADS) void wenet_decode_kernel(WrDecodeAr
         // ---- update r: thread = check (mpdecode_core.c:414-436).  All 14 slots are processed for every check:
         //      the phantom 14th edge of check 0 adds +0.0 LAST to phi_sum (no change) and contributes no sign.
         int ok = 0;
-        for (int chk = tid; chk < WR_NPAR; chk += WR_DEC_THREADS) {   // (516 checks on 512 threads: lanes 0..3 go round twice)
+        {
+            const int chk = tid;                                // checks 0..511: one per thread
             // messages stay signed in their registers: |m| is a free source modifier of the adds, the parity of the signs is the
             // top bit of the XOR of the raw words, and an edge's new sign is its own sign XOR that parity
             float mr[14];
@@ -370,6 +371,25 @@ __global__ __launch_bounds__(WR_DEC_THREADS) void wenet_decode_kernel(WrDecodeAr
                 msg[k * WR_NPAR + chk] = __uint_as_float(__float_as_uint(r) | ((__float_as_uint(mr[k]) ^ par_bit) & 0x80000000u));
             }
             if (chk == 0) msg[13 * WR_NPAR] = 0.f;
+        }
+        // checks 512..515: not a second trip of four lanes through the whole pass (it would make one wavefront the straggler of every
+        // iteration) but edge-parallel on 56 lanes of the last wavefront: every lane of a check's group adds the 14 magnitudes
+        // itself, in order, and then updates only its own edge -- a quarter of the instructions, the same values.
+        if (tid >= WR_DEC_THREADS - 64 && tid < WR_DEC_THREADS - 64 + (WR_NPAR - WR_DEC_THREADS) * 14) {
+            const int l = tid - (WR_DEC_THREADS - 64), g = l / 14, k = l - g * 14, chk = WR_DEC_THREADS + g;
+            unsigned px = 0;
+            float phi_sum = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 14; kk++) {
+                const float m = msg[kk * WR_NPAR + chk];
+                px ^= __float_as_uint(m);
+                phi_sum = (kk == 0) ? fabsf(m) : phi_sum + fabsf(m);
+            }
+            const unsigned par_bit = px & 0x80000000u;
+            if (k == 0) ok += (par_bit == 0) ? 1 : 0;
+            const float mine = msg[k * WR_NPAR + chk];
+            const float r = phi0_dev(phi_sum - fabsf(mine), lut);
+            msg[k * WR_NPAR + chk] = __uint_as_float(__float_as_uint(r) | ((__float_as_uint(mine) ^ par_bit) & 0x80000000u));
         }
         // Two workgroup barriers per iteration (check pass | variable pass); the two counts ride on them: every wave adds its ballot
         // to the cell of this iteration's parity before the barrier, everyone reads it after, and the cell of the other parity is
