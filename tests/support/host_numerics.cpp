@@ -74,6 +74,22 @@ long check_x87(long n, uint64_t seed, double *first_bad) {
         float l = wx_llr(e, sd);
         if (!same_f(ref_l, l)) { if (!bad) { first_bad[0] = e; first_bad[1] = sd; } bad++; }
     }
+    // products that land on or next to a float half-way point (where rounding through the 64-bit significand and rounding once
+    // differ, and where wx_llr leaves its double-precision fast path)
+    for (long i = 0; i < n / 4; i++) {
+        uint64_t r = splitmix(s), r2 = splitmix(s);
+        const float f = wg_u2f(0x30000000u + (uint32_t)(r % 0x1f000000u));                 // 4.6e-10 .. 1.7e28
+        const double T = ((double)f + (double)nextafterf(f, INFINITY)) * 0.5;
+        const double sd0 = ldexp(1.0 + (double)(r2 >> 12) * (1.0 / 4503599627370496.0), (int)(r2 % 40) - 20);
+        const double e0 = T / (4.0 * sd0);
+        for (int de = -2; de <= 2; de++)
+            for (int neg = 0; neg < 2; neg++) {
+                const double e = wx_u2d(wx_d2u(e0) + (uint64_t)(int64_t)de), sd = neg ? -sd0 : sd0;
+                volatile float ref_l = 4.0L * e * sd;
+                float l = wx_llr(e, sd);
+                if (!same_f(ref_l, l)) { if (!bad) { first_bad[0] = e; first_bad[1] = sd; } bad++; }
+            }
+    }
     return bad;
 }
 }

@@ -203,6 +203,17 @@ WX_HD double wx_est_esn0(double estvar) {
 // llr = (float)(4.0L * estEsN0 * sd)    (mpdecode_core.c:594)
 WX_HD float wx_llr(double estEsN0, double sd) {
     if (!wx_finite(estEsN0) || !wx_finite(sd)) return (float)(4.0 * estEsN0 * sd);
+    {
+        // Fast path.  The x87 result is rnd24(rnd64(e)), e = the exact product.  hi = rnd53(e) (one double multiply; 4.0*estEsN0
+        // is exact) rounds to the same float unless hi sits EXACTLY half-way between two floats: the half-way points are
+        // doubles, rounding is monotone, so e, rnd64(e) and hi lie on the same side of every half-way point that hi does not
+        // hit.  Outside the normal float range, and on a half-way point (2^-29 of the cases), the integer emulation decides.
+        const double c4 = 4.0 * estEsN0;
+        const double hi = c4 * sd;
+        const uint64_t u = wx_d2u(hi);
+        const int be = (int)((u >> 52) & 0x7ff);
+        if (wx_finite(c4) && be >= 1023 - 126 && be <= 1023 + 126 && (u & 0x1fffffffULL) != 0x10000000ULL) return (float)hi;
+    }
     wx_x87 c = wx_from_double(estEsN0);
     if (c.mant) c.exp += 2;                                               // 4.0L * estEsN0, exact
     return wx_to_float(wx_mul(c, wx_from_double(sd)));
