@@ -62,6 +62,11 @@ struct WrDemodCfg {
     int p_off_CK, p_off_CKD, p_off_TP;
     int p_off_XR, p_off_PH, p_off_FI, p_off_FB, p_off_FE, p_off_FW, p_off_SD, p_off_SC, p_off_PHE, p_off_CT;
     int p_off_TW, p_off_HANN, p_off_SRC, p_off_PFT, p_off_DPHI;
+    // batch kernel, one wavefront per capture (demod_oct_impl.h): o_caps captures per workgroup, each with an LDS block of
+    // o_cap_stride bytes (o_off_FB .. o_off_CT inside it), the tables once behind the blocks; o_ok = geometry supported
+    int o_ok, o_caps, o_cap_stride, o_lds_bytes, o_nhb, o_first_bins;
+    int o_off_FB, o_off_FE, o_off_FW, o_off_CK, o_off_CT;
+    int o_off_TW, o_off_HANN, o_off_SRC, o_off_DPHI, o_off_PFT, o_off_BACK;
     // per-channel state block layout (floats from the block start)
     int st_fft_est, st_samp_old, st_sd_last, st_floats;
 };
@@ -74,6 +79,8 @@ struct WrChanHdr {
     float  ppm;                 // fsk.h:80
     int    nin;                 // fsk.h:83
     int    slips_call;          // frames of the last launch whose nin differed from N (pipelined kernels: speculation misses)
+    int    uncertain_call;      // fast mode: frames of the last launch whose timing estimate fell within the guard band of a nin threshold
+    int    pad0;
     long long frames_total;     // frames demodulated since create
     long long frames_call;      // frames produced by the last launch
     long long consumed_call;    // samples consumed by the last launch

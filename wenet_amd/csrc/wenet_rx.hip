@@ -25,6 +25,7 @@
 extern "C" hipError_t wr_launch_demod(const WrDemodCfg *cfg, const WrChan *d_chans, int nchan, hipStream_t stream);
 extern "C" hipError_t wr_launch_demod_pipe(const WrDemodCfg *cfg, const WrChan *d_chans, int nchan, hipStream_t stream, int prof);
 extern "C" hipError_t wr_launch_demod_ex(const WrDemodCfg *cfg, const WrChan *d_chans, int nchan, hipStream_t stream, int prof);
+extern "C" hipError_t wr_launch_demod_oct(const WrDemodCfg *cfg, const WrChan *d_chans, int nchan, hipStream_t stream, int fast);
 extern "C" hipError_t wr_launch_deframe(const WrDeframeChan *d_chans, int nchan, int mode, hipStream_t stream);
 extern "C" hipError_t wr_launch_decode(const WrDecodeArgs *args, hipStream_t stream);
 
@@ -160,6 +161,40 @@ struct DemodTables {
         // WENET_RX_TRI_MAP="role cap dw" (hex) overrides them (placement experiments).
         c.tri_role = 0xffafdf58u; c.tri_cap = 0x12999480u; c.tri_dw = 0x6a050000u;
         if (const char *m = getenv("WENET_RX_TRI_MAP")) sscanf(m, "%x %x %x", &c.tri_role, &c.tri_cap, &c.tri_dw);
+        return c;
+    }
+
+    // configuration copy for the batch kernel with one wavefront per capture (demod_oct_impl.h), caps captures per workgroup;
+    // o_ok == 0 in it if the geometry is not one it was written for (two tones, Ts 8 or 10 with P = Ts, one 256-point FFT per frame)
+    WrDemodCfg oct_cfg(int caps) const {
+        WrDemodCfg c = cfg;
+        c.o_ok = 0;
+        if (cfg.big || cfg.M != 2 || (cfg.Ts != 8 && cfg.Ts != 10) || cfg.P != cfg.Ts || cfg.Ndft != 256 || cfg.Nsym != WR_NSYM ||
+            cfg.N < cfg.Ndft + cfg.Ts / 2 || cfg.N + cfg.Ts / 2 >= 2 * cfg.Ndft || getenv("WENET_RX_NO_OCT") != nullptr)
+            return c;
+        if (caps < 1) caps = 1;
+        if (caps > 14) caps = 14;
+        const int NH = cfg.Ndft / 2, NIq = (cfg.NI + 3) & ~3, H = cfg.Ts / 2;
+        c.o_caps = caps;
+        c.o_nhb = (cfg.L + H - 1) / H;
+        int t = 0;
+        c.o_off_FB = t;  t = align16(t + (cfg.Ndft * 8 > 2 * NIq * 4 ? cfg.Ndft * 8 : 2 * NIq * 4));   // FFT buffer, then the timing products
+        c.o_off_FE = t;  t = align16(t + NH * 4);
+        c.o_off_FW = t;  t = align16(t + NH * 4);
+        c.o_off_CK = t;  t = align16(t + cfg.M * c.o_nhb * 8);
+        c.o_off_CT = t;  t = align16(t + 16 * 4);
+        c.o_cap_stride = (t + 127) & ~127;
+        t = caps * c.o_cap_stride;
+        c.o_off_TW = t;   t = align16(t + cfg.Ndft * 8);
+        c.o_off_HANN = t; t = align16(t + cfg.Ndft * 4);
+        c.o_off_SRC = t;  t = align16(t + cfg.Ndft * 4);
+        c.o_off_DPHI = t; t = align16(t + NH * 8);
+        c.o_off_PFT = t;  t = align16(t + cfg.NI * 8);
+        c.o_off_BACK = t; t = align16(t + 3 * NH * 8);
+        c.o_lds_bytes = t;
+        c.o_first_bins = 0;
+        while (c.o_first_bins < NH && host_binf[c.o_first_bins] < 1.0f) c.o_first_bins++;                 // fsk.c:750 "f_est[0] < 1"
+        c.o_ok = t <= 160 * 1024 ? 1 : 0;
         return c;
     }
 
@@ -825,6 +860,9 @@ struct wenet_rx {
     DemodTables tab;
     int mode = 1, max_iter = 10, spp = 3230;
     bool want_trace = false, want_llr = false;
+    int fast = 0;                                        // 1: parity-ladder rung P3 demodulator (demod_oct_impl.h, FAST) with exact re-runs
+    const char *last_kernel = "";                        // demod kernel of the last enqueue
+    long long fast_flagged = 0;                          // captures of the last fast batch that were re-run through the exact kernel
     int nchan = 0, max_pk = 0;
     std::vector<long long> sd_off, cap_frames;           // per channel: float offset into d_sd, frame capacity
     DevBuf d_states, d_chans, d_dchans, d_dstates, d_sd, d_starts, d_out, d_trace, d_llr, d_raw, d_prof, d_esn0, d_census, d_big;
@@ -887,6 +925,8 @@ extern "C" int wenet_rx_packet_census(wenet_rx *rx, int ch, long long counts[8])
 }
 extern "C" void wenet_rx_enable_trace(wenet_rx *rx, int on) { if (rx) { rx->want_trace = on != 0; rx->tab.cfg.stats = on ? 1 : 0; } }
 extern "C" void wenet_rx_enable_llr_dump(wenet_rx *rx, int on) { if (rx) rx->want_llr = on != 0; }
+extern "C" void wenet_rx_set_fast(wenet_rx *rx, int on) { if (rx) rx->fast = on ? 1 : 0; }
+extern "C" const char *wenet_rx_last_kernel(wenet_rx *rx) { return rx ? rx->last_kernel : ""; }
 
 // raw[i]: device address of capture i.  host_src != nullptr: its content still has to be copied there from host_src[i];
 // the batch is then cut into sub-batches whose uploads (copy stream) overlap the kernels of the previous sub-batch.
@@ -979,6 +1019,25 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const lon
                           (getenv("WENET_RX_TRI") != nullptr || (2 * nchan >= 3 * wenet_rx_device_info(1) && !slippy));   // from 1.5 captures per CU on it wins (measured 384..3072)
     WrDemodCfg launch_cfg = want_tri ? rx->tab.tri_cfg() : (want_raw ? rx->tab.raw_cfg() : rx->tab.cfg);
     if (want_tri && !launch_cfg.p_tri) launch_cfg = want_raw ? rx->tab.raw_cfg() : rx->tab.cfg;     // geometry does not fit three blocks
+    // Batches (round 2): one wavefront per capture, `caps` captures per workgroup sharing an NCO-chain and a timing-sum wavefront
+    // (demod_oct_impl.h) -- no speculation, so timing slips cost nothing.  A capture advances one frame per ~23 k cycles there (the
+    // pipelined kernels: 11.5 k), so it takes over once the CUs hold several captures each.  WENET_RX_OCT=<caps> forces it
+    // (tests), WENET_RX_NO_OCT turns it off.  Traces with Eb/N0 accumulators and profiling stay with the pipelined kernels.
+    int oct_caps = 0;
+    if (fmt == WENET_FMT_CU8 && !rx->profile) {
+        const char *force = getenv("WENET_RX_OCT");
+        if (force) oct_caps = atoi(force) > 0 ? atoi(force) : 8;
+        else if (!rx->want_trace && nchan >= 6 * wenet_rx_device_info(1)) oct_caps = 8;
+    }
+    WrDemodCfg oct_cfg;
+    bool use_oct = false;
+    if (oct_caps > 0 || rx->fast) {
+        oct_cfg = rx->tab.oct_cfg(oct_caps > 0 ? oct_caps : 8);
+        use_oct = oct_cfg.o_ok != 0 && fmt == WENET_FMT_CU8;
+    }
+    const int oct_fast = use_oct && rx->fast ? 1 : 0;
+    rx->last_kernel = use_oct ? (oct_fast ? "wenet_demod_oct_kernel<fast>" : "wenet_demod_oct_kernel")
+                              : (launch_cfg.p_tri ? "wenet_demod_tri_kernel" : (launch_cfg.pipe_ok && !launch_cfg.big ? "wenet_demod_pipe_kernel" : "wenet_demod_kernel"));
     // more captures than CUs: SIMD time matters more than the latency of one frame (see tstage in demod_pipe_kernel.hip)
     launch_cfg.p_tsum_split = getenv("WENET_RX_TSUM_SPLIT") ? atoi(getenv("WENET_RX_TSUM_SPLIT")) : ((nchan > wenet_rx_device_info(1)) ? 1 : 0);
     if (launch_cfg.p_tri) launch_cfg.p_tsum_split = 1;                  // (the batch form throughout)
@@ -1011,7 +1070,8 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const lon
         ak.census = a.census + (size_t)lo * WR_CENSUS_CLASSES;
         if (a.llr_out) ak.llr_out = a.llr_out + (size_t)lo * max_pk * WR_NCODE;
         WR_CHECK(hipEventRecord(e.ev[0], stream), -4);
-        WR_CHECK(wr_launch_demod_ex(&launch_cfg, rx->d_chans.as<WrChan>() + lo, n, stream, prof), -4);
+        if (use_oct) WR_CHECK(wr_launch_demod_oct(&oct_cfg, rx->d_chans.as<WrChan>() + lo, n, stream, oct_fast), -4);
+        else WR_CHECK(wr_launch_demod_ex(&launch_cfg, rx->d_chans.as<WrChan>() + lo, n, stream, prof), -4);
         WR_CHECK(hipEventRecord(e.ev[1], stream), -4);
         WR_CHECK(wr_launch_deframe(rx->d_dchans.as<WrDeframeChan>() + lo, n, rx->mode, stream), -4);
         WR_CHECK(hipEventRecord(e.ev[2], stream), -4);

@@ -35,6 +35,13 @@ class RxBatch:
     def enable_llr_dump(self, on=True):
         self._L.wenet_rx_enable_llr_dump(self._h, 1 if on else 0)
 
+    def set_fast(self, on=True):
+        """fast mode (parity-ladder rung P3, include/wenet_rx.h): soft decisions within ~1e-6 of the reference's instead of bit-identical."""
+        self._L.wenet_rx_set_fast(self._h, 1 if on else 0)
+
+    def last_kernel(self):
+        return self._L.wenet_rx_last_kernel(self._h).decode()
+
     # ---- host buffers ------------------------------------------------------------------
     def process(self, captures, fmt):
         """captures: list of numpy arrays (raw samples in format fmt)."""
