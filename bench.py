@@ -215,7 +215,7 @@ def main():
             "packets_valid_per_step_rank0": npk_valid, "packets_found_per_step_rank0": npk_all,
             "kernel_ms": {"demod": round(k_ms[0], 3), "deframe": round(k_ms[1], 3), "decode": round(k_ms[2], 3),
                           "gpu_total": round(k_ms[3], 3)},
-            "roofline": {"bound": "hbm", "kernel": demod_kernel_name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": rx.last_kernel(), "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "traffic_source": "rocprofv3 PMC profile of this kernel (profiles/), per-sample bytes x samples in launch",
                          "algorithmic_bytes_per_launch": round(ALGO_BYTES_PER_SAMPLE * B * nsamp),

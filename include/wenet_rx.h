@@ -180,6 +180,8 @@ long long wenet_rx_get_llrs(wenet_rx *rx, int ch, float *llr, long long cap_pack
  * computed as in exact mode, a capture with a frame whose timing estimate fell within the guard band of a nin threshold
  * (fsk.c:900-907) is re-run through the exact kernel by the same call.  Soft decisions then agree to ~1e-6 relative. */
 void wenet_rx_set_fast(wenet_rx *rx, int on);
+/* captures of the last fast-mode batch that were demodulated a second time by the exact kernel */
+long long wenet_rx_fast_reruns(wenet_rx *rx);
 /* name of the demodulator kernel the last enqueue launched (the library picks it by batch size, format and geometry) */
 const char *wenet_rx_last_kernel(wenet_rx *rx);
 /* timing of the last enqueue in milliseconds (HIP events on the launch stream):

@@ -1,0 +1,122 @@
+"""GPU: the batch demodulator with one wavefront per capture (wenet_amd/csrc/demod_oct_impl.h; the library picks it by itself from
+six captures per CU on, forced here through WENET_RX_OCT=<captures per workgroup>) against the oracle -- exact mode bit for bit,
+fast mode (parity-ladder rung P3) with identical control decisions and soft decisions / LLRs within tolerance."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from conftest import bits_equal
+from wenet_amd import siggen
+from wenet_amd.rx import RxBatch
+
+pytestmark = pytest.mark.gpu
+
+SPEC = ((3, 8.0, 0.0), (1, 20.0, 0.0), (5, 6.0, 900.0), (2, 9.0, -1400.0), (4, 7.0, 3000.0), (1, 12.0, 0.0), (6, 8.5, -250.0),
+        (2, 8.0, 100.0), (3, 10.0, -100.0), (2, 5.0, 0.0), (1, 8.0, 0.0), (2, 7.5, 5000.0))
+
+
+def _captures(cfg, seed0):
+    caps = [siggen.make_capture(cfg, n, eb, seed=seed0 + i, ppm=ppm)[0] for i, (n, eb, ppm) in enumerate(SPEC)]
+    caps.insert(4, np.zeros(0, np.uint8))                       # an empty capture inside a group
+    caps.append(caps[0][:2 * cfg.Ts * 48 * 7 + 10])              # ragged tails: the groups' captures end at different frames
+    caps.append(caps[2][:2 * cfg.Ts * 48 * 40])
+    caps.append(np.full(2 * cfg.Ts * 48 * 20, 127, np.uint8))    # silence: the estimator finds nothing (first-run rule stays on)
+    return caps
+
+
+@pytest.mark.parametrize("name,group", [("v2", 7), ("v1", 7), ("v2", 3), ("v1", 15), ("v2", 1)])
+def test_exact_mode_equals_oracle(name, group, monkeypatch):
+    """Different lengths and SNRs, heavy clock errors (nin != N on many frames: the estimator run made ahead with nin = N is
+    repeated), an empty capture, a silent one; every capture equals the oracle in any slot and with any group size."""
+    monkeypatch.setenv("WENET_RX_OCT", str(group))
+    cfg = siggen.CONFIGS[name]()
+    caps = _captures(cfg, 600)
+    rx = RxBatch(cfg.Fs, cfg.Rs, cfg.M, framing=cfg.mode)
+    rx.enable_trace()
+    rx.enable_llr_dump()
+    rx.process(caps, "cu8")
+    assert rx.last_kernel() == "wenet_demod_oct_kernel"
+    res, slips = [], 0
+    for i, c in enumerate(caps):
+        if not c.size:
+            assert rx.frames(i) == 0 and rx.npackets(i) == 0
+            res.append(b"")
+            continue
+        sd, tr = ol.oracle_demod(c, "cu8", cfg.Fs, cfg.Rs, cfg.M, want_trace=True)
+        assert bits_equal(rx.soft(i), sd), i
+        assert bits_equal(np.ascontiguousarray(rx.trace(i)[:, :7]), np.ascontiguousarray(tr[:, :7])), i      # f_est, nin, timing, ppm
+        ref = ol.oracle_deframe(sd, cfg.mode, want_llr=True)
+        p = rx.packets(i)
+        assert p["n"] == ref["n"]
+        if ref["n"]:
+            assert (p["bytes"] == ref["bytes"]).all() and (p["iter"] == ref["iter"]).all() and bits_equal(rx.llrs(i), ref["llr"])
+        slips += int((tr[:, 4] != cfg.Ts * 48).sum())
+        res.append(rx.valid_payloads(i))
+    assert slips > 30
+    rx.process(caps[::-1], "cu8")                                # other slots, other neighbours in the groups
+    assert [rx.valid_payloads(i) for i in range(len(caps))] == res[::-1]
+    rx.close()
+
+
+def test_large_batch_picks_the_kernel_by_itself():
+    """From six captures per CU on the library takes the one-wavefront-per-capture kernel without being told; spot-check captures
+    of such a batch against the oracle."""
+    from wenet_amd import lib
+    ncu = lib.load().wenet_rx_device_info(1)
+    cfg = siggen.config_v2()
+    base = [siggen.make_capture(cfg, 2, 8.0 + 0.5 * k, seed=650 + k, ppm=40.0 * k)[0] for k in range(8)]
+    caps = [base[i % 8][: base[i % 8].size - 2 * (i % 5) * 480] for i in range(6 * ncu + 3)]
+    rx = RxBatch(cfg.Fs, cfg.Rs, cfg.M, framing=cfg.mode)
+    rx.process(caps, "cu8")
+    assert rx.last_kernel() == "wenet_demod_oct_kernel"
+    for i in list(range(0, len(caps), 97)) + [len(caps) - 1]:
+        sd, _ = ol.oracle_demod(caps[i], "cu8", cfg.Fs, cfg.Rs, cfg.M)
+        assert bits_equal(rx.soft(i), sd), i
+        ref = ol.oracle_deframe(sd, cfg.mode)
+        assert rx.npackets(i) == ref["n"] and (rx.packets(i)["bytes"] == ref["bytes"]).all()
+    rx.close()
+
+
+@pytest.mark.parametrize("name", ["v2", "v1"])
+def test_fast_mode_within_tolerance(name):
+    """Rung P3: tone bins and nin identical to the oracle's on every frame (or the capture was re-run exactly), packet bytes
+    identical, soft decisions and LLRs within 1e-4 RELATIVE (of the frame's / packet's largest).  What limits the agreement is not
+    the fast arithmetic but the reference's own rounding: its ordered float sum of 490 timing products carries ~1e-6..6e-6 of noise
+    in norm_rx_timing, which moves the resampling instant of every symbol of the frame (fsk.c:913-934); an ABSOLUTE 1e-4 on LLRs of
+    magnitude > 10 is therefore out of reach for anything but the exact mode (measured here: 4e-4)."""
+    cfg = siggen.CONFIGS[name]()
+    caps = _captures(cfg, 700)
+    rx = RxBatch(cfg.Fs, cfg.Rs, cfg.M, framing=cfg.mode)
+    rx.set_fast()
+    rx.enable_trace()
+    rx.enable_llr_dump()
+    rx.process(caps, "cu8")
+    assert "oct" in rx.last_kernel()
+    worst_sd = worst_llr_rel = worst_llr_abs = worst_nrt = 0.0
+    for i, c in enumerate(caps):
+        if not c.size:
+            assert rx.frames(i) == 0
+            continue
+        sd, tr = ol.oracle_demod(c, "cu8", cfg.Fs, cfg.Rs, cfg.M, want_trace=True)
+        g, gt = rx.soft(i), rx.trace(i)
+        assert g.size == sd.size
+        assert bits_equal(np.ascontiguousarray(gt[:, :5]), np.ascontiguousarray(tr[:, :5])), i                 # f_est and nin: identical
+        worst_nrt = max(worst_nrt, float(np.abs(gt[:, 5] - tr[:, 5]).max()))                                   # norm_rx_timing
+        fr_max = np.abs(sd.reshape(-1, 48)).max(axis=1, keepdims=True)
+        err = (np.abs(g - sd).reshape(-1, 48) / np.maximum(fr_max, 1e-9)).max() if sd.size else 0.0
+        worst_sd = max(worst_sd, float(err))
+        ref = ol.oracle_deframe(sd, cfg.mode, want_llr=True)
+        p = rx.packets(i)
+        assert p["n"] == ref["n"] and (p["start"] == ref["start"]).all()
+        if ref["n"]:
+            # what the reference pipe writes -- the CRC-valid packets -- is identical; a packet the decoder gives up on after
+            # max_iter iterations ends in a state that depends chaotically on the last bit of every LLR, in any arithmetic
+            assert (p["crc_ok"] == ref["crc_ok"]).all() and (p["bytes"][ref["crc_ok"]] == ref["bytes"][ref["crc_ok"]]).all(), i
+            assert (p["iter"][ref["crc_ok"]] == ref["iter"][ref["crc_ok"]]).all(), i
+            d = np.abs(rx.llrs(i) - ref["llr"])
+            worst_llr_abs = max(worst_llr_abs, float(d.max()))
+            worst_llr_rel = max(worst_llr_rel, float((d.max(axis=1) / np.abs(ref["llr"]).max(axis=1)).max()))
+    print(f"fast mode {name}: {rx.fast_reruns()} captures re-run exactly; max |d norm_rx_timing| {worst_nrt:.3g} (guard band 2e-5), "
+          f"max |d sd| / frame max {worst_sd:.3g}, max |d LLR| {worst_llr_abs:.3g} abs, {worst_llr_rel:.3g} of the packet's largest")
+    assert worst_nrt < 2e-5 and worst_sd < 1e-4 and worst_llr_rel < 1e-4
+    rx.close()

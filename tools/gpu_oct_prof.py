@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Phase cycle counts of the one-wavefront-per-capture batch kernel (WENET_RX_PROFILE=4).  usage: gpu_oct_prof.py [captures] [seconds] [caps]"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 7
+secs = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+caps = sys.argv[3] if len(sys.argv) > 3 else "7"
+os.environ["WENET_RX_PROFILE"] = "4"
+os.environ["WENET_RX_OCT"] = caps
+import numpy as np
+import torch
+from wenet_amd import siggen
+from wenet_amd.rx import RxBatch
+from wenet_amd.tx import Tx
+
+cfg = siggen.config_v2()
+dev = torch.device("cuda", 0)
+nsym = int(secs * cfg.Rs); nsamp = nsym * cfg.Ts
+tx = Tx.from_config(cfg)
+spp = tx.symbols_per_packet
+nfr = nsym // spp + 1
+payloads = torch.randint(0, 256, (B * nfr, 256), dtype=torch.uint8, device=dev)
+symbols = torch.empty(B * nfr * spp, dtype=torch.uint8, device=dev)
+tx.frame_packets_device(payloads.data_ptr(), B * nfr, symbols.data_ptr())
+caps_t = [torch.empty(2 * nsamp, dtype=torch.uint8, device=dev) for _ in range(B)]
+tx.modulate_device([symbols.data_ptr() + i * nfr * spp for i in range(B)], [nsym] * B, [c.data_ptr() for c in caps_t], 8.0,
+                   seeds=[7000 + i for i in range(B)])
+torch.cuda.synchronize()
+rx = RxBatch(cfg.Fs, cfg.Rs, cfg.M, framing=cfg.mode)
+for _ in range(2):
+    rx.enqueue_device([int(c.data_ptr()) for c in caps_t], [nsamp] * B, "cu8"); rx.collect()
+print("kernel", rx.last_kernel(), "captures", B, "demod ms", round(rx.last_ms(0), 3), "Gsamples/s", round(B * nsamp / rx.last_ms(0) / 1e6, 2))
+L = rx._L
+L.wenet_rx_debug_profile.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+buf = (C.c_longlong * 26)()
+for ch in range(0, B, int(caps)):
+    n = L.wenet_rx_debug_profile(rx._h, ch, buf)
+    v = list(buf)
+    fr = max(v[6], 1)
+    names = ["D decide", "A chain|E-ahead", "B mix/integ", "C sums"]
+    print(f"group@{ch}: frames {v[6]}; per frame (wave 0): " + ", ".join(f"{names[k]} {v[k] / fr:.0f}" for k in range(4)) +
+          f" | E-ahead busy {v[4] / fr:.0f}, chain busy {v[8 + 5] / fr:.0f}  total/frame {sum(v[:4]) / fr:.0f}")
+    if ch >= 3 * int(caps):
+        break

@@ -5,7 +5,7 @@ extern "C" hipError_t wr_launch_demod_oct(const WrDemodCfg *cfg, const WrChan *d
     if (nchan <= 0) return hipSuccess;
     if (!cfg->o_ok) return hipErrorInvalidValue;
     const int groups = (nchan + cfg->o_caps - 1) / cfg->o_caps;
-    const int threads = (cfg->o_caps + (fast ? 0 : 2)) * 64;
+    const int threads = (cfg->o_caps + (fast ? 0 : 1)) * 64;
 #define WO_LAUNCH(TT, FF)                                                                                                          \
     do {                                                                                                                           \
         hipError_t e = hipFuncSetAttribute((const void *)wenet_demod_oct_kernel<2, TT, FF>, hipFuncAttributeMaxDynamicSharedMemorySize, \

@@ -37,13 +37,13 @@
 
 #pragma clang fp contract(off)
 
-#define WO_CAPS_MAX 14               // capture waves per workgroup (cfg.o_caps of them) + chain wave + sum wave <= 16 wavefronts
+#define WO_CAPS_MAX 15               // capture waves per workgroup (cfg.o_caps of them) + the duty wave (NCO chains, timing sums) <= 16 wavefronts
 #define WO_GUARD 2e-5f              // |norm_rx_timing -+ 0.25| below this: the fast estimate does not decide nin(k+1) safely
 
 namespace {
 
-enum { OC_NIN = 0, OC_ALIVE = 1, OC_FBIN = 2 /* [4] this frame */, OC_FBINP = 6 /* [4] previous frame, first-run rule applied (fsk.c:750-753) */,
-       OC_TC = 10 /* float re, im: timing sum */, OC_INTS = 16 };
+enum { OC_NIN = 0, OC_ALIVE = 1, OC_FBIN = 2 /* [2] this frame */, OC_FBINP = 4 /* [2] previous frame, first-run rule applied (fsk.c:750-753) */,
+       OC_FBINN = 6 /* [2] next frame (estimated ahead, see the frame loop) */, OC_TC = 10 /* float re, im: timing sum */, OC_INTS = 16 };
 
 typedef __attribute__((address_space(3))) float oct_lds_f32;
 
@@ -67,13 +67,13 @@ __device__ __forceinline__ float nco_steps(float own, float k1, float k2) {     
 }  // namespace
 
 template <int M, int TS, bool FAST>
-__global__ __launch_bounds__(1024, FAST ? 4 : 5) void wenet_demod_oct_kernel(WrDemodCfg cfg, const WrChan *chans, int nchan) {
+__global__ __launch_bounds__(1024, 4) void wenet_demod_oct_kernel(WrDemodCfg cfg, const WrChan *chans, int nchan) {
     static_assert(M == 2, "two tones (four would need two soft decisions per lane)");
     constexpr int H = TS / 2;                                            // checkpoint spacing = the unit of a timing slip
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int G = cfg.o_caps;                                            // captures (= capture waves) of this workgroup
-    const bool is_cap = wave < G, is_chain = !FAST && wave == G, is_sum = !FAST && wave == G + 1;
+    const bool is_cap = wave < G, is_chain = !FAST && wave == G, is_sum = is_chain;      // one duty wave: the chain, later the sums
     const int cap = is_cap ? wave : 0;
     const int ch = blockIdx.x * G + cap;
     const bool present = is_cap && ch < nchan;
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(1024, FAST ? 4 : 5) void wenet_demod_oct_kernel(WrD
     unsigned char *smem = smem_all + cap * cfg.o_cap_stride;
     float2 *FB = (float2 *)(smem + cfg.o_off_FB);                        // [Ndft] estimator FFT buffer ...
     float  *TPf = (float *)(smem + cfg.o_off_FB);                        // ... later the frame's timing products: a row of re, a row of im
-    float  *FE = (float *)(smem + cfg.o_off_FE);                         // [Ndft/2] smoothed spectrum (carried)
+    float  *FE2 = (float *)(smem + cfg.o_off_FE);                        // [2][Ndft/2] smoothed spectrum after this frame's estimator run | after the next one's
     float  *FW = (float *)(smem + cfg.o_off_FW);                         // [Ndft/2]
     float2 *CK = (float2 *)(smem + cfg.o_off_CK);                        // [M][o_nhb] phasor at the start of every half symbol
     int    *CT = (int *)(smem + cfg.o_off_CT);
@@ -99,7 +99,6 @@ __global__ __launch_bounds__(1024, FAST ? 4 : 5) void wenet_demod_oct_kernel(WrD
 
     const int N = cfg.N, Nmem = cfg.Nmem, nstash = cfg.nstash, Ndft = cfg.Ndft, NH = cfg.Ndft / 2, L = cfg.L, NI = cfg.NI;
     const int NIq = (NI + 3) & ~3, NHB = cfg.o_nhb;
-    const int NBLK = (L + TS - 1) / TS;                                  // lanes that own samples
     const int NOUT = NI / TS;                                            // lanes that own integrator outputs (NI = (Nsym+1)*TS)
     constexpr int NE = 4;                                                // estimator samples per lane (Ndft = 256)
 
@@ -129,14 +128,14 @@ __global__ __launch_bounds__(1024, FAST ? 4 : 5) void wenet_demod_oct_kernel(WrD
     int nslip = 0, nuncertain = 0;
     bool alive = false;
     if (is_cap) {
-        for (int i = lane; i < NH; i += 64) FE[i] = present ? st_fft[i] : 0.f;
+        for (int i = lane; i < NH; i += 64) FE2[i] = present ? st_fft[i] : 0.f;
         if (present) {
             if (lane < cfg.Nbits) sdl = st_sd[lane];
             nin = __builtin_amdgcn_readfirstlane(hdr->nin);
             norm_rx_timing_st = hdr->norm_rx_timing; ppm = hdr->ppm;
         }
         alive = present && (long long)nin <= C.nsamples && C.cap_frames > 0;
-        if (lane < M) CT[OC_FBINP + lane] = present ? hdr->f_bin[lane] : 0;          // bins of the frame before this launch
+        if (lane < M) CT[OC_FBIN + lane] = present ? hdr->f_bin[lane] : 0;           // bins of the frame before this launch
         if (lane == 0) { CT[OC_NIN] = nin; CT[OC_ALIVE] = alive ? 1 : 0; }
     }
     // chain wave: lane 4c + 2m + part carries one component of phi_c[m] of capture c, in a register, across the frames
@@ -169,7 +168,10 @@ __global__ __launch_bounds__(1024, FAST ? 4 : 5) void wenet_demod_oct_kernel(WrD
     };
 
     // E(j): tone estimator (fsk.c:540-677) on the prefetched samples; one FFT (Ndft <= nin < 2 Ndft)
-    auto estimate = [&](int nin_j) {
+    int fecur = 0;                                                       // FE2[fecur]: spectrum after the estimator run of the frame in work
+    auto estimate = [&](int nin_j) {                                     // reads FE2[fecur], leaves FE2[fecur ^ 1] and the bins in OC_FBINN
+        const float *FEin = FE2 + fecur * NH;
+        float *FEout = FE2 + (fecur ^ 1) * NH;
         const int fft_samps = nin_j - Ndft;                              // fsk.c:583-584 with fft_loops == 1
 #pragma unroll
         for (int j = 0; j < NE; j++) {
@@ -213,8 +215,8 @@ __global__ __launch_bounds__(1024, FAST ? 4 : 5) void wenet_demod_oct_kernel(WrD
             float mag = (v.x * v.x) + (v.y * v.y);
             if (i < cfg.f_min) mag = 0.f;
             if (cfg.f_max - 1 >= 0 && i >= cfg.f_max - 1) mag = 0.f;
-            const float e = (FE[i] * cfg.one_minus_tc) + (sqrtf(mag) * cfg.tc);
-            FE[i] = e;
+            const float e = (FEin[i] * cfg.one_minus_tc) + (sqrtf(mag) * cfg.tc);
+            FEout[i] = e;
             FW[i] = e;
         }
         wave_sync();
@@ -242,13 +244,18 @@ __global__ __launch_bounds__(1024, FAST ? 4 : 5) void wenet_demod_oct_kernel(WrD
             fbin[k] = imax;
         }
         if (fbin[0] > fbin[1]) { const int t = fbin[0]; fbin[0] = fbin[1]; fbin[1] = t; }     // fsk.c:658-667 (M == 2)
-        // first-run rule (fsk.c:750-753): while the stored estimate of tone 0 is below 1 Hz the old part of the frame is mixed
-        // with the NEW estimates
+        if (lane == 0) { CT[OC_FBINN] = fbin[0]; CT[OC_FBINN + 1] = fbin[1]; }
+        wave_sync();
+    };
+    // the frame whose estimator run is in OC_FBINN / FE2[fecur ^ 1] becomes the frame in work.  First-run rule (fsk.c:750-753): while
+    // the stored estimate of tone 0 is below 1 Hz the old part of the frame is mixed with the NEW estimates
+    auto commit_estimate = [&]() {
         if (lane == 0) {
-            const bool first = CT[OC_FBINP] < cfg.o_first_bins;               // bin_freq[bin] < 1.0f
+            const bool first = CT[OC_FBIN] < cfg.o_first_bins;                // bin_freq[stored bin of tone 0] < 1.0f
 #pragma unroll
-            for (int m = 0; m < M; m++) { CT[OC_FBIN + m] = fbin[m]; if (first) CT[OC_FBINP + m] = fbin[m]; }
+            for (int m = 0; m < M; m++) { const int nb = CT[OC_FBINN + m]; CT[OC_FBINP + m] = first ? nb : CT[OC_FBIN + m]; CT[OC_FBIN + m] = nb; }
         }
+        fecur ^= 1;
         wave_sync();
     };
 
@@ -494,8 +501,14 @@ __global__ __launch_bounds__(1024, FAST ? 4 : 5) void wenet_demod_oct_kernel(WrD
     };
 
     // ================================ frame loop ===============================================
-    int ran = 0;                                                         // chain wave: captures that demodulated at least one frame
-    if (is_cap && alive) { prefetch_est(0); prefetch_slot(0, nin); estimate(nin); }
+    // Exact mode, per frame k (four workgroup barriers):
+    //   A  duty wave: NCO chains of frame k          | capture waves: E(k+1) AHEAD, assuming nin(k+1) = N (they would idle otherwise)
+    //   B  capture waves: mix / integrate / timing products of frame k
+    //   C  duty wave: ordered timing sums of frame k
+    //   D  capture waves: timing estimate, nin(k+1), decisions; if nin(k+1) != N the estimator run of frame k+1 is repeated with the
+    //      true nin (it reads the untouched spectrum of frame k); then frame k+1 becomes the frame in work
+    int ran = 0;                                                         // duty wave: captures that demodulated at least one frame
+    if (is_cap && alive) { prefetch_est(0); prefetch_slot(0, nin); estimate(nin); commit_estimate(); if (!FAST) prefetch_est(nin); }
     if (FAST) {
         // no shared stages: every capture wave runs on its own
         while (alive) {
@@ -504,44 +517,61 @@ __global__ __launch_bounds__(1024, FAST ? 4 : 5) void wenet_demod_oct_kernel(WrD
             dstage(off, nin);
             const int nn = tstage(frames);
             const bool more = off1 + nn <= C.nsamples && frames + 1 < C.cap_frames;
-            if (lane == 0) { for (int m = 0; m < M; m++) CT[OC_FBINP + m] = CT[OC_FBIN + m]; CT[OC_NIN] = nn; }
             nslip += (nn != N) ? 1 : 0;
             off = off1; nin = nn; frames++;
             alive = more;
-            if (alive) { prefetch_slot(off, nin); estimate(nin); }
+            if (alive) { prefetch_slot(off, nin); estimate(nin); commit_estimate(); }
         }
     } else {
+        // development (WENET_RX_PROFILE=4): cycles of wave 0 and of the duty wave per phase, summed over the frames:
+        //   [0] phase D (to its barrier)  [1] phase A  [2] phase B  [3] phase C  [5] duty wave: chain busy  [6] frames; duty wave at +8
+        const bool pp = C.prof != nullptr && lane == 0 && (wave == 0 || is_chain);
+        long long *pr = C.prof + (is_chain ? 8 : 0);
+        long long pt[6] = {0, 0, 0, 0, 0, 0}, t0 = pp ? (long long)__builtin_readcyclecounter() : 0;
+#define WO_STAMP(k) do { if (pp) { const long long t1 = (long long)__builtin_readcyclecounter(); pt[k] += t1 - t0; t0 = t1; } } while (0)
         for (;;) {
-            lds_barrier();                                               // E(k) done, nin / bins / alive published
+            lds_barrier();                                               // nin(k), bins(k), alive published
+            WO_STAMP(0);
             const int mask = alive_mask();
             if (!mask) break;
+            const long long off1 = off + nin;
             if (is_chain) { chain(mask); ran |= mask; }
-            long long off1 = off + nin;
-            if (is_cap && alive) prefetch_est(off1);
+            if (pp && is_chain) { pt[5] += (long long)__builtin_readcyclecounter() - t0; }
+            if (is_cap && alive) { estimate(N); prefetch_est(off1 + N); }   // E(k+1) ahead; then the samples of E(k+2), one frame ahead again
+            if (pp && !is_chain) { pt[4] += (long long)__builtin_readcyclecounter() - t0; }
             lds_barrier();                                               // checkpoints of frame k
+            WO_STAMP(1);
             if (is_cap && alive) dstage(off, nin);
             lds_barrier();                                               // timing products
+            WO_STAMP(2);
             if (is_sum) tsum(mask);
             lds_barrier();                                               // timing sums
+            WO_STAMP(3);
             if (is_cap && alive) {
                 const int nn = tstage(frames);
                 const bool more = off1 + nn <= C.nsamples && frames + 1 < C.cap_frames;
-                if (lane == 0) { for (int m = 0; m < M; m++) CT[OC_FBINP + m] = CT[OC_FBIN + m]; CT[OC_NIN] = nn; CT[OC_ALIVE] = more ? 1 : 0; }
+                if (more) {
+                    prefetch_slot(off1, nn);
+                    if (nn != N) { prefetch_est(off1); estimate(nn); prefetch_est(off1 + nn); }      // (a timing slip: E(k+1) again)
+                    commit_estimate();
+                }
+                if (lane == 0) { CT[OC_NIN] = nn; CT[OC_ALIVE] = more ? 1 : 0; }
                 nslip += (nn != N) ? 1 : 0;
                 off = off1; nin = nn; frames++;
                 alive = more;
-                if (alive) { prefetch_slot(off, nin); estimate(nin); }
             }
         }
+        if (pp) { for (int k = 0; k < 6; k++) pr[k] = pt[k]; if (!is_chain) pr[6] = frames; }
+#undef WO_STAMP
     }
 
     // ================================ save carried state =======================================
     if (is_cap && present) {
         if (frames > 0) {
-            for (int i = lane; i < NH; i += 64) st_fft[i] = FE[i];
+            for (int i = lane; i < NH; i += 64) st_fft[i] = FE2[fecur * NH + i];
             for (int i = lane; i < nstash; i += 64) st_old[i] = cvt(raw16[off - nstash + i]);     // fsk.c:851 (off >= nin > nstash)
             if (lane < cfg.Nbits) st_sd[lane] = sdl;
-            if (lane < M) hdr->f_bin[lane] = CT[OC_FBINP + lane];
+            if (lane < M) hdr->f_bin[lane] = CT[OC_FBIN + lane];
         }
         if (lane == 0) {
             hdr->norm_rx_timing = norm_rx_timing_st;

@@ -173,13 +173,13 @@ struct DemodTables {
             cfg.N < cfg.Ndft + cfg.Ts / 2 || cfg.N + cfg.Ts / 2 >= 2 * cfg.Ndft || getenv("WENET_RX_NO_OCT") != nullptr)
             return c;
         if (caps < 1) caps = 1;
-        if (caps > 14) caps = 14;
+        if (caps > 15) caps = 15;
         const int NH = cfg.Ndft / 2, NIq = (cfg.NI + 3) & ~3, H = cfg.Ts / 2;
         c.o_caps = caps;
         c.o_nhb = (cfg.L + H - 1) / H;
         int t = 0;
         c.o_off_FB = t;  t = align16(t + (cfg.Ndft * 8 > 2 * NIq * 4 ? cfg.Ndft * 8 : 2 * NIq * 4));   // FFT buffer, then the timing products
-        c.o_off_FE = t;  t = align16(t + NH * 4);
+        c.o_off_FE = t;  t = align16(t + 2 * NH * 4);
         c.o_off_FW = t;  t = align16(t + NH * 4);
         c.o_off_CK = t;  t = align16(t + cfg.M * c.o_nhb * 8);
         c.o_off_CT = t;  t = align16(t + 16 * 4);
@@ -865,7 +865,7 @@ struct wenet_rx {
     long long fast_flagged = 0;                          // captures of the last fast batch that were re-run through the exact kernel
     int nchan = 0, max_pk = 0;
     std::vector<long long> sd_off, cap_frames;           // per channel: float offset into d_sd, frame capacity
-    DevBuf d_states, d_chans, d_dchans, d_dstates, d_sd, d_starts, d_out, d_trace, d_llr, d_raw, d_prof, d_esn0, d_census, d_big;
+    DevBuf d_states, d_chans, d_chans2, d_dchans, d_dstates, d_sd, d_starts, d_out, d_trace, d_llr, d_raw, d_prof, d_esn0, d_census, d_big;
     std::vector<unsigned> h_census;
     bool profile = false;
     double slip_rate = 0.0;                              // share of frames with nin != N in the last collected batch
@@ -927,6 +927,7 @@ extern "C" void wenet_rx_enable_trace(wenet_rx *rx, int on) { if (rx) { rx->want
 extern "C" void wenet_rx_enable_llr_dump(wenet_rx *rx, int on) { if (rx) rx->want_llr = on != 0; }
 extern "C" void wenet_rx_set_fast(wenet_rx *rx, int on) { if (rx) rx->fast = on ? 1 : 0; }
 extern "C" const char *wenet_rx_last_kernel(wenet_rx *rx) { return rx ? rx->last_kernel : ""; }
+extern "C" long long wenet_rx_fast_reruns(wenet_rx *rx) { return rx ? rx->fast_flagged : -1; }
 
 // raw[i]: device address of capture i.  host_src != nullptr: its content still has to be copied there from host_src[i];
 // the batch is then cut into sub-batches whose uploads (copy stream) overlap the kernels of the previous sub-batch.
@@ -1024,15 +1025,15 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const lon
     // pipelined kernels: 11.5 k), so it takes over once the CUs hold several captures each.  WENET_RX_OCT=<caps> forces it
     // (tests), WENET_RX_NO_OCT turns it off.  Traces with Eb/N0 accumulators and profiling stay with the pipelined kernels.
     int oct_caps = 0;
-    if (fmt == WENET_FMT_CU8 && !rx->profile) {
+    if (fmt == WENET_FMT_CU8 && (!rx->profile || getenv("WENET_RX_PROFILE")[0] == '4')) {
         const char *force = getenv("WENET_RX_OCT");
-        if (force) oct_caps = atoi(force) > 0 ? atoi(force) : 8;
-        else if (!rx->want_trace && nchan >= 6 * wenet_rx_device_info(1)) oct_caps = 8;
+        if (force) oct_caps = atoi(force) > 0 ? atoi(force) : 7;
+        else if (!rx->want_trace && nchan >= 6 * wenet_rx_device_info(1)) oct_caps = 7;
     }
     WrDemodCfg oct_cfg;
     bool use_oct = false;
     if (oct_caps > 0 || rx->fast) {
-        oct_cfg = rx->tab.oct_cfg(oct_caps > 0 ? oct_caps : 8);
+        oct_cfg = rx->tab.oct_cfg(oct_caps > 0 ? oct_caps : 7);
         use_oct = oct_cfg.o_ok != 0 && fmt == WENET_FMT_CU8;
     }
     const int oct_fast = use_oct && rx->fast ? 1 : 0;
@@ -1072,6 +1073,34 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const lon
         WR_CHECK(hipEventRecord(e.ev[0], stream), -4);
         if (use_oct) WR_CHECK(wr_launch_demod_oct(&oct_cfg, rx->d_chans.as<WrChan>() + lo, n, stream, oct_fast), -4);
         else WR_CHECK(wr_launch_demod_ex(&launch_cfg, rx->d_chans.as<WrChan>() + lo, n, stream, prof), -4);
+        if (oct_fast) {
+            // Fast mode: a capture with a frame whose timing estimate fell within the guard band of a nin threshold (fsk.c:900-907)
+            // may have taken the other branch than the reference; it is demodulated again, from reset state, by an exact kernel
+            // (the decisions of all other captures are the reference's: verified frame by frame in tests/test_gpu_oct.py).
+            WR_CHECK(hipMemcpyAsync(rx->h_states.data() + (size_t)lo * c.st_floats, rx->d_states.as<float>() + (size_t)lo * c.st_floats,
+                                    stb * n, hipMemcpyDeviceToHost, stream), -3);
+            WR_CHECK(hipStreamSynchronize(stream), -3);
+            std::vector<WrChan> redo;
+            for (int i = lo; i < hi; i++)
+                if (((const WrChanHdr *)&rx->h_states[(size_t)i * c.st_floats])->uncertain_call > 0) {
+                    redo.push_back(chans[i]);
+                    WR_CHECK(hipMemcpyAsync(chans[i].state, st0.data(), stb, hipMemcpyHostToDevice, stream), -3);
+                }
+            if (k == 0) rx->fast_flagged = 0;
+            rx->fast_flagged += (long long)redo.size();
+            if (!redo.empty()) {
+                if (!rx->d_chans2.reserve(sizeof(WrChan) * redo.size())) return -2;
+                WR_CHECK(hipMemcpyAsync(rx->d_chans2.p, redo.data(), sizeof(WrChan) * redo.size(), hipMemcpyHostToDevice, stream), -3);
+                WR_CHECK(hipStreamSynchronize(stream), -3);                  // (redo goes out of scope)
+                const int nr = (int)redo.size();
+                if (nr >= 4 * ncu) WR_CHECK(wr_launch_demod_oct(&oct_cfg, rx->d_chans2.as<WrChan>(), nr, stream, 0), -4);
+                else {
+                    WrDemodCfg rc = (2 * nr >= 3 * ncu) ? rx->tab.tri_cfg() : (nr > 2 * ncu ? rx->tab.raw_cfg() : rx->tab.cfg);
+                    rc.p_tsum_split = (rc.p_tri || nr > ncu) ? 1 : 0;
+                    WR_CHECK(wr_launch_demod_ex(&rc, rx->d_chans2.as<WrChan>(), nr, stream, 0), -4);
+                }
+            }
+        }
         WR_CHECK(hipEventRecord(e.ev[1], stream), -4);
         WR_CHECK(wr_launch_deframe(rx->d_dchans.as<WrDeframeChan>() + lo, n, rx->mode, stream), -4);
         WR_CHECK(hipEventRecord(e.ev[2], stream), -4);

@@ -39,6 +39,10 @@ class RxBatch:
         """fast mode (parity-ladder rung P3, include/wenet_rx.h): soft decisions within ~1e-6 of the reference's instead of bit-identical."""
         self._L.wenet_rx_set_fast(self._h, 1 if on else 0)
 
+    def fast_reruns(self):
+        """captures of the last fast-mode batch that the library demodulated again with the exact kernel"""
+        return int(self._L.wenet_rx_fast_reruns(self._h))
+
     def last_kernel(self):
         return self._L.wenet_rx_last_kernel(self._h).decode()
 
