@@ -41,8 +41,8 @@ for ch in range(0, B, int(caps)):
     n = L.wenet_rx_debug_profile(rx._h, ch, buf)
     v = list(buf)
     fr = max(v[6], 1)
-    names = ["D decide", "A chain|E-ahead", "B mix/integ", "C sums"]
-    print(f"group@{ch}: frames {v[6]}; per frame (wave 0): " + ", ".join(f"{names[k]} {v[k] / fr:.0f}" for k in range(4)) +
-          f" | E-ahead busy {v[4] / fr:.0f}, chain busy {v[8 + 5] / fr:.0f}  total/frame {sum(v[:4]) / fr:.0f}")
+    print(f"group@{ch}: frames {v[6]}; per frame: wave 0: decide+E-ahead+wait {v[0] / fr:.0f} (busy {v[4] / fr:.0f}), mix/integ {v[1] / fr:.0f}, wait sums {v[2] / fr:.0f}"
+          f" [T1 to publish {v[3] / fr:.0f}, +T2+prefetch {(v[5] - v[3]) / fr:.0f}, +FFT ahead {(v[4] - v[5]) / fr:.0f}]"
+          f" | duty: wait nin {v[8] / fr:.0f}, chains {v[9] / fr:.0f}, barriers {v[10] / fr:.0f}, sums {v[11] / fr:.0f} | total/frame {sum(v[8:12]) / fr:.0f}")
     if ch >= 3 * int(caps):
         break

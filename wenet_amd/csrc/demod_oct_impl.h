@@ -9,8 +9,8 @@
 // stages are done for all eight captures of the workgroup at once by two extra wavefronts:
 //
 //     waves 0..7   capture wave c:  E(k) estimator | mix + slot-ordered integrate + timing products | atan2f, nin, decisions
-//     wave  8      NCO chain of the eight captures (lanes 4c..4c+3 = tone x {re, im} of capture c), checkpoint every Ts/2 steps
-//     wave  9      ordered timing sums of the eight captures (lanes 2c, 2c+1 = re, im)
+//     duty wave    NCO chains of the captures (lane 2c + m = tone m of capture c), a checkpoint every Ts/2 steps;
+//                  later in the frame the ordered timing sums of the captures (lanes 2c, 2c+1 = re, im)
 //
 // Per frame: [E(k)] barrier [chain(k)] barrier [mix/integrate(k)] barrier [sums(k)] barrier [decide(k), E(k+1)] ...  Two such
 // workgroups share a CU (62 KB of LDS each), so one group's narrow phases run under the other's wide ones.
@@ -43,7 +43,8 @@
 namespace {
 
 enum { OC_NIN = 0, OC_ALIVE = 1, OC_FBIN = 2 /* [2] this frame */, OC_FBINP = 4 /* [2] previous frame, first-run rule applied (fsk.c:750-753) */,
-       OC_FBINN = 6 /* [2] next frame (estimated ahead, see the frame loop) */, OC_TC = 10 /* float re, im: timing sum */, OC_INTS = 16 };
+       OC_FBINN = 6 /* [2] next frame (estimated ahead, see the frame loop) */, OC_TC = 10 /* float re, im: timing sum */,
+       OC_SEQ = 12 /* frames whose nin, bins and alive flag are published: the duty wave starts a frame's chains on it */, OC_INTS = 16 };
 
 typedef __attribute__((address_space(3))) float oct_lds_f32;
 
@@ -53,15 +54,27 @@ __device__ __forceinline__ float lane_up(float v) {
 }
 __device__ __forceinline__ v2f lane_up(v2f v) { return (v2f){lane_up(v.x), lane_up(v.y)}; }
 
+// x * conj(p) = (x.x p.x + x.y p.y, x.y p.x - x.x p.y): the products and sums of c_mul(x, c_conj(p)) (comp_prim.h:47-65), each rounded
+// once, in three packed instructions
+__device__ __forceinline__ v2f cmul_conj_pk(v2f x, v2f p) {
+    v2f r, t1, t2;
+    asm("v_pk_mul_f32 %1, %3, %4 op_sel_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %2, %3, %4 op_sel:[1,1] op_sel_hi:[0,1]\n\t"
+        "v_pk_add_f32 %0, %1, %2 neg_lo:[0,0] neg_hi:[0,1]"
+        : "=v"(r), "=&v"(t1), "=&v"(t2)
+        : "v"(x), "v"(p));
+    return r;
+}
+
 template <int N>
-__device__ __forceinline__ float nco_steps(float own, float k1, float k2) {          // N steps of nco_step_split in one asm block
-    float t1, t2;
-#define WO_NCO1 "v_mul_f32 %1, %0, %3\n\ts_nop 0\n\tv_mul_f32_dpp %2, %0, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_add_f32 %0, %1, %2\n\t"
+__device__ __forceinline__ v2f nco_steps(v2f phi, v2f d) {           // N steps phi *= d (cmul_pk) in one asm block: no padding between them
+    v2f t1, t2;
+#define WO_NCO1 "v_pk_mul_f32 %1, %0, %3 op_sel_hi:[1,0]\n\tv_pk_mul_f32 %2, %0, %3 op_sel:[1,1] op_sel_hi:[0,1]\n\tv_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]\n\t"
     static_assert(N == 4 || N == 5, "half a symbol of Ts 8 or 10");
-    if (N == 4) asm(WO_NCO1 WO_NCO1 WO_NCO1 WO_NCO1 : "+v"(own), "=&v"(t1), "=&v"(t2) : "v"(k1), "v"(k2));
-    else asm(WO_NCO1 WO_NCO1 WO_NCO1 WO_NCO1 WO_NCO1 : "+v"(own), "=&v"(t1), "=&v"(t2) : "v"(k1), "v"(k2));
+    if (N == 4) asm(WO_NCO1 WO_NCO1 WO_NCO1 WO_NCO1 : "+v"(phi), "=&v"(t1), "=&v"(t2) : "v"(d));
+    else asm(WO_NCO1 WO_NCO1 WO_NCO1 WO_NCO1 WO_NCO1 : "+v"(phi), "=&v"(t1), "=&v"(t2) : "v"(d));
 #undef WO_NCO1
-    return own;
+    return phi;
 }
 
 }  // namespace
@@ -82,8 +95,8 @@ __global__ __launch_bounds__(1024, 4) void wenet_demod_oct_kernel(WrDemodCfg cfg
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
     unsigned char *smem = smem_all + cap * cfg.o_cap_stride;
-    float2 *FB = (float2 *)(smem + cfg.o_off_FB);                        // [Ndft] estimator FFT buffer ...
-    float  *TPf = (float *)(smem + cfg.o_off_FB);                        // ... later the frame's timing products: a row of re, a row of im
+    float2 *FB = (float2 *)(smem + cfg.o_off_FB);                        // [Ndft] estimator FFT buffer
+    float  *TPf = (float *)(smem + cfg.o_off_TP);                        // the frame's timing products: a row of re, a row of im
     float  *FE2 = (float *)(smem + cfg.o_off_FE);                        // [2][Ndft/2] smoothed spectrum after this frame's estimator run | after the next one's
     float  *FW = (float *)(smem + cfg.o_off_FW);                         // [Ndft/2]
     float2 *CK = (float2 *)(smem + cfg.o_off_CK);                        // [M][o_nhb] phasor at the start of every half symbol
@@ -136,80 +149,142 @@ __global__ __launch_bounds__(1024, 4) void wenet_demod_oct_kernel(WrDemodCfg cfg
         }
         alive = present && (long long)nin <= C.nsamples && C.cap_frames > 0;
         if (lane < M) CT[OC_FBIN + lane] = present ? hdr->f_bin[lane] : 0;           // bins of the frame before this launch
-        if (lane == 0) { CT[OC_NIN] = nin; CT[OC_ALIVE] = alive ? 1 : 0; }
+        if (lane == 0) { CT[OC_NIN] = nin; CT[OC_ALIVE] = alive ? 1 : 0; CT[OC_SEQ] = 0; }
     }
-    // chain wave: lane 4c + 2m + part carries one component of phi_c[m] of capture c, in a register, across the frames
-    float own = 0.f;
+    // duty wave: lane M c + m carries phi_c[m] of capture c, in registers, across the frames.  (Latency, not SIMD time, is what the
+    // chain costs here -- the capture waves wait for it -- so it runs in the packed form: three dependent instructions per step.)
+    v2f own = {1.f, 0.f};
     if (is_chain) {
-        const int cc = lane / (2 * M), m = (lane >> 1) % M, part = lane & 1;
+        const int cc = lane / M, m = lane % M;
         const int chc = blockIdx.x * G + cc;
         if (cc < G && chc < nchan) {
             const WrChanHdr *h = (const WrChanHdr *)chans[chc].state;
-            own = part ? h->phi_c[m].y : h->phi_c[m].x;
-        } else own = part ? 0.f : 1.f;
+            own = (v2f){h->phi_c[m].x, h->phi_c[m].y};
+        }
     }
     lds_barrier();
 
-    auto cvt = [](unsigned w) -> float2 {                                // fsk_demod.c:283-284, exact in float
-        return make_float2(((float)(w & 0xffu) - 127.0f) / 128.0f, ((float)((w >> 8) & 0xffu) - 127.0f) / 128.0f);
+    auto cvt = [](unsigned w) -> float2 {                                // fsk_demod.c:283-284: ((float)u8 - 127) / 128 is exact in float, and so is
+        // the one-rounding form u8/128 - 127/128 (the exact value is representable): one instruction per component
+        return make_float2(__builtin_fmaf((float)(w & 0xffu), 0.0078125f, -0.9921875f), __builtin_fmaf((float)((w >> 8) & 0xffu), 0.0078125f, -0.9921875f));
     };
 
     // ================================ capture-wave stages ======================================
     unsigned epre[NE];                                                   // estimator samples of the NEXT frame (its start is known a frame ahead)
-    unsigned xr[TS];                                                     // this lane's symbol slot of the frame about to be mixed
+    unsigned xr[TS / 2 + 1];                                             // this lane's symbol slot of the frame about to be mixed, two cu8 samples per dword
+    const int NBLK = (L + TS - 1) / TS;                                  // lanes that own samples
+    const int slot = lane < NBLK ? lane : NBLK - 1;                      // (idle lanes repeat the last slot: always inside the frame)
     auto prefetch_est = [&](long long off_j) {
+        if (off_j + Ndft <= C.nsamples) {                                // the whole transform window is inside the capture: no index clamping
+            const unsigned short *p = raw16 + off_j;
 #pragma unroll
-        for (int j = 0; j < NE; j++) { long long a = off_j + src_t[lane + 64 * j]; epre[j] = raw16[a < last_smp ? a : last_smp]; }
+            for (int j = 0; j < NE; j++) epre[j] = p[src_t[4 * lane + j]];
+        } else {                                                         // (a run ahead of the capture's end: its result is never used)
+#pragma unroll
+            for (int j = 0; j < NE; j++) { long long a = off_j + src_t[4 * lane + j]; epre[j] = raw16[a < last_smp ? a : last_smp]; }
+        }
     };
+    // The lane's symbol slot as TS/2 + 1 aligned dwords (two cu8 samples each) starting at the even sample at or below its first
+    // one; slot_align() shifts them down by a sample when the first one is odd -- at the point of use, so the loads stay in flight.
     auto prefetch_slot = [&](long long off_j, int nin_j) {
-        const long long a0 = off_j - (Nmem - nin_j) + TS * lane;         // (negative only in a launch's first frame: patched from samp_old)
+        const long long b0 = off_j - (Nmem - nin_j);                     // buffer position 0 (negative only in a launch's first frame)
+        if (b0 >= 0 && b0 + Nmem + 1 <= C.nsamples) {                    // positions 0 .. Nmem (one past the window) are samples of the capture
+            const unsigned *p = (const unsigned *)(raw16 + ((b0 & ~1LL) + TS * slot));
 #pragma unroll
-        for (int u = 0; u < TS; u++) { long long a = a0 + u; a = a < 0 ? 0 : (a < last_smp ? a : last_smp); xr[u] = raw16[a]; }
+            for (int u = 0; u < TS / 2 + 1; u++) xr[u] = p[u];
+        } else {                                                         // first frame (window starts in the carried samp_old[]) / capture's last sample
+            unsigned w[TS];
+#pragma unroll
+            for (int u = 0; u < TS; u++) {
+                const long long a = b0 + TS * slot + u;
+                if (a < 0) {                                             // carried samples came from cu8 input (or are the zeros of a reset): exact inverse
+                    const float2 v = present ? st_old[nstash + a] : make_float2(0.f, 0.f);
+                    w[u] = (unsigned)(int)(v.x * 128.0f + 127.0f) | ((unsigned)(int)(v.y * 128.0f + 127.0f) << 8);
+                } else w[u] = raw16[a < last_smp ? a : last_smp];
+            }
+            const bool odd = (b0 & 1) != 0;                              // leave them as slot_align() expects them
+#pragma unroll
+            for (int u = 0; u < TS / 2 + 1; u++) {
+                const unsigned lo = odd ? (2 * u - 1 >= 0 && 2 * u - 1 < TS ? w[2 * u - 1 < 0 ? 0 : (2 * u - 1 < TS ? 2 * u - 1 : 0)] : 0u) : (2 * u < TS ? w[2 * u < TS ? 2 * u : 0] : 0u);
+                const unsigned hi = odd ? (2 * u < TS ? w[2 * u < TS ? 2 * u : 0] : 0u) : (2 * u + 1 < TS ? w[2 * u + 1 < TS ? 2 * u + 1 : 0] : 0u);
+                xr[u] = lo | (hi << 16);
+            }
+        }
+    };
+    auto slot_align = [&](long long off_j, int nin_j) {
+        if ((off_j - (Nmem - nin_j)) & 1) {
+#pragma unroll
+            for (int u = 0; u < TS / 2; u++) xr[u] = __builtin_amdgcn_alignbit(xr[u + 1], xr[u], 16);
+        }
+    };
+    auto slot_sample = [&](int u) -> v2f {                               // sample u of the (aligned) slot -> COMP, fsk_demod.c:283-284
+        const unsigned w = xr[u >> 1] >> (16 * (u & 1));
+        // ((float)u8 - 127) / 128 is exact in float, and so is the one-rounding form u8/128 - 127/128: one instruction per component
+        return (v2f){__builtin_fmaf((float)(w & 0xffu), 0.0078125f, -0.9921875f), __builtin_fmaf((float)((w >> 8) & 0xffu), 0.0078125f, -0.9921875f)};
     };
 
     // E(j): tone estimator (fsk.c:540-677) on the prefetched samples; one FFT (Ndft <= nin < 2 Ndft)
     int fecur = 0;                                                       // FE2[fecur]: spectrum after the estimator run of the frame in work
-    auto estimate = [&](int nin_j) {                                     // reads FE2[fecur], leaves FE2[fecur ^ 1] and the bins in OC_FBINN
-        const float *FEin = FE2 + fecur * NH;
-        float *FEout = FE2 + (fecur ^ 1) * NH;
+    // E(j) in two parts: estimate_fft (window + FFT, leaves the spectrum in FB) and estimate_pick (magnitude, smoothing, tone
+    // search: reads FE2[fecur], leaves FE2[fecur ^ 1] and the bins in OC_FBINN)
+    // 256 points = four radix-4 stages of kiss_fft's decimation-in-time recursion (kiss_fft.c:237-302, kf_bfly4 :44-90), innermost
+    // butterflies first.  Lane b loads the four digit-reversed inputs of ITS first butterfly (elements 4b .. 4b+3), so the window
+    // goes straight into stage one; that stage's twiddles are all tw[0] = (1, -0), a multiplication that changes nothing but the
+    // sign of a zero (which no later sum or |.|^2 can see); of the last stage only the Ndft/2 outputs the spectrum reads are formed.
+    auto bfly4 = [&](float2 f0, float2 s0, float2 s1, float2 s2, float2 &o0, float2 &o1, float2 &o2, float2 &o3) {
+        const float2 s5 = make_float2(f0.x - s1.x, f0.y - s1.y);
+        f0 = make_float2(f0.x + s1.x, f0.y + s1.y);
+        const float2 s3 = make_float2(s0.x + s2.x, s0.y + s2.y);
+        const float2 s4 = make_float2(s0.x - s2.x, s0.y - s2.y);
+        o2 = make_float2(f0.x - s3.x, f0.y - s3.y);
+        o0 = make_float2(f0.x + s3.x, f0.y + s3.y);
+        o1 = make_float2(s5.x + s4.y, s5.y - s4.x);
+        o3 = make_float2(s5.x - s4.y, s5.y + s4.x);
+    };
+    auto estimate_fft = [&](int nin_j) {
         const int fft_samps = nin_j - Ndft;                              // fsk.c:583-584 with fft_loops == 1
+        float2 v[4];
 #pragma unroll
-        for (int j = 0; j < NE; j++) {
-            const int n = lane + 64 * j, idx = src_t[n];
-            float2 v = make_float2(0.f, 0.f);
-            if (idx < fft_samps) { const float h = hann_t[idx]; const float2 x = cvt(epre[j]); v = make_float2(h * x.x, h * x.y); }
-            FB[n] = v;
+        for (int j = 0; j < NE; j++) {                                   // fsk.c:587-603: half-Hann window, zero padding
+            const int idx = src_t[4 * lane + j];
+            v[j] = make_float2(0.f, 0.f);
+            if (idx < fft_samps) { const float h = hann_t[idx]; const float2 x = cvt(epre[j]); v[j] = make_float2(h * x.x, h * x.y); }
+        }
+        {
+            float2 o0, o1, o2, o3;
+            bfly4(v[0], v[1], v[2], v[3], o0, o1, o2, o3);
+            float4 *F4 = (float4 *)(FB + 4 * lane);
+            F4[0] = make_float4(o0.x, o0.y, o1.x, o1.y);
+            F4[1] = make_float4(o2.x, o2.y, o3.x, o3.y);
         }
         wave_sync();
-        for (int s = cfg.nstages - 1; s >= 0; s--) {
-            const int m = cfg.mstage[s], p = cfg.radix[s], fs = cfg.fstride[s];
-            const int lgm = 31 - __clz(m);
-            const int nb = Ndft / p;
-            for (int b = lane; b < nb; b += 64) {
-                const int blk = b >> lgm, k = b & (m - 1);
-                float2 *F = FB + blk * m * p + k;
-                if (p == 4) {                                            // kf_bfly4 (kiss_fft.c:44-90)
-                    const float2 s0 = cmul(F[m], tw_t[k * fs]);
-                    const float2 s1 = cmul(F[2 * m], tw_t[k * fs * 2]);
-                    const float2 s2 = cmul(F[3 * m], tw_t[k * fs * 3]);
-                    float2 f0 = F[0];
-                    const float2 s5 = make_float2(f0.x - s1.x, f0.y - s1.y);
-                    f0 = make_float2(f0.x + s1.x, f0.y + s1.y);
-                    const float2 s3 = make_float2(s0.x + s2.x, s0.y + s2.y);
-                    const float2 s4 = make_float2(s0.x - s2.x, s0.y - s2.y);
-                    F[2 * m] = make_float2(f0.x - s3.x, f0.y - s3.y);
-                    F[0] = make_float2(f0.x + s3.x, f0.y + s3.y);
-                    F[m] = make_float2(s5.x + s4.y, s5.y - s4.x);
-                    F[3 * m] = make_float2(s5.x - s4.y, s5.y + s4.x);
-                } else {                                                 // kf_bfly2 (kiss_fft.c:21-42)
-                    const float2 t = cmul(F[m], tw_t[k * fs]);
-                    const float2 f0 = F[0];
-                    F[m] = make_float2(f0.x - t.x, f0.y - t.y);
-                    F[0] = make_float2(f0.x + t.x, f0.y + t.y);
-                }
-            }
+#pragma unroll
+        for (int st = 0; st < 2; st++) {                                 // m = 4, fstride 16;  m = 16, fstride 4
+            const int lgm = st ? 4 : 2, m = 1 << lgm, fs = st ? 4 : 16;
+            const int blk = lane >> lgm, k = lane & (m - 1);
+            float2 *F = FB + blk * m * 4 + k;
+            const float2 s0 = cmul(F[m], tw_t[k * fs]);
+            const float2 s1 = cmul(F[2 * m], tw_t[k * fs * 2]);
+            const float2 s2 = cmul(F[3 * m], tw_t[k * fs * 3]);
+            float2 o0, o1, o2, o3;
+            bfly4(F[0], s0, s1, s2, o0, o1, o2, o3);
+            F[0] = o0; F[m] = o1; F[2 * m] = o2; F[3 * m] = o3;
             wave_sync();
         }
+        {                                                                // m = 64, fstride 1: outputs 0 .. Ndft/2 - 1 only
+            float2 *F = FB + lane;
+            const float2 s0 = cmul(F[64], tw_t[lane]);
+            const float2 s1 = cmul(F[128], tw_t[2 * lane]);
+            const float2 s2 = cmul(F[192], tw_t[3 * lane]);
+            float2 o0, o1, o2, o3;
+            bfly4(F[0], s0, s1, s2, o0, o1, o2, o3);
+            F[0] = o0; F[64] = o1;
+            wave_sync();
+        }
+    };
+    auto estimate_pick = [&]() {
+        const float *FEin = FE2 + fecur * NH;
+        float *FEout = FE2 + (fecur ^ 1) * NH;
         for (int i = lane; i < NH; i += 64) {                            // fsk.c:612-628
             const float2 v = FB[i];
             float mag = (v.x * v.x) + (v.y * v.y);
@@ -247,6 +322,7 @@ __global__ __launch_bounds__(1024, 4) void wenet_demod_oct_kernel(WrDemodCfg cfg
         if (lane == 0) { CT[OC_FBINN] = fbin[0]; CT[OC_FBINN + 1] = fbin[1]; }
         wave_sync();
     };
+    auto estimate = [&](int nin_j) { estimate_fft(nin_j); estimate_pick(); };
     // the frame whose estimator run is in OC_FBINN / FE2[fecur ^ 1] becomes the frame in work.  First-run rule (fsk.c:750-753): while
     // the stored estimate of tone 0 is below 1 Hz the old part of the frame is mixed with the NEW estimates
     auto commit_estimate = [&]() {
@@ -263,13 +339,10 @@ __global__ __launch_bounds__(1024, 4) void wenet_demod_oct_kernel(WrDemodCfg cfg
     // D(j): mix, integrate, timing products
     auto dstage = [&](long long off_j, int nin_j) {
         const int nold = Nmem - nin_j;
-        float2 x[TS];
+        slot_align(off_j, nin_j);
+        v2f x[TS];
 #pragma unroll
-        for (int u = 0; u < TS; u++) x[u] = cvt(xr[u]);
-        if (off_j < (long long)nold) {                                   // first frame of a launch: the window starts in the carried samp_old[]
-#pragma unroll
-            for (int u = 0; u < TS; u++) { const long long a = off_j - nold + TS * lane + u; if (a < 0 && present) x[u] = st_old[nstash + a]; }
-        }
+        for (int u = 0; u < TS; u++) x[u] = slot_sample(u);
         float ft1[TS];
 #pragma unroll
         for (int m = 0; m < M; m++) {
@@ -278,31 +351,28 @@ __global__ __launch_bounds__(1024, 4) void wenet_demod_oct_kernel(WrDemodCfg cfg
                 const float2 dA2 = dphi_t[CT[OC_FBINP + m]], dB2 = dphi_t[CT[OC_FBIN + m]];
 #pragma unroll
                 for (int hh = 0; hh < 2; hh++) {
-                    const int hb = 2 * lane + hh;
+                    const int hb = 2 * slot + hh;
                     const float2 p2 = CK[m * NHB + (hb < NHB ? hb : NHB - 1)];
                     v2f phi = {p2.x, p2.y};
                     const bool segA = hb * H < nold;
                     const v2f dd = {segA ? dA2.x : dB2.x, segA ? dA2.y : dB2.y};
 #pragma unroll
                     for (int u = 0; u < H; u++) {
-                        const float2 mx = cmul(x[hh * H + u], make_float2(phi.x, -phi.y));       // fsk.c:796 / :822
-                        d[hh * H + u] = (v2f){mx.x, mx.y};
+                        d[hh * H + u] = cmul_conj_pk(x[hh * H + u], phi);                                // fsk.c:796 / :822
                         if (u < H - 1) phi = cmul_pk(phi, dd);                                     // fsk.c:798 / :824 (replayed from the checkpoint)
                     }
                 }
-                // slot-ordered window sums (fsk.c:829-840), see the header
-                v2f P[TS + 1];
-                P[1] = (v2f){0.f, 0.f} + d[0];
-#pragma unroll
-                for (int n = 1; n < TS; n++) P[n + 1] = P[n] + d[n];
-                F[m][0] = P[TS];
+                // slot-ordered window sums (fsk.c:829-840), see the header: `run` is the block's running prefix sum
+                v2f run = (v2f){0.f, 0.f} + d[0];
 #pragma unroll
                 for (int r = 1; r < TS; r++) {
-                    v2f acc = lane_up(P[r]) + d[r];
+                    v2f acc = lane_up(run) + d[r];
 #pragma unroll
                     for (int n = r + 1; n < TS; n++) acc = acc + d[n];
                     F[m][r] = acc;
+                    run = run + d[r];
                 }
+                F[m][0] = run;
             } else {
 #pragma clang fp contract(fast)
                 // phasor of buffer position s: the old part of the frame turns with the previous bin, the new part with this frame's,
@@ -326,17 +396,19 @@ __global__ __launch_bounds__(1024, 4) void wenet_demod_oct_kernel(WrDemodCfg cfg
             }
 #pragma unroll
             for (int r = 0; r < TS; r++) {                               // fsk.c:862-868
-                const float a = (F[m][r].x * F[m][r].x) + (F[m][r].y * F[m][r].y);
+                const v2f sq = F[m][r] * F[m][r];
+                const float a = sq.x + sq.y;
                 ft1[r] = (m == 0) ? a : ft1[r] + a;
             }
         }
         if (!FAST) {
             if (lane < NOUT) {
 #pragma unroll
-                for (int r = 0; r < TS; r++) {
-                    const float2 pf = pft_t[TS * lane + r];
-                    TPf[TS * lane + r] = ft1[r] * pf.x;                  // fsk.c:870-871: the products; wave 9 adds them in order
-                    TPf[NIq + TS * lane + r] = ft1[r] * pf.y;
+                for (int r = 0; r < TS; r += 2) {                        // fsk.c:870-871: the products; the duty wave adds them in order
+                    const float2 pa = pft_t[TS * lane + r], pb = pft_t[TS * lane + r + 1];
+                    const v2f ta = (v2f){ft1[r], ft1[r]} * (v2f){pa.x, pa.y}, tb = (v2f){ft1[r + 1], ft1[r + 1]} * (v2f){pb.x, pb.y};
+                    *(float2 *)(TPf + TS * lane + r) = make_float2(ta.x, tb.x);
+                    *(float2 *)(TPf + NIq + TS * lane + r) = make_float2(ta.y, tb.y);
                 }
             }
         } else {
@@ -353,32 +425,59 @@ __global__ __launch_bounds__(1024, 4) void wenet_demod_oct_kernel(WrDemodCfg cfg
     };
 
     // T(j): timing estimate, nin of the next frame, resampling and decisions (fsk.c:876-993); returns nin(j+1)
-    auto tstage = [&](long long fr) -> int {
+    // T(j) in two parts.  tstage1: timing estimate and nin of the next frame (fsk.c:876-907) -- everything the next frame's NCO
+    // chain waits for; tstage2: resampling, decisions, outputs (fsk.c:913-993).
+    float t_rxt = 0.f, t_fract = 0.f;
+    int t_low = 0, t_high = 0, t_nin_next = 0, t_bins[M] = {0, 0};      // (t_bins: tone bins of the frame, for the trace)
+    bool t_nan = false;
+    // nin(k+1) first: norm_rx_timing = (float)((double)atan2f / 2 pi) is monotone in the atan2f value, so "norm_rx_timing > 0.25f"
+    // is the same predicate as "atan2f > o_at_hi" (the host finds the float where it flips, DemodTables::oct_cfg): the double
+    // division leaves the path the next frame's NCO chain waits on
+    float t_at = 0.f, t_tcr = 0.f, t_tci = 0.f;
+    bool t_have_at = false;
+    auto tstage1a = [&]() -> int {
         const float tcr = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(((const float *)CT)[OC_TC])));
         const float tci = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(((const float *)CT)[OC_TC + 1])));
+        t_nan = (tcr != tcr) || (tci != tci);                            // fsk.c:878-880
         int nin_next = nin;
-        float tr_rxt = 0.f;
-        const bool nan_frame = (tcr != tcr) || (tci != tci);             // fsk.c:878-880
-        if (!nan_frame) {
-            const float at = wg_atan2f(tci, tcr);
+        t_have_at = false;
+        if (!t_nan) {
+            // an angle well inside (-pi/2, pi/2) -- |angle| < atan(16) = 86.4 degrees, all but a few per cent of the frames of a locked
+            // signal -- leaves nin at N whatever the last bits of atan2f are: the value itself is then computed after the publication
+            if (16.0f * tcr > fabsf(tci)) nin_next = N;
+            else {
+                t_at = wg_atan2f(tci, tcr); t_have_at = true;
+                nin_next = t_at > cfg.o_at_hi ? N + TS / 2 : (t_at < cfg.o_at_lo ? N - TS / 2 : N);  // fsk.c:900-907
+            }
+        }
+        t_tcr = tcr; t_tci = tci;
+        t_nin_next = __builtin_amdgcn_readfirstlane(nin_next);
+        return t_nin_next;
+    };
+    auto tstage1b = [&]() {
+        t_rxt = 0.f;
+        if (!t_nan) {
+            if (!t_have_at) t_at = wg_atan2f(t_tci, t_tcr);
+            const float at = t_at;
             const float norm_rx_timing = (float)((double)at / (2 * 3.14159265358979323846));
             const float rx_timing = norm_rx_timing * cfg.P_f;
             const float d_nrt = norm_rx_timing - norm_rx_timing_st;
             norm_rx_timing_st = norm_rx_timing;
-            if ((double)fabsf(d_nrt) < .2) {
+            // ppm (fsk.c:890-896) feeds nothing but the statistics: it is kept up only when a trace is asked for
+            if (C.trace && (double)fabsf(d_nrt) < .2) {
                 const float appm = (float)(1e6 * (double)d_nrt / (double)cfg.nsym_f);
                 ppm = (float)(.9 * (double)ppm + .1 * (double)appm);
             }
-            if (norm_rx_timing > 0.25f) nin_next = N + TS / 2;
-            else if (norm_rx_timing < -0.25f) nin_next = N - TS / 2;
-            else nin_next = N;
             if (FAST && (fabsf(norm_rx_timing - 0.25f) < WO_GUARD || fabsf(norm_rx_timing + 0.25f) < WO_GUARD)) nuncertain++;
-            nin_next = __builtin_amdgcn_readfirstlane(nin_next);
-            const int low_sample = __builtin_amdgcn_readfirstlane((int)floorf(rx_timing));
-            const float fract = rx_timing - (float)low_sample;
-            const int high_sample = __builtin_amdgcn_readfirstlane((int)ceilf(rx_timing));
-            const float omf = 1 - fract;
-            tr_rxt = rx_timing;
+            t_low = __builtin_amdgcn_readfirstlane((int)floorf(rx_timing));
+            t_fract = rx_timing - (float)t_low;
+            t_high = __builtin_amdgcn_readfirstlane((int)ceilf(rx_timing));
+            t_rxt = rx_timing;
+        }
+    };
+    auto tstage2 = [&](long long fr) {
+        if (!t_nan) {
+            const float fract = t_fract, omf = 1 - fract;
             // symbol `lane` is resampled between f_int[.][(lane+1)*P + low_sample] and [.. + high_sample]: for an offset o >= 0
             // that is output o of the NEXT lane's slot, for o < 0 output TS + o of this lane's
             auto pick = [&](int o, int m) -> v2f {
@@ -391,7 +490,7 @@ __global__ __launch_bounds__(1024, 4) void wenet_demod_oct_kernel(WrDemodCfg cfg
             float tmax[M];
 #pragma unroll
             for (int m = 0; m < M; m++) {
-                const v2f a = pick(low_sample, m), b = pick(high_sample, m);
+                const v2f a = pick(t_low, m), b = pick(t_high, m);
                 float tr = omf * a.x, ti = omf * a.y;
                 tr = tr + fract * b.x;
                 ti = ti + fract * b.y;
@@ -403,62 +502,54 @@ __global__ __launch_bounds__(1024, 4) void wenet_demod_oct_kernel(WrDemodCfg cfg
         if (C.trace && lane == 0) {
             float *tr = C.trace + fr * WR_TRACE_FLOATS;
 #pragma unroll
-            for (int m = 0; m < WR_M_MAX; m++) tr[WR_TR_FEST + m] = (m < M) ? cfg.bin_freq[CT[OC_FBIN + (m < M ? m : 0)]] : 0.f;
-            tr[WR_TR_NIN] = (float)nin_next;
+            for (int m = 0; m < WR_M_MAX; m++) tr[WR_TR_FEST + m] = (m < M) ? cfg.bin_freq[t_bins[m < M ? m : 0]] : 0.f;
+            tr[WR_TR_NIN] = (float)t_nin_next;
             tr[WR_TR_NRT] = norm_rx_timing_st;
             tr[WR_TR_PPM] = ppm;
             tr[WR_TR_MEAN] = 0.f;                                        // (Eb/N0 accumulators: the stats path runs the pipelined kernels)
             tr[WR_TR_STD] = 0.f;
-            tr[WR_TR_RXT] = tr_rxt;
+            tr[WR_TR_RXT] = t_rxt;
         }
-        return nin_next;
     };
 
     // ================================ narrow stages (exact mode) ===============================
     // C(j) of the captures in `mask`: lanes 2M c .. 2M c + 2M - 1
     auto chain = [&](int mask) {
-        const int cc = lane / (2 * M);
+        const int cc = lane / M;
         if (cc >= G || !((mask >> cc) & 1)) return;
-        const int m = (lane >> 1) % M, part = lane & 1;
+        const int m = lane % M;
         const int *CTc = CT0 + cc * ctw;
-        oct_lds_f32 *ck = (oct_lds_f32 *)(smem_all + cc * cfg.o_cap_stride + cfg.o_off_CK) + m * NHB * 2 + part;
+        v2f *ck = (v2f *)(smem_all + cc * cfg.o_cap_stride + cfg.o_off_CK) + m * NHB;
         const int nin_j = CTc[OC_NIN];
         const int nold = Nmem - nin_j;
         const int bc = CTc[OC_FBIN + m], bp = CTc[OC_FBINP + m];
         const int ncase = (nin_j < N) ? 0 : ((nin_j > N) ? 2 : 1);
         const float2 bo = back_t[ncase * NH + bp];
-        {
-            const float oth = __shfl_xor(own, 1, 64);
-            const v2f pc = {part ? oth : own, part ? own : oth};
-            const v2f phi0 = cmul_pk((v2f){bo.x, bo.y}, pc);             // fsk.c:758-759
-            own = part ? phi0.y : phi0.x;
-        }
+        own = cmul_pk((v2f){bo.x, bo.y}, own);                           // fsk.c:758-759
         const float2 d0 = dphi_t[bp], d1 = dphi_t[bc];
-        float k1 = d0.x, k2 = part ? d0.y : -d0.y;
+        v2f d = {d0.x, d0.y};
         const int hsw = nold / H;                                        // 3, 4 or 5: the half symbol that starts with the new samples
         int hb = 0;
         auto blocks = [&](int upto) {
-            for (; hb < upto; hb++) { ck[2 * hb] = own; own = nco_steps<H>(own, k1, k2); }
+            for (; hb < upto; hb++) { ck[hb] = own; own = nco_steps<H>(own, d); }
         };
         auto swtch = [&]() {                                             // fsk.c:785-788: normalise, continue with this frame's estimate
             if (hb == hsw) {
-                const float oth = __shfl_xor(own, 1, 64);
-                const float re = part ? oth : own, im = part ? own : oth;
-                const float av = sqrtf(re * re + im * im);
-                own = own / av;
-                k1 = d1.x; k2 = part ? d1.y : -d1.y;
+                const float av = sqrtf(own.x * own.x + own.y * own.y);
+                own = (v2f){own.x / av, own.y / av};
+                d = (v2f){d1.x, d1.y};
             }
         };
         blocks(3); swtch(); blocks(4); swtch(); blocks(5); swtch();
         const int full = L / H;
-        for (; hb + 4 <= full; hb += 4) {                                // four checkpoints per trip: a taken branch costs ~16 cycles
+        for (; hb + 8 <= full; hb += 8) {                                // eight checkpoints per trip: a taken branch costs ~16 cycles
 #pragma unroll
-            for (int k = 0; k < 4; k++) { ck[2 * (hb + k)] = own; own = nco_steps<H>(own, k1, k2); }
+            for (int k = 0; k < 8; k++) { ck[hb + k] = own; own = nco_steps<H>(own, d); }
         }
         blocks(full);
         if (full * H < L) {
-            ck[2 * hb] = own;
-            for (int s = full * H; s < L; s++) own = nco_step_split(own, k1, k2);
+            ck[hb] = own;
+            for (int s = full * H; s < L; s++) own = cmul_pk(own, d);
         }
     };
 
@@ -468,7 +559,7 @@ __global__ __launch_bounds__(1024, 4) void wenet_demod_oct_kernel(WrDemodCfg cfg
         int sc = lane >> 1;
         const bool mine = sc < G && ((mask >> sc) & 1);
         if (!mine) sc = __builtin_ctz(mask);
-        const float *row = (const float *)(smem_all + sc * cfg.o_cap_stride + cfg.o_off_FB) + (lane & 1) * NIq;
+        const float *row = (const float *)(smem_all + sc * cfg.o_cap_stride + cfg.o_off_TP) + (lane & 1) * NIq;
         const v4f *T4 = (const v4f *)row;
         float acc = 0.f;
         v4f bufA[4], bufB[4];
@@ -502,20 +593,35 @@ __global__ __launch_bounds__(1024, 4) void wenet_demod_oct_kernel(WrDemodCfg cfg
 
     // ================================ frame loop ===============================================
     // Exact mode, per frame k (four workgroup barriers):
-    //   A  duty wave: NCO chains of frame k          | capture waves: E(k+1) AHEAD, assuming nin(k+1) = N (they would idle otherwise)
+    //   A  duty wave: NCO chains of frame k, started as soon as every capture has published nin(k) and its tone bins (an LDS
+    //      sequence word per capture: no barrier)    | capture waves: decisions and outputs of frame k-1, then the FFT of E(k+1)
+    //      AHEAD, assuming nin(k+1) = N (they would idle otherwise)
     //   B  capture waves: mix / integrate / timing products of frame k
-    //   C  duty wave: ordered timing sums of frame k
-    //   D  capture waves: timing estimate, nin(k+1), decisions; if nin(k+1) != N the estimator run of frame k+1 is repeated with the
-    //      true nin (it reads the untouched spectrum of frame k); then frame k+1 becomes the frame in work
+    //   C  duty wave: ordered timing sums of frame k  | capture waves: smoothing and tone search of E(k+1)
+    //   D  capture waves: timing estimate and nin(k+1); if nin(k+1) != N the estimator run of frame k+1 is repeated with the true
+    //      nin (it reads the untouched spectrum of frame k); frame k+1 becomes the frame in work and is published
     int ran = 0;                                                         // duty wave: captures that demodulated at least one frame
-    if (is_cap && alive) { prefetch_est(0); prefetch_slot(0, nin); estimate(nin); commit_estimate(); if (!FAST) prefetch_est(nin); }
+    auto publish = [&](int nn, bool more, long long seq) {               // inputs of the next frame are final: its chain may start
+        if (lane == 0) {
+            CT[OC_NIN] = nn; CT[OC_ALIVE] = more ? 1 : 0;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __hip_atomic_store(&CT[OC_SEQ], (int)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
+    if (is_cap) {
+        if (alive) { prefetch_est(0); prefetch_slot(0, nin); estimate(nin); commit_estimate(); if (!FAST) prefetch_est(nin); }
+        if (!FAST) publish(nin, alive, 1);
+    }
     if (FAST) {
         // no shared stages: every capture wave runs on its own
         while (alive) {
             const long long off1 = off + nin;
             prefetch_est(off1);
             dstage(off, nin);
-            const int nn = tstage(frames);
+            t_bins[0] = CT[OC_FBIN]; t_bins[1] = CT[OC_FBIN + 1];
+            const int nn = tstage1a();
+            tstage1b();
+            tstage2(frames);
             const bool more = off1 + nn <= C.nsamples && frames + 1 < C.cap_frames;
             nslip += (nn != N) ? 1 : 0;
             off = off1; nin = nn; frames++;
@@ -523,43 +629,64 @@ __global__ __launch_bounds__(1024, 4) void wenet_demod_oct_kernel(WrDemodCfg cfg
             if (alive) { prefetch_slot(off, nin); estimate(nin); commit_estimate(); }
         }
     } else {
-        // development (WENET_RX_PROFILE=4): cycles of wave 0 and of the duty wave per phase, summed over the frames:
-        //   [0] phase D (to its barrier)  [1] phase A  [2] phase B  [3] phase C  [5] duty wave: chain busy  [6] frames; duty wave at +8
+        if (is_chain) __builtin_amdgcn_s_setprio(2);                     // the serial wave wins VALU arbitration against the wide ones
+        // development (WENET_RX_PROFILE=4): cycles of wave 0 and of the duty wave per section, summed over the frames:
+        //   wave 0: [0] decide + E ahead + wait for the chains  [1] mix / integrate (to its barrier)  [2] wait for the sums  [4] decide + E ahead busy
+        //   duty wave (+8): [0] wait for nin  [1] chains  [2] barrier wait  [3] sums   [6] frames
         const bool pp = C.prof != nullptr && lane == 0 && (wave == 0 || is_chain);
         long long *pr = C.prof + (is_chain ? 8 : 0);
         long long pt[6] = {0, 0, 0, 0, 0, 0}, t0 = pp ? (long long)__builtin_readcyclecounter() : 0;
 #define WO_STAMP(k) do { if (pp) { const long long t1 = (long long)__builtin_readcyclecounter(); pt[k] += t1 - t0; t0 = t1; } } while (0)
+        int mask = (1 << G) - 1;                                         // captures whose next frame is awaited
+        long long kf = 0;                                                // frame index within this launch (lock-step over the group)
         for (;;) {
-            lds_barrier();                                               // nin(k), bins(k), alive published
-            WO_STAMP(0);
-            const int mask = alive_mask();
+            if (is_chain) {
+                // frame kf of every capture that was alive: wait until its nin / bins / alive flag are published, then run the chains
+                for (int c = 0; c < G; c++)
+                    if ((mask >> c) & 1)
+                        while (__hip_atomic_load((int *)&CT0[c * ctw + OC_SEQ], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (int)(kf + 1)) __builtin_amdgcn_s_sleep(2);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                WO_STAMP(0);
+                const int m2 = alive_mask() & mask;
+                if (m2) { chain(m2); ran |= m2; }
+                WO_STAMP(1);
+            } else if (alive) {
+                estimate_fft(N); prefetch_est(off + nin + N);            // E(k+1) ahead, first half; then the samples of E(k+2), one frame ahead again
+                if (pp) { pt[4] += (long long)__builtin_readcyclecounter() - t0; }
+            }
+            lds_barrier();                                               // checkpoints of frame k; every capture's flags are final
+            WO_STAMP(is_chain ? 2 : 0);
+            mask &= alive_mask();
             if (!mask) break;
             const long long off1 = off + nin;
-            if (is_chain) { chain(mask); ran |= mask; }
-            if (pp && is_chain) { pt[5] += (long long)__builtin_readcyclecounter() - t0; }
-            if (is_cap && alive) { estimate(N); prefetch_est(off1 + N); }   // E(k+1) ahead; then the samples of E(k+2), one frame ahead again
-            if (pp && !is_chain) { pt[4] += (long long)__builtin_readcyclecounter() - t0; }
-            lds_barrier();                                               // checkpoints of frame k
-            WO_STAMP(1);
             if (is_cap && alive) dstage(off, nin);
             lds_barrier();                                               // timing products
-            WO_STAMP(2);
+            WO_STAMP(is_chain ? 2 : 1);
             if (is_sum) tsum(mask);
+            else if (alive) estimate_pick();                             // E(k+1) ahead, second half (under the sums)
             lds_barrier();                                               // timing sums
-            WO_STAMP(3);
+            WO_STAMP(is_chain ? 3 : 2);
             if (is_cap && alive) {
-                const int nn = tstage(frames);
+                t_bins[0] = CT[OC_FBIN]; t_bins[1] = CT[OC_FBIN + 1];
+                __builtin_amdgcn_s_setprio(1);
+                const int nn = tstage1a();
                 const bool more = off1 + nn <= C.nsamples && frames + 1 < C.cap_frames;
                 if (more) {
-                    prefetch_slot(off1, nn);
-                    if (nn != N) { prefetch_est(off1); estimate(nn); prefetch_est(off1 + nn); }      // (a timing slip: E(k+1) again)
+                    if (nn != N) { prefetch_est(off1); estimate(nn); }                               // (a timing slip: E(k+1) again)
                     commit_estimate();
                 }
-                if (lane == 0) { CT[OC_NIN] = nn; CT[OC_ALIVE] = more ? 1 : 0; }
+                publish(nn, more, kf + 2);                               // -> the duty wave starts the chains of frame k+1 ...
+                __builtin_amdgcn_s_setprio(0);
+                tstage1b();
+                if (pp) { const long long t1 = (long long)__builtin_readcyclecounter(); pt[3] += t1 - t0; }
+                tstage2(frames);                                         // ... while this wave resamples, decides and writes frame k
+                if (more) { prefetch_slot(off1, nn); if (nn != N) prefetch_est(off1 + nn); }
+                if (pp) { const long long t1 = (long long)__builtin_readcyclecounter(); pt[5] += t1 - t0; }
                 nslip += (nn != N) ? 1 : 0;
                 off = off1; nin = nn; frames++;
                 alive = more;
             }
+            kf++;
         }
         if (pp) { for (int k = 0; k < 6; k++) pr[k] = pt[k]; if (!is_chain) pr[6] = frames; }
 #undef WO_STAMP
@@ -585,11 +712,11 @@ __global__ __launch_bounds__(1024, 4) void wenet_demod_oct_kernel(WrDemodCfg cfg
         }
     }
     if (is_chain) {                                                      // un-normalised, as saved at fsk.c:846
-        const int cc = lane / (2 * M), m = (lane >> 1) % M, part = lane & 1;
+        const int cc = lane / M, m = lane % M;
         const int chc = blockIdx.x * G + cc;
         if (cc < G && chc < nchan && ((ran >> cc) & 1)) {
             WrChanHdr *h = (WrChanHdr *)chans[chc].state;
-            if (part) h->phi_c[m].y = own; else h->phi_c[m].x = own;
+            h->phi_c[m] = make_float2(own.x, own.y);
         }
     }
 }

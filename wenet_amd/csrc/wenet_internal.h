@@ -65,8 +65,9 @@ struct WrDemodCfg {
     // batch kernel, one wavefront per capture (demod_oct_impl.h): o_caps captures per workgroup, each with an LDS block of
     // o_cap_stride bytes (o_off_FB .. o_off_CT inside it), the tables once behind the blocks; o_ok = geometry supported
     int o_ok, o_caps, o_cap_stride, o_lds_bytes, o_nhb, o_first_bins;
-    int o_off_FB, o_off_FE, o_off_FW, o_off_CK, o_off_CT;
+    int o_off_FB, o_off_TP, o_off_FE, o_off_FW, o_off_CK, o_off_CT;
     int o_off_TW, o_off_HANN, o_off_SRC, o_off_DPHI, o_off_PFT, o_off_BACK;
+    float o_at_hi, o_at_lo;              // atan2f values beyond which norm_rx_timing > 0.25f / < -0.25f (fsk.c:883,900-903)
     // per-channel state block layout (floats from the block start)
     int st_fft_est, st_samp_old, st_sd_last, st_floats;
 };

@@ -178,7 +178,8 @@ struct DemodTables {
         c.o_caps = caps;
         c.o_nhb = (cfg.L + H - 1) / H;
         int t = 0;
-        c.o_off_FB = t;  t = align16(t + (cfg.Ndft * 8 > 2 * NIq * 4 ? cfg.Ndft * 8 : 2 * NIq * 4));   // FFT buffer, then the timing products
+        c.o_off_FB = t;  t = align16(t + cfg.Ndft * 8);
+        c.o_off_TP = t;  t = align16(t + 2 * NIq * 4);
         c.o_off_FE = t;  t = align16(t + 2 * NH * 4);
         c.o_off_FW = t;  t = align16(t + NH * 4);
         c.o_off_CK = t;  t = align16(t + cfg.M * c.o_nhb * 8);
@@ -194,6 +195,17 @@ struct DemodTables {
         c.o_lds_bytes = t;
         c.o_first_bins = 0;
         while (c.o_first_bins < NH && host_binf[c.o_first_bins] < 1.0f) c.o_first_bins++;                 // fsk.c:750 "f_est[0] < 1"
+        {   // largest float a with (float)((double)a / 2 pi) <= 0.25f, smallest with >= -0.25f (the map is monotone)
+            auto nrt = [](float a) { return (float)((double)a / (2 * M_PI)); };
+            float a = (float)M_PI_2;
+            while (nrt(a) <= 0.25f) a = nextafterf(a, INFINITY);
+            while (nrt(a) > 0.25f) a = nextafterf(a, -INFINITY);
+            c.o_at_hi = a;
+            a = -(float)M_PI_2;
+            while (nrt(a) >= -0.25f) a = nextafterf(a, -INFINITY);
+            while (nrt(a) < -0.25f) a = nextafterf(a, INFINITY);
+            c.o_at_lo = a;
+        }
         c.o_ok = t <= 160 * 1024 ? 1 : 0;
         return c;
     }
