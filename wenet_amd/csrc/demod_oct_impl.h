@@ -38,6 +38,9 @@
 #pragma clang fp contract(off)
 
 #define WO_CAPS_MAX 15               // capture waves per workgroup (cfg.o_caps of them) + the duty wave (NCO chains, timing sums) <= 16 wavefronts
+#ifndef WO_WAVES_PER_EU
+#define WO_WAVES_PER_EU 4            // wavefronts per SIMD the register allocation aims at: 4 -> 128 VGPRs, two workgroups of 7 + 1 waves per CU
+#endif
 #define WO_GUARD 2e-5f              // |norm_rx_timing -+ 0.25| below this: the fast estimate does not decide nin(k+1) safely
 
 namespace {
@@ -80,7 +83,7 @@ __device__ __forceinline__ v2f nco_steps(v2f phi, v2f d) {           // N steps 
 }  // namespace
 
 template <int M, int TS, bool FAST>
-__global__ __launch_bounds__(1024, 4) void wenet_demod_oct_kernel(WrDemodCfg cfg, const WrChan *chans, int nchan) {
+__global__ __launch_bounds__(1024, WO_WAVES_PER_EU) void wenet_demod_oct_kernel(WrDemodCfg cfg, const WrChan *chans, int nchan) {
     static_assert(M == 2, "two tones (four would need two soft decisions per lane)");
     constexpr int H = TS / 2;                                            // checkpoint spacing = the unit of a timing slip
     const int tid = threadIdx.x, lane = tid & 63;
@@ -173,20 +176,24 @@ __global__ __launch_bounds__(1024, 4) void wenet_demod_oct_kernel(WrDemodCfg cfg
     unsigned epre[NE];                                                   // estimator samples of the NEXT frame (its start is known a frame ahead)
     unsigned xr[TS / 2 + 1];                                             // this lane's symbol slot of the frame about to be mixed, two cu8 samples per dword
     const int NBLK = (L + TS - 1) / TS;                                  // lanes that own samples
-    const int slot = lane < NBLK ? lane : NBLK - 1;                      // (idle lanes repeat the last slot: always inside the frame)
+    // The lane number, opaque to the optimiser: per-lane LDS / global addresses derived from it are recomputed where they are used
+    // (a handful of integer instructions) instead of being hoisted out of the frame loop into dozens of registers that then spill.
+    auto fresh_lane = [&]() -> int { int l = lane; asm volatile("" : "+v"(l)); return l; };
     auto prefetch_est = [&](long long off_j) {
+        const int ln = fresh_lane();
         if (off_j + Ndft <= C.nsamples) {                                // the whole transform window is inside the capture: no index clamping
             const unsigned short *p = raw16 + off_j;
 #pragma unroll
-            for (int j = 0; j < NE; j++) epre[j] = p[src_t[4 * lane + j]];
+            for (int j = 0; j < NE; j++) epre[j] = p[src_t[4 * ln + j]];
         } else {                                                         // (a run ahead of the capture's end: its result is never used)
 #pragma unroll
-            for (int j = 0; j < NE; j++) { long long a = off_j + src_t[4 * lane + j]; epre[j] = raw16[a < last_smp ? a : last_smp]; }
+            for (int j = 0; j < NE; j++) { long long a = off_j + src_t[4 * ln + j]; epre[j] = raw16[a < last_smp ? a : last_smp]; }
         }
     };
     // The lane's symbol slot as TS/2 + 1 aligned dwords (two cu8 samples each) starting at the even sample at or below its first
     // one; slot_align() shifts them down by a sample when the first one is odd -- at the point of use, so the loads stay in flight.
     auto prefetch_slot = [&](long long off_j, int nin_j) {
+        const int ln = fresh_lane(), slot = ln < NBLK ? ln : NBLK - 1;    // (idle lanes repeat the last slot: always inside the frame)
         const long long b0 = off_j - (Nmem - nin_j);                     // buffer position 0 (negative only in a launch's first frame)
         if (b0 >= 0 && b0 + Nmem + 1 <= C.nsamples) {                    // positions 0 .. Nmem (one past the window) are samples of the capture
             const unsigned *p = (const unsigned *)(raw16 + ((b0 & ~1LL) + TS * slot));
@@ -243,17 +250,18 @@ __global__ __launch_bounds__(1024, 4) void wenet_demod_oct_kernel(WrDemodCfg cfg
     };
     auto estimate_fft = [&](int nin_j) {
         const int fft_samps = nin_j - Ndft;                              // fsk.c:583-584 with fft_loops == 1
+        const int ln = fresh_lane();
         float2 v[4];
 #pragma unroll
         for (int j = 0; j < NE; j++) {                                   // fsk.c:587-603: half-Hann window, zero padding
-            const int idx = src_t[4 * lane + j];
+            const int idx = src_t[4 * ln + j];
             v[j] = make_float2(0.f, 0.f);
             if (idx < fft_samps) { const float h = hann_t[idx]; const float2 x = cvt(epre[j]); v[j] = make_float2(h * x.x, h * x.y); }
         }
         {
             float2 o0, o1, o2, o3;
             bfly4(v[0], v[1], v[2], v[3], o0, o1, o2, o3);
-            float4 *F4 = (float4 *)(FB + 4 * lane);
+            float4 *F4 = (float4 *)(FB + 4 * ln);
             F4[0] = make_float4(o0.x, o0.y, o1.x, o1.y);
             F4[1] = make_float4(o2.x, o2.y, o3.x, o3.y);
         }
@@ -261,7 +269,7 @@ __global__ __launch_bounds__(1024, 4) void wenet_demod_oct_kernel(WrDemodCfg cfg
 #pragma unroll
         for (int st = 0; st < 2; st++) {                                 // m = 4, fstride 16;  m = 16, fstride 4
             const int lgm = st ? 4 : 2, m = 1 << lgm, fs = st ? 4 : 16;
-            const int blk = lane >> lgm, k = lane & (m - 1);
+            const int blk = ln >> lgm, k = ln & (m - 1);
             float2 *F = FB + blk * m * 4 + k;
             const float2 s0 = cmul(F[m], tw_t[k * fs]);
             const float2 s1 = cmul(F[2 * m], tw_t[k * fs * 2]);
@@ -272,10 +280,10 @@ __global__ __launch_bounds__(1024, 4) void wenet_demod_oct_kernel(WrDemodCfg cfg
             wave_sync();
         }
         {                                                                // m = 64, fstride 1: outputs 0 .. Ndft/2 - 1 only
-            float2 *F = FB + lane;
-            const float2 s0 = cmul(F[64], tw_t[lane]);
-            const float2 s1 = cmul(F[128], tw_t[2 * lane]);
-            const float2 s2 = cmul(F[192], tw_t[3 * lane]);
+            float2 *F = FB + ln;
+            const float2 s0 = cmul(F[64], tw_t[ln]);
+            const float2 s1 = cmul(F[128], tw_t[2 * ln]);
+            const float2 s2 = cmul(F[192], tw_t[3 * ln]);
             float2 o0, o1, o2, o3;
             bfly4(F[0], s0, s1, s2, o0, o1, o2, o3);
             F[0] = o0; F[64] = o1;
@@ -285,7 +293,8 @@ __global__ __launch_bounds__(1024, 4) void wenet_demod_oct_kernel(WrDemodCfg cfg
     auto estimate_pick = [&]() {
         const float *FEin = FE2 + fecur * NH;
         float *FEout = FE2 + (fecur ^ 1) * NH;
-        for (int i = lane; i < NH; i += 64) {                            // fsk.c:612-628
+        const int ln = fresh_lane();
+        for (int i = ln; i < NH; i += 64) {                            // fsk.c:612-628
             const float2 v = FB[i];
             float mag = (v.x * v.x) + (v.y * v.y);
             if (i < cfg.f_min) mag = 0.f;
@@ -299,7 +308,7 @@ __global__ __launch_bounds__(1024, 4) void wenet_demod_oct_kernel(WrDemodCfg cfg
 #pragma unroll
         for (int k = 0; k < M; k++) {                                    // fsk.c:633-654
             BestBin best; best.v = 0.f; best.i = 0;
-            for (int jj = lane; jj < NH; jj += 64) {
+            for (int jj = ln; jj < NH; jj += 64) {
                 const float v = FW[jj];
                 if (v > best.v) { best.v = v; best.i = jj; }
             }
@@ -314,7 +323,7 @@ __global__ __launch_bounds__(1024, 4) void wenet_demod_oct_kernel(WrDemodCfg cfg
             int lo = imax - cfg.f_zero; lo = lo < 0 ? 0 : lo;
             int hi = imax + cfg.f_zero; hi = hi > NH ? NH : hi;
             wave_sync();
-            for (int jj = lo + lane; jj < hi; jj += 64) FW[jj] = 0.f;
+            for (int jj = lo + ln; jj < hi; jj += 64) FW[jj] = 0.f;
             wave_sync();
             fbin[k] = imax;
         }
@@ -335,15 +344,31 @@ __global__ __launch_bounds__(1024, 4) void wenet_demod_oct_kernel(WrDemodCfg cfg
         wave_sync();
     };
 
-    v2f F[M][TS];                                                        // integrator outputs of this lane's symbol slot (fsk.c:803-841)
+    // The integrator outputs of this lane's symbol slot (fsk.c:803-841: M x TS complex values per lane) are needed twice: at once
+    // for the timing products, and after the timing estimate for the two of them the symbol is resampled from.  Holding them in
+    // registers across the timing sum would cost 40 VGPRs per wave (and a CU another workgroup); they are parked in the capture's
+    // scratch block instead, [tone][output][lane] float2 = one coalesced 512-byte store per value, L2-resident, and the four
+    // values a lane needs come back (its own or its upper neighbour's) while the wave has slack.
+    float2 *Fscr = (float2 *)C.big;
     // D(j): mix, integrate, timing products
     auto dstage = [&](long long off_j, int nin_j) {
         const int nold = Nmem - nin_j;
         slot_align(off_j, nin_j);
-        v2f x[TS];
+        const int ln = fresh_lane(), slot = ln < NBLK ? ln : NBLK - 1;
+        char *fbase[3];
+        fbase[0] = (char *)(Fscr + ln);
 #pragma unroll
-        for (int u = 0; u < TS; u++) x[u] = slot_sample(u);
+        for (int k = 1; k < 3; k++) { fbase[k] = fbase[k - 1] + 4096; asm volatile("" : "+v"(fbase[k])); }
         float ft1[TS];
+        auto put_out = [&](int m, int r, v2f f) __attribute__((always_inline)) {
+            // value (m, r) sits 512 (m TS + r) bytes above the lane's first one: reached from three lane pointers 4 KB apart with the
+            // store's immediate offset (left to itself the compiler materialises -- and spills -- twenty 64-bit addresses)
+            const int byte = (m * TS + r) * 512;
+            *(float2 *)(fbase[byte >> 12] + (byte & 4095)) = make_float2(f.x, f.y);
+            const v2f sq = f * f;                                        // fsk.c:862-868
+            const float a = sq.x + sq.y;
+            ft1[r] = (m == 0) ? a : ft1[r] + a;
+        };
 #pragma unroll
         for (int m = 0; m < M; m++) {
             v2f d[TS];
@@ -358,7 +383,7 @@ __global__ __launch_bounds__(1024, 4) void wenet_demod_oct_kernel(WrDemodCfg cfg
                     const v2f dd = {segA ? dA2.x : dB2.x, segA ? dA2.y : dB2.y};
 #pragma unroll
                     for (int u = 0; u < H; u++) {
-                        d[hh * H + u] = cmul_conj_pk(x[hh * H + u], phi);                                // fsk.c:796 / :822
+                        d[hh * H + u] = cmul_conj_pk(slot_sample(hh * H + u), phi);                       // fsk.c:796 / :822
                         if (u < H - 1) phi = cmul_pk(phi, dd);                                     // fsk.c:798 / :824 (replayed from the checkpoint)
                     }
                 }
@@ -369,53 +394,48 @@ __global__ __launch_bounds__(1024, 4) void wenet_demod_oct_kernel(WrDemodCfg cfg
                     v2f acc = lane_up(run) + d[r];
 #pragma unroll
                     for (int n = r + 1; n < TS; n++) acc = acc + d[n];
-                    F[m][r] = acc;
+                    put_out(m, r, acc);
                     run = run + d[r];
                 }
-                F[m][0] = run;
+                put_out(m, 0, run);
             } else {
 #pragma clang fp contract(fast)
                 // phasor of buffer position s: the old part of the frame turns with the previous bin, the new part with this frame's,
                 // phase-continuous at s = nold (fsk.c:756-764,785-788); angles are multiples of 2 pi / Ndft
                 const int bp = CT[OC_FBINP + m], bc = CT[OC_FBIN + m];
-                const int s0 = TS * lane;
+                const int s0 = TS * ln;
 #pragma unroll
                 for (int u = 0; u < TS; u++) {
                     const int s = s0 + u;
                     const int k = (s < nold) ? bp * s : bp * nold + bc * (s - nold);
                     const float2 w = tw_t[k & (Ndft - 1)];                // e^{-j 2 pi k / Ndft} = conj(phasor)
-                    d[u] = (v2f){x[u].x * w.x - x[u].y * w.y, x[u].x * w.y + x[u].y * w.x};
+                    const v2f x = slot_sample(u);
+                    d[u] = (v2f){x.x * w.x - x.y * w.y, x.x * w.y + x.y * w.x};
                 }
                 v2f P[TS + 1];
                 P[1] = d[0];
 #pragma unroll
                 for (int n = 1; n < TS; n++) P[n + 1] = P[n] + d[n];
-                F[m][0] = P[TS];
+                put_out(m, 0, P[TS]);
 #pragma unroll
-                for (int r = 1; r < TS; r++) F[m][r] = (P[TS] - P[r]) + lane_up(P[r]);
-            }
-#pragma unroll
-            for (int r = 0; r < TS; r++) {                               // fsk.c:862-868
-                const v2f sq = F[m][r] * F[m][r];
-                const float a = sq.x + sq.y;
-                ft1[r] = (m == 0) ? a : ft1[r] + a;
+                for (int r = 1; r < TS; r++) put_out(m, r, (P[TS] - P[r]) + lane_up(P[r]));
             }
         }
         if (!FAST) {
-            if (lane < NOUT) {
+            if (ln < NOUT) {
 #pragma unroll
                 for (int r = 0; r < TS; r += 2) {                        // fsk.c:870-871: the products; the duty wave adds them in order
-                    const float2 pa = pft_t[TS * lane + r], pb = pft_t[TS * lane + r + 1];
+                    const float2 pa = pft_t[TS * ln + r], pb = pft_t[TS * ln + r + 1];
                     const v2f ta = (v2f){ft1[r], ft1[r]} * (v2f){pa.x, pa.y}, tb = (v2f){ft1[r + 1], ft1[r + 1]} * (v2f){pb.x, pb.y};
-                    *(float2 *)(TPf + TS * lane + r) = make_float2(ta.x, tb.x);
-                    *(float2 *)(TPf + NIq + TS * lane + r) = make_float2(ta.y, tb.y);
+                    *(float2 *)(TPf + TS * ln + r) = make_float2(ta.x, tb.x);
+                    *(float2 *)(TPf + NIq + TS * ln + r) = make_float2(ta.y, tb.y);
                 }
             }
         } else {
             float sr = 0.f, si = 0.f;
-            if (lane < NOUT) {
+            if (ln < NOUT) {
 #pragma unroll
-                for (int r = 0; r < TS; r++) { const float2 pf = pft_t[TS * lane + r]; sr += ft1[r] * pf.x; si += ft1[r] * pf.y; }
+                for (int r = 0; r < TS; r++) { const float2 pf = pft_t[TS * ln + r]; sr += ft1[r] * pf.x; si += ft1[r] * pf.y; }
             }
 #pragma unroll
             for (int sh = 32; sh >= 1; sh >>= 1) { sr += __shfl_xor(sr, sh, 64); si += __shfl_xor(si, sh, 64); }
@@ -478,19 +498,15 @@ __global__ __launch_bounds__(1024, 4) void wenet_demod_oct_kernel(WrDemodCfg cfg
     auto tstage2 = [&](long long fr) {
         if (!t_nan) {
             const float fract = t_fract, omf = 1 - fract;
+            const int ln = fresh_lane();
             // symbol `lane` is resampled between f_int[.][(lane+1)*P + low_sample] and [.. + high_sample]: for an offset o >= 0
             // that is output o of the NEXT lane's slot, for o < 0 output TS + o of this lane's
-            auto pick = [&](int o, int m) -> v2f {
-                const int r = o >= 0 ? o : TS + o;
-                v2f v = F[m][0];
-#pragma unroll
-                for (int q = 1; q < TS; q++) if (r == q) v = F[m][q];
-                return o >= 0 ? lane_up(v) : v;
-            };
+            const int r_lo = t_low >= 0 ? t_low : TS + t_low, r_hi = t_high >= 0 ? t_high : TS + t_high;
             float tmax[M];
 #pragma unroll
             for (int m = 0; m < M; m++) {
-                const v2f a = pick(t_low, m), b = pick(t_high, m);
+                const float2 a = Fscr[(m * TS + r_lo) * 64 + ln + (t_low >= 0 ? 1 : 0)];     // (lane 63 has no symbol)
+                const float2 b = Fscr[(m * TS + r_hi) * 64 + ln + (t_high >= 0 ? 1 : 0)];
                 float tr = omf * a.x, ti = omf * a.y;
                 tr = tr + fract * b.x;
                 ti = ti + fract * b.y;
@@ -562,26 +578,27 @@ __global__ __launch_bounds__(1024, 4) void wenet_demod_oct_kernel(WrDemodCfg cfg
         const float *row = (const float *)(smem_all + sc * cfg.o_cap_stride + cfg.o_off_TP) + (lane & 1) * NIq;
         const v4f *T4 = (const v4f *)row;
         float acc = 0.f;
-        v4f bufA[4], bufB[4];
-        int i = 0;
-#define WO_ADD16(buf) do { _Pragma("unroll") for (int u = 0; u < 4; u++) { acc = acc + buf[u].x; acc = acc + buf[u].y; acc = acc + buf[u].z; acc = acc + buf[u].w; } } while (0)
-#define WO_LD16(buf, at) do { _Pragma("unroll") for (int u = 0; u < 4; u++) buf[u] = T4[((at) >> 2) + u]; } while (0)
-        if (NI >= 16) {
-            WO_LD16(bufA, 0);
-            for (i = 16; i + 32 <= NI; i += 32) {
-                WO_LD16(bufB, i);
-                WO_ADD16(bufA);
-                asm volatile("" : "+v"(acc) : : "memory");
-                WO_LD16(bufA, i + 16);
-                WO_ADD16(bufB);
-                asm volatile("" : "+v"(acc) : : "memory");
+        // Straight-line code, the products fetched 32 ahead of the adds (three buffers of four 128-bit reads): the compiler waits
+        // for ALL outstanding LDS reads before a batch's first add, so the reads it then waits for were issued a whole batch of
+        // sixteen dependent adds earlier and are back.
+        constexpr int NIc = (WR_NSYM + 1) * TS, NB = NIc / 16;
+        v4f buf[3][4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { buf[0][u] = T4[u]; buf[1][u] = T4[4 + u]; }
+#pragma unroll
+        for (int bk = 0; bk < NB; bk++) {
+            if (bk + 2 < NB) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) buf[(bk + 2) % 3][u] = T4[4 * (bk + 2) + u];
             }
-            if (i + 16 <= NI) { WO_LD16(bufB, i); WO_ADD16(bufA); WO_ADD16(bufB); i += 16; }
-            else WO_ADD16(bufA);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                acc = acc + buf[bk % 3][u].x; acc = acc + buf[bk % 3][u].y; acc = acc + buf[bk % 3][u].z; acc = acc + buf[bk % 3][u].w;
+            }
+            asm volatile("" : "+v"(acc));                                // (keeps the batches in order)
         }
-#undef WO_ADD16
-#undef WO_LD16
-        for (; i < NI; i++) acc = acc + row[i];
+#pragma unroll
+        for (int i = NB * 16; i < NIc; i++) acc = acc + row[i];
         if (mine) ((float *)(smem_all + sc * cfg.o_cap_stride + cfg.o_off_CT))[OC_TC + (lane & 1)] = acc;
     };
 

@@ -974,7 +974,9 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const lon
     if (rx->want_llr && !rx->d_llr.reserve((size_t)nchan * max_pk * WR_NCODE * 4)) return -2;
     rx->profile = getenv("WENET_RX_PROFILE") != nullptr;
     if (rx->profile && !rx->d_prof.reserve((size_t)nchan * 32 * 8)) return -2;
+    const size_t oct_scr = (size_t)c.M * c.Ts * 64 * 8 + 64;            // demod_oct_impl.h: integrator outputs of one frame, [tone][output][lane] float2
     if (c.big && !rx->d_big.reserve((size_t)nchan * c.big_bytes)) return -2;           // frame scratch, geometries beyond LDS
+    if (!c.big && !rx->d_big.reserve((size_t)nchan * oct_scr)) return -2;
     // fresh modem + deframer state per capture
     std::vector<float> st0;
     rx->tab.init_state(st0);
@@ -995,7 +997,7 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const lon
         ch.trace = rx->want_trace ? rx->d_trace.as<float>() + (rx->sd_off[i] / c.Nbits) * WR_TRACE_FLOATS : nullptr;
         ch.prof = rx->profile ? rx->d_prof.as<long long>() + (size_t)i * 32 : nullptr;
         ch.prof2 = rx->profile ? rx->d_prof.as<long long>() + (size_t)i * 32 + 16 : nullptr;
-        ch.big = c.big ? rx->d_big.as<unsigned char>() + (size_t)i * c.big_bytes : nullptr;
+        ch.big = rx->d_big.as<unsigned char>() + (size_t)i * (c.big ? (size_t)c.big_bytes : oct_scr);
         WrDeframeChan &d = dch[i];
         memset(&d, 0, sizeof(d));
         d.sd = ch.sd_out;
