@@ -348,12 +348,20 @@ __global__ __launch_bounds__(1024, WO_WAVES_PER_EU) void wenet_demod_oct_kernel(
     // for the timing products, and after the timing estimate for the two of them the symbol is resampled from.  Holding them in
     // registers across the timing sum would cost 40 VGPRs per wave (and a CU another workgroup); they are parked in the capture's
     // scratch block instead, [tone][output][lane] float2 = one coalesced 512-byte store per value, L2-resident, and the four
-    // values a lane needs come back (its own or its upper neighbour's) while the wave has slack.
+    // values a lane needs come back (its own or its upper neighbour's) while the wave has slack.  Only the outputs the resampler can
+    // ask for are parked: rx_timing of a locked signal moves by a fraction of a sample per frame, so while the timing vector stays
+    // within 34 degrees of the previous frame's (a test on dot products, before anything is published) the two outputs lie among
+    // FOUR of the TS, known beforehand; any other frame (first frame, a timing slip, no signal) parks all of them, and a frame that
+    // breaks the prediction is integrated a second time with the full mask before the next frame's chains overwrite the checkpoints.
+    // (Keeping the four in registers instead was tried: 16 more live VGPRs spill, +18 % frame time.)
     float2 *Fscr = (float2 *)C.big;
+    unsigned omask = (1u << TS) - 1;                                     // outputs parked by the mix / integrate stage of the frame in work
+    float pv_r = 0.f, pv_i = 0.f;                                        // the previous frame's timing vector (0, 0: none)
     // D(j): mix, integrate, timing products
-    auto dstage = [&](long long off_j, int nin_j) {
+    // omask: which of the TS outputs per tone are parked (bit r); realign = false when the slot dwords were aligned by an earlier call
+    auto dstage = [&](long long off_j, int nin_j, unsigned omask, bool realign) {
         const int nold = Nmem - nin_j;
-        slot_align(off_j, nin_j);
+        if (realign) slot_align(off_j, nin_j);
         const int ln = fresh_lane(), slot = ln < NBLK ? ln : NBLK - 1;
         char *fbase[3];
         fbase[0] = (char *)(Fscr + ln);
@@ -364,7 +372,7 @@ __global__ __launch_bounds__(1024, WO_WAVES_PER_EU) void wenet_demod_oct_kernel(
             // value (m, r) sits 512 (m TS + r) bytes above the lane's first one: reached from three lane pointers 4 KB apart with the
             // store's immediate offset (left to itself the compiler materialises -- and spills -- twenty 64-bit addresses)
             const int byte = (m * TS + r) * 512;
-            *(float2 *)(fbase[byte >> 12] + (byte & 4095)) = make_float2(f.x, f.y);
+            if ((omask >> r) & 1) *(float2 *)(fbase[byte >> 12] + (byte & 4095)) = make_float2(f.x, f.y);
             const v2f sq = f * f;                                        // fsk.c:862-868
             const float a = sq.x + sq.y;
             ft1[r] = (m == 0) ? a : ft1[r] + a;
@@ -495,6 +503,21 @@ __global__ __launch_bounds__(1024, WO_WAVES_PER_EU) void wenet_demod_oct_kernel(
             t_rxt = rx_timing;
         }
     };
+    // the four outputs frame k+1 parks if frame k's rx_timing is rt (low = floor(rt)): offsets low-1 .. low+2 cover every
+    // rx_timing within 0.94 samples of rt
+    auto window_mask = [&](int low) -> unsigned {
+        unsigned mk = 0;
+#pragma unroll
+        for (int j = -1; j <= 2; j++) mk |= 1u << (((low + j) % TS + TS) % TS);
+        return mk;
+    };
+    // is this frame's timing vector within 34 degrees of the previous frame's?  (36 degrees = one sample of rx_timing at P = 10,
+    // 45 at P = 8; all of this is wave-uniform arithmetic with two degrees to spare for its rounding)
+    auto timing_near_previous = [&]() -> bool {
+        const float dot = t_tcr * pv_r + t_tci * pv_i;
+        const float n2 = (t_tcr * t_tcr + t_tci * t_tci) * (pv_r * pv_r + pv_i * pv_i);
+        return !t_nan && dot > 0.f && dot * dot > 0.6873f * n2;          // cos^2(34 deg); false for a zero or NaN vector
+    };
     auto tstage2 = [&](long long fr) {
         if (!t_nan) {
             const float fract = t_fract, omf = 1 - fract;
@@ -503,6 +526,7 @@ __global__ __launch_bounds__(1024, WO_WAVES_PER_EU) void wenet_demod_oct_kernel(
             // that is output o of the NEXT lane's slot, for o < 0 output TS + o of this lane's
             const int r_lo = t_low >= 0 ? t_low : TS + t_low, r_hi = t_high >= 0 ? t_high : TS + t_high;
             float tmax[M];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (this wave's own parked outputs: stores before the loads below)
 #pragma unroll
             for (int m = 0; m < M; m++) {
                 const float2 a = Fscr[(m * TS + r_lo) * 64 + ln + (t_low >= 0 ? 1 : 0)];     // (lane 63 has no symbol)
@@ -634,10 +658,14 @@ __global__ __launch_bounds__(1024, WO_WAVES_PER_EU) void wenet_demod_oct_kernel(
         while (alive) {
             const long long off1 = off + nin;
             prefetch_est(off1);
-            dstage(off, nin);
+            dstage(off, nin, omask, true);
             t_bins[0] = CT[OC_FBIN]; t_bins[1] = CT[OC_FBIN + 1];
             const int nn = tstage1a();
             tstage1b();
+            if (!t_nan && !(((omask >> (t_low >= 0 ? t_low : TS + t_low)) & (omask >> (t_high >= 0 ? t_high : TS + t_high))) & 1))
+                dstage(off, nin, (1u << TS) - 1, false);                 // prediction missed: integrate again, park everything
+            omask = (!t_nan && timing_near_previous()) ? window_mask(t_low) : (1u << TS) - 1;
+            pv_r = t_nan ? 0.f : t_tcr; pv_i = t_nan ? 0.f : t_tci;
             tstage2(frames);
             const bool more = off1 + nn <= C.nsamples && frames + 1 < C.cap_frames;
             nslip += (nn != N) ? 1 : 0;
@@ -676,7 +704,7 @@ __global__ __launch_bounds__(1024, WO_WAVES_PER_EU) void wenet_demod_oct_kernel(
             mask &= alive_mask();
             if (!mask) break;
             const long long off1 = off + nin;
-            if (is_cap && alive) dstage(off, nin);
+            if (is_cap && alive) dstage(off, nin, omask, true);
             lds_barrier();                                               // timing products
             WO_STAMP(is_chain ? 2 : 1);
             if (is_sum) tsum(mask);
@@ -687,6 +715,16 @@ __global__ __launch_bounds__(1024, WO_WAVES_PER_EU) void wenet_demod_oct_kernel(
                 t_bins[0] = CT[OC_FBIN]; t_bins[1] = CT[OC_FBIN + 1];
                 __builtin_amdgcn_s_setprio(1);
                 const int nn = tstage1a();
+                // do the parked outputs cover this frame's resampling points?  Sure if everything was parked or the timing vector is
+                // near the previous one's; otherwise look (exact rx_timing) and, on a miss, integrate the frame again -- before the
+                // next frame's chains may overwrite the checkpoints
+                bool did_1b = false;
+                const bool near_prev = timing_near_previous();
+                if (omask != (1u << TS) - 1 && !near_prev) {
+                    tstage1b(); did_1b = true;
+                    if (!t_nan && !(((omask >> (t_low >= 0 ? t_low : TS + t_low)) & (omask >> (t_high >= 0 ? t_high : TS + t_high))) & 1))
+                        dstage(off, nin, (1u << TS) - 1, false);
+                }
                 const bool more = off1 + nn <= C.nsamples && frames + 1 < C.cap_frames;
                 if (more) {
                     if (nn != N) { prefetch_est(off1); estimate(nn); }                               // (a timing slip: E(k+1) again)
@@ -694,7 +732,9 @@ __global__ __launch_bounds__(1024, WO_WAVES_PER_EU) void wenet_demod_oct_kernel(
                 }
                 publish(nn, more, kf + 2);                               // -> the duty wave starts the chains of frame k+1 ...
                 __builtin_amdgcn_s_setprio(0);
-                tstage1b();
+                if (!did_1b) tstage1b();
+                omask = (!t_nan && near_prev) ? window_mask(t_low) : (1u << TS) - 1;
+                pv_r = t_nan ? 0.f : t_tcr; pv_i = t_nan ? 0.f : t_tci;
                 if (pp) { const long long t1 = (long long)__builtin_readcyclecounter(); pt[3] += t1 - t0; }
                 tstage2(frames);                                         // ... while this wave resamples, decides and writes frame k
                 if (more) { prefetch_slot(off1, nn); if (nn != N) prefetch_est(off1 + nn); }
