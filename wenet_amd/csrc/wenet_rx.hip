@@ -1041,8 +1041,10 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const lon
     int oct_caps = 0;
     if (fmt == WENET_FMT_CU8 && (!rx->profile || getenv("WENET_RX_PROFILE")[0] == '4')) {
         const char *force = getenv("WENET_RX_OCT");
+        // measured (tools/gpu_batch_sweep.py, 2 s captures): up to 6 captures per CU the pipelined kernels win (20.8 ms per 3 captures
+        // per CU); 6..12 per CU: three workgroups of four captures per CU (44 ms for 2048); beyond: two of seven (55 ms for 3584)
         if (force) oct_caps = atoi(force) > 0 ? atoi(force) : 7;
-        else if (!rx->want_trace && nchan >= 6 * wenet_rx_device_info(1)) oct_caps = 7;
+        else if (!rx->want_trace && nchan >= 6 * wenet_rx_device_info(1)) oct_caps = nchan > 12 * wenet_rx_device_info(1) ? 7 : 4;
     }
     WrDemodCfg oct_cfg;
     bool use_oct = false;
