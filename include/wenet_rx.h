@@ -166,6 +166,21 @@ long long wenet_rx_get_packets(wenet_rx *rx, int ch, uint8_t *pkt_bytes, wenet_p
  * counts[0..3] = 0x00 text, 0x01 GPS, 0x02 orientation, 0x03 secondary payload; [4] 0x54 image telemetry;
  * [5] 0x55 SSDV; [6] 0x56 idle; [7] anything else.  Returns 0, <0 on error. */
 int wenet_rx_packet_census(wenet_rx *rx, int ch, long long counts[8]);
+/* ---- packet consumer: what rx/rx_ssdv.py:182-275 does with the 256-byte blocks of the pipe, as data ----
+ * type class of a packet (rx/WenetPackets.py:28-47 decode_packet_type, census order above) */
+int wenet_packet_type_class(const uint8_t *packet);
+/* SSDV header (rx/WenetPackets.py:98-123 ssdv_packet_info): callsign (base-40, least significant character first, <= 7
+ * characters), fec = (packet[1] == 0x66), image_id, packet_id, width, height.  Returns 0, or -1 "Not a SSDV Packet". */
+typedef struct { char callsign[8]; int fec; int image_id; int packet_id; int width; int height; } wenet_ssdv_info;
+int wenet_ssdv_packet_info(const uint8_t *packet256, wenet_ssdv_info *out);
+/* per-type streams of the last batch: the CRC-valid packets of channel ch whose type class is cls (0..7), 256 bytes each, in
+ * stream order (rx_ssdv.py dispatches every packet of the pipe on exactly this).  Returns the count (<= cap), <0 on error. */
+long long wenet_rx_get_packets_of_class(wenet_rx *rx, int ch, int cls, uint8_t *pkt256, long long cap);
+/* SSDV image runs of channel ch as rx_ssdv.py:224-268 cuts them: a new image starts where image_id or callsign differs from the
+ * previous SSDV packet's.  out[i] = header of the run's first packet, its packet count, and the index of its first packet in
+ * the channel's SSDV stream (class 5 above).  Returns the number of runs (<= cap). */
+typedef struct { wenet_ssdv_info first; long long npackets; long long first_index; } wenet_ssdv_image;
+long long wenet_rx_ssdv_images(wenet_rx *rx, int ch, wenet_ssdv_image *out, long long cap);
 /* soft-decision stream of channel ch (Nbits per frame); returns floats copied */
 long long wenet_rx_get_soft(wenet_rx *rx, int ch, float *sd, long long cap);
 /* per-frame trace of channel ch (10 floats per frame, see wenet_fsk_demod_stream); enable before process */

@@ -1198,6 +1198,61 @@ extern "C" long long wenet_rx_get_packets(wenet_rx *rx, int ch, uint8_t *pkt_byt
     }
     return n;
 }
+// ---- packet consumer (rx/rx_ssdv.py:182-275, rx/WenetPackets.py:28-123) -------------------------------------------------
+extern "C" int wenet_packet_type_class(const uint8_t *packet) {
+    const unsigned t = packet[0];                                      // decode_packet_type (WenetPackets.py:44-47)
+    return t <= 3u ? (int)t : (t >= 0x54u && t <= 0x56u ? (int)(t - 0x54u + 4u) : 7);
+}
+extern "C" int wenet_ssdv_packet_info(const uint8_t *p, wenet_ssdv_info *out) {
+    if (!p || !out) return -2;
+    memset(out, 0, sizeof(*out));
+    if (p[0] != 0x55) return -1;                                       // "ERROR: Not a SSDV Packet." (WenetPackets.py:105-106)
+    static const char alphabet[] = "-0123456789---ABCDEFGHIJKLMNOPQRSTUVWXYZ";
+    uint32_t code = ((uint32_t)p[2] << 24) | ((uint32_t)p[3] << 16) | ((uint32_t)p[4] << 8) | p[5];   // struct.unpack('>I') (:89-90)
+    int n = 0;
+    while (code && n < 7) { out->callsign[n++] = alphabet[code % 40]; code /= 40; }                    // :93-95
+    out->fec = p[1] == 0x66;
+    out->image_id = p[6];
+    out->packet_id = (p[7] << 8) + p[8];
+    out->width = p[9] * 16;
+    out->height = p[10] * 16;
+    return 0;
+}
+extern "C" long long wenet_rx_get_packets_of_class(wenet_rx *rx, int ch, int cls, uint8_t *pkt256, long long cap) {
+    const long long n = wenet_rx_packets(rx, ch);
+    if (n < 0 || cls < 0 || cls >= WR_CENSUS_CLASSES) return -1;
+    long long got = 0;
+    for (long long i = 0; i < n; i++) {
+        const WrPacketOut &o = rx->h_out[(size_t)ch * rx->max_pk + i];
+        if (!o.crc_ok || wenet_packet_type_class(o.bytes) != cls) continue;       // the pipe carries CRC-valid packets only (drs232_ldpc.c:254-257)
+        if (got < cap && pkt256) memcpy(pkt256 + (size_t)got * 256, o.bytes, 256);
+        got++;
+        if (got >= cap && pkt256) break;
+    }
+    return got;
+}
+extern "C" long long wenet_rx_ssdv_images(wenet_rx *rx, int ch, wenet_ssdv_image *out, long long cap) {
+    const long long n = wenet_rx_packets(rx, ch);
+    if (n < 0) return -1;
+    long long runs = 0, idx = 0;
+    wenet_ssdv_info cur;
+    bool have = false;
+    for (long long i = 0; i < n; i++) {
+        const WrPacketOut &o = rx->h_out[(size_t)ch * rx->max_pk + i];
+        if (!o.crc_ok || o.bytes[0] != 0x55) continue;
+        wenet_ssdv_info inf;
+        wenet_ssdv_packet_info(o.bytes, &inf);
+        if (!have || inf.image_id != cur.image_id || strcmp(inf.callsign, cur.callsign) != 0) {       // rx_ssdv.py:224
+            if (runs < cap && out) { out[runs].first = inf; out[runs].npackets = 0; out[runs].first_index = idx; }
+            runs++;
+            cur = inf; have = true;
+        }
+        if (runs <= cap && out) out[runs - 1].npackets++;
+        idx++;
+    }
+    return runs < cap ? runs : cap;
+}
+
 extern "C" long long wenet_rx_get_soft(wenet_rx *rx, int ch, float *sd, long long cap) {
     long long fr = wenet_rx_frames(rx, ch);
     if (fr < 0) return fr;

@@ -27,6 +27,7 @@ EXPORTS = [
     "wenet_rx_frames", "wenet_rx_packets", "wenet_rx_get_packets", "wenet_rx_packet_census", "wenet_rx_get_soft",
     "wenet_rx_enable_trace", "wenet_rx_get_trace", "wenet_rx_enable_llr_dump", "wenet_rx_get_llrs",
     "wenet_rx_last_ms", "wenet_rx_device_info", "wenet_rx_version", "wenet_rx_set_fast", "wenet_rx_last_kernel", "wenet_rx_fast_reruns",
+    "wenet_packet_type_class", "wenet_ssdv_packet_info", "wenet_rx_get_packets_of_class", "wenet_rx_ssdv_images",
 ]
 # every symbol include/wenet_tx.h declares
 EXPORTS_TX = [
@@ -37,6 +38,15 @@ EXPORTS_TX = [
 
 class PacketInfo(C.Structure):
     _fields_ = [("iter", C.c_int), ("crc_ok", C.c_int), ("start_symbol", C.c_longlong)]
+
+
+class SsdvInfo(C.Structure):            # wenet_ssdv_info
+    _fields_ = [("callsign", C.c_char * 8), ("fec", C.c_int), ("image_id", C.c_int), ("packet_id", C.c_int),
+                ("width", C.c_int), ("height", C.c_int)]
+
+
+class SsdvImage(C.Structure):           # wenet_ssdv_image
+    _fields_ = [("first", SsdvInfo), ("npackets", C.c_longlong), ("first_index", C.c_longlong)]
 
 
 class LdpcStruct(C.Structure):          # struct wenet_ldpc == reference struct LDPC (mpdecode_core.h:18-33)
@@ -101,6 +111,10 @@ def load():
     L.wenet_rx_set_fast.argtypes = [vp, i]
     L.wenet_rx_fast_reruns.restype = ll; L.wenet_rx_fast_reruns.argtypes = [vp]
     L.wenet_rx_last_kernel.restype = C.c_char_p; L.wenet_rx_last_kernel.argtypes = [vp]
+    L.wenet_packet_type_class.argtypes = [vp]
+    L.wenet_ssdv_packet_info.argtypes = [vp, C.POINTER(SsdvInfo)]
+    L.wenet_rx_get_packets_of_class.restype = ll; L.wenet_rx_get_packets_of_class.argtypes = [vp, i, i, vp, ll]
+    L.wenet_rx_ssdv_images.restype = ll; L.wenet_rx_ssdv_images.argtypes = [vp, i, C.POINTER(SsdvImage), ll]
     L.wenet_rx_device_info.argtypes = [i]
     L.wenet_rx_version.restype = C.c_char_p
     d = C.c_double

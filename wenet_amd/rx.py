@@ -103,6 +103,27 @@ class RxBatch:
             raise RuntimeError("wenet_rx_packet_census failed")
         return [int(x) for x in c]
 
+    def packets_of_class(self, ch, cls):
+        """CRC-valid packets of capture ch with type class cls (wenet_amd.packets.CENSUS_CLASSES order), in stream order: the
+        per-type stream rx/rx_ssdv.py dispatches.  Returns a list of 256-byte blobs."""
+        n = int(self._L.wenet_rx_get_packets_of_class(self._h, ch, cls, None, 0))
+        if n < 0:
+            raise RuntimeError("wenet_rx_get_packets_of_class failed")
+        buf = np.zeros((max(n, 1), 256), np.uint8)
+        got = int(self._L.wenet_rx_get_packets_of_class(self._h, ch, cls, buf.ctypes.data, n)) if n else 0
+        return [bytes(buf[i]) for i in range(got)]
+
+    def ssdv_images(self, ch):
+        """SSDV image runs of capture ch as rx/rx_ssdv.py:224-268 cuts them: list of dicts (header of the first packet, npackets, first_index)."""
+        cap = max(self.npackets(ch), 1)
+        arr = (_lib.SsdvImage * cap)()
+        n = int(self._L.wenet_rx_ssdv_images(self._h, ch, arr, cap))
+        if n < 0:
+            raise RuntimeError("wenet_rx_ssdv_images failed")
+        return [dict(callsign=arr[i].first.callsign.decode(), fec=bool(arr[i].first.fec), image_id=arr[i].first.image_id,
+                     packet_id=arr[i].first.packet_id, width=arr[i].first.width, height=arr[i].first.height,
+                     npackets=int(arr[i].npackets), first_index=int(arr[i].first_index)) for i in range(n)]
+
     def soft(self, ch):
         n = self.frames(ch) * self.Nbits
         sd = np.zeros(max(n, 1), np.float32)
