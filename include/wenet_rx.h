@@ -88,6 +88,10 @@ typedef struct {
 /* Enable statistics: a snapshot is kept for every `period`-th frame starting at frame `first`
  * (src/fsk_demod.c:345-401 prints when stats_ctr<0 => first=1, period=stats_loop+1). */
 void wenet_fsk_enable_stats(wenet_fsk *fsk, long first, long period);
+/* fsk_get_demod_stats (src/fsk.h:130, src/fsk.c:496-517): the statistics as they stand after the last demodulated frame for
+ * which a snapshot was kept (with wenet_fsk_enable_stats(fsk, 0, 1): after the frame the last fsk_demod / fsk_demod_sd call
+ * processed, as in the reference).  All zeros before the first snapshot. */
+void wenet_fsk_get_demod_stats(wenet_fsk *fsk, wenet_modem_stats *stats);
 /* Stats snapshots produced by the last wenet_fsk_demod_stream call; returns how many were copied. */
 int wenet_fsk_get_stats(wenet_fsk *fsk, wenet_modem_stats *out, int cap);
 

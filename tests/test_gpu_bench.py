@@ -1,0 +1,55 @@
+"""GPU: bench.py's contract -- the JSON line of a small single-rank run, and the multi-rank path (one process per rank over
+torch.distributed, barrier + max-over-ranks timing) exercised with two ranks sharing the one GPU of the test box
+(WENET_BENCH_BACKEND=gloo), so that the driver's 8-GPU run is not the first run of that code."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _line(out):
+    lines = [l for l in out.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def test_single_rank_line_has_the_contract_fields():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--captures", "24", "--seconds", "1", "--steps", "2", "--warmup", "1"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _line(r.stdout)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    nsamp = d["config"]["samples_per_capture"]
+    assert abs(d["value"] - 24 * nsamp * 2 / (d["ms_per_step"] * 2e-3) / 1e6) < 1e-3 * d["value"]
+    roof = d["roofline"]
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-6
+    assert roof["kernel"].startswith("wenet_demod")                       # what the library reports it launched
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("reference", "port") and cb["packets_match_gpu"] is True and cb["value"] > 0
+    if cb["kind"] == "reference":
+        assert set(cb["legs"]) == {"a_stats100", "b_stats_off", "c_all_cores"}
+    ow = d["other_workloads"]
+    assert {"fast_mode", "single_stream", "host_fed", "slipping_100ppm"} <= set(ow)
+    assert ow["fast_mode"]["packets_valid"] == d["packets_valid_per_step_rank0"]          # fast mode decodes the same packets
+
+
+def test_two_ranks_on_one_gpu_over_gloo():
+    env = dict(os.environ, WENET_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29517",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--captures", "16", "--seconds", "1", "--steps", "2", "--warmup", "1"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _line(r.stdout)                                                   # rank 0 prints the one line
+    assert d["n_gpus"] == 2 and d["cpu_baseline"] is None and "other_workloads" not in d
+    nsamp = d["config"]["samples_per_capture"]
+    # value = samples of ALL ranks / max-over-ranks time
+    assert abs(d["value"] - 2 * 16 * nsamp * 2 / (d["ms_per_step"] * 2e-3) / 1e6) < 1e-3 * d["value"]
+    assert d["packets_valid_per_step_rank0"] > 0

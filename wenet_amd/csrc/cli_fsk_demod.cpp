@@ -4,6 +4,10 @@
 //
 //   usage: fsk_demod [-l] [-p P] [-s] [(-c|-d)] [-t [r]] [-f] (2|4) SampleRate SymbolRate In Out
 //
+// Built a second time with -DWENET_FUSED as `wenet_rx`: the same front end with the L2 stage (src/drs232_ldpc.c /
+// src/wenet_ldpc.c main loop) in the same process -- IQ in, CRC-valid 256-byte packets out, ONE HIP start-up instead of
+// two.  Extra options there: -m/--framing 1|2 (drs232 / wenet framing, default 2), -v / -vv as the L2 tools.
+//
 // Differences that cannot be avoided, all outside the data path:
 //   * -l/--lbr (fsk_create, 1-second frames) runs the same kernel with its frame buffers in global memory
 //     (the frame does not fit LDS); like the reference it ignores -p, -b and -u.
@@ -11,6 +15,7 @@
 //     samples per fread; the frames produced, their order and the trailing-partial-frame rule
 //     (src/fsk_demod.c:270) are identical.
 #include <errno.h>
+#include <fcntl.h>
 #include <getopt.h>
 #include <poll.h>
 #include <signal.h>
@@ -28,7 +33,13 @@
 static void sig_handler(int signo) { if (signo == SIGTERM) exit(0); }      /* fsk_demod.c:47-52 */
 
 static void usage(const char *argv0) {                                      /* fsk_demod.c:163-178 */
+#ifdef WENET_FUSED
+    fprintf(stderr, "usage: %s [-m 1|2] [-v|-vv] [-p P] [(-c|-d)] [-t [r]] (2|4) SampleRate SymbolRate InputModemRawFile OutputPackets\n", argv0);
+    fprintf(stderr, " -m --framing=N    -  1: drs232_ldpc framing (RS232 8N1), 2: wenet_ldpc framing (I2S, scrambled). Default 2.\n");
+    fprintf(stderr, " -v / -vv          -  per-packet / per-checksum messages of drs232_ldpc / wenet_ldpc on stderr.\n");
+#else
     fprintf(stderr, "usage: %s [-l] [-p P]  [-s] [(-c|-d)] [-t [r]] [-f] (2|4) SampleRate SymbolRate InputModemRawFile OutputFile\n", argv0);
+#endif
     fprintf(stderr, " -lP --conv=P      -  P specifies the rate at which symbols are down-converted before further processing\n");
     fprintf(stderr, "                        P must be divisible by the symbol size. Smaller P values will result in faster\n");
     fprintf(stderr, "                        processing but lower demodulation preformance. If no P value is specified,\n");
@@ -37,6 +48,7 @@ static void usage(const char *argv0) {                                      /* f
     fprintf(stderr, " -d --cu8          -  The raw input file will be in complex unsigned 8 bit format.\n");
     fprintf(stderr, "                        If neither -c nor -d are used, the input should be in signed 16 bit format.\n");
     fprintf(stderr, " -f --testframes   -  Testframe mode, prints stats to stderr when a testframe is detected, if -t (JSON) \n");
+    fprintf(stderr, "                        is enabled stats will be in JSON format\n");
     fprintf(stderr, " -t[r] --stats=[r] -  Print out modem statistics to stderr in JSON.\n");
     fprintf(stderr, "                         r, if provided, sets the number of modem frames between statistic printouts.\n");
     fprintf(stderr, " -s --soft-dec     -  The output file will be in a soft-decision format, with one 32-bit float per bit.\n");
@@ -83,6 +95,10 @@ int main(int argc, char *argv[]) {
     int complex_input = 1, bytes_per_sample = 2, stats_rate = 8;
     int fsk_lower = -1, fsk_upper = -1;
     int o = 0, opt_idx = 0;
+#ifdef WENET_FUSED
+    int framing = 2, verbose = 0;
+    soft_dec_mode = 1;
+#endif
     while (o != -1) {
         static struct option long_opts[] = {
             {"help", no_argument, 0, 'h'},        {"lbr", no_argument, 0, 'l'},
@@ -90,8 +106,17 @@ int main(int argc, char *argv[]) {
             {"cu8", no_argument, 0, 'd'},         {"fsk_lower", optional_argument, 0, 'b'},
             {"fsk_upper", optional_argument, 0, 'u'}, {"stats", optional_argument, 0, 't'},
             {"soft-dec", no_argument, 0, 's'},    {"testframes", no_argument, 0, 'f'},
+#ifdef WENET_FUSED
+            {"framing", required_argument, 0, 'm'},
+#endif
             {0, 0, 0, 0}};
+#ifdef WENET_FUSED
+        o = getopt_long(argc, argv, "hlp:cdt::sb:u:m:v", long_opts, &opt_idx);
+        if (o == 'm') { framing = atoi(optarg); if (framing != 1 && framing != 2) usage(argv[0]); continue; }
+        if (o == 'v') { verbose++; continue; }
+#else
         o = getopt_long(argc, argv, "fhlp:cdt::sb:u:", long_opts, &opt_idx);
+#endif
         switch (o) {
         case 'l': hbr = 0; break;
         case 'c': complex_input = 2; bytes_per_sample = 2; break;
@@ -113,7 +138,6 @@ int main(int argc, char *argv[]) {
     if ((argc - dx) < 5) { fprintf(stderr, "Too few arguments\n"); usage(argv[0]); }
     if ((argc - dx) > 5) { fprintf(stderr, "Too many arguments\n"); usage(argv[0]); }
     M = atoi(argv[dx]); Fs = atoi(argv[dx + 1]); Rs = atoi(argv[dx + 2]);
-    if (Rs <= 0 || Fs <= 0) { fprintf(stderr, "Invalid sample/symbol rate\n"); exit(1); }
     if (P == 0) P = Fs / Rs;                                                 /* fsk_demod.c:186-188 */
     if ((M != 2) && (M != 4)) { fprintf(stderr, "Mode %d is not valid. Mode must be 2 or 4.\n", M); usage(argv[0]); }
 
@@ -126,6 +150,13 @@ int main(int argc, char *argv[]) {
         fprintf(stderr, "Setting estimator limits to %d to %d Hz.\n", fsk_lower, fsk_upper);
     }
     if (fin == NULL || fout == NULL || fsk == NULL) { fprintf(stderr, "Couldn't open files\n"); exit(1); }
+#ifdef WENET_FUSED
+    wenet_deframer *dfr = wenet_deframer_create(framing, 10 /* MAX_ITER, src/H2064_516_sparse.h:15 */);
+    if (!dfr) { fprintf(stderr, "wenet_rx: no GPU available\n"); exit(1); }
+    uint16_t packet_errors = 0, packets = 0;                                 /* uint16_t as the reference (drs232_ldpc.c:113-114) */
+    std::vector<uint8_t> pk;
+    std::vector<wenet_packet_info> pinfo;
+#endif
 
     const int Nbits = wenet_fsk_info(fsk, 6), N = wenet_fsk_info(fsk, 1), Ts = wenet_fsk_info(fsk, 2);
     int stats_period = 1;
@@ -159,6 +190,9 @@ int main(int argc, char *argv[]) {
     std::vector<wenet_modem_stats> stats(enable_stats ? (max_block / (size_t)(N - Ts / 2) + 2) / (size_t)stats_period + 2 : 1);   // snapshots one call can produce
     bool eof = false;
     const int fd = fileno(fin);
+#ifdef F_SETPIPE_SZ
+    (void)fcntl(fd, F_SETPIPE_SZ, 1 << 20);                                  // a pipe: let the upstream run 1 MiB ahead (bigger blocks per GPU call); fails harmlessly on files
+#endif
     while (true) {
         size_t have = buf.size() / bps;
         // need at least one frame's worth
@@ -209,13 +243,36 @@ int main(int argc, char *argv[]) {
             int ns = wenet_fsk_get_stats(fsk, stats.data(), (int)stats.size());
             for (int i = 0; i < ns; i++) print_stats(stats[i], M);
         }
+#ifdef WENET_FUSED
+        {   // L2 in the same process: the symbol loop of drs232_ldpc.c:176-274 / wenet_ldpc.c:171-258 on this block's soft decisions
+            const long nsym = frames * Nbits;
+            const size_t cap_pk = (size_t)(nsym / 2584 + 4);
+            if (pinfo.size() < cap_pk) { pinfo.resize(cap_pk); pk.resize(cap_pk * 258); }
+            long n = wenet_deframer_push(dfr, (const float *)out.data(), nsym, pk.data(), pinfo.data(), (long)pinfo.size());
+            if (n < 0) { fprintf(stderr, "wenet_rx: GPU decode failed (%ld)\n", n); exit(1); }
+            for (long i = 0; i < n; i++) {
+                const uint8_t *packet = &pk[(size_t)i * 258];
+                packets++;
+                if (pinfo[i].crc_ok) { fwrite(packet, sizeof(char), 256, fout); fflush(fout); }    /* drs232_ldpc.c:254-257 */
+                else packet_errors++;
+                if (verbose)
+                    fprintf(stderr, "packets: %d packet_errors: %d PER: %4.3f iter: %d\n", packets, packet_errors,
+                            (float)packet_errors / packets, pinfo[i].iter);
+            }
+        }
+#else
         fwrite(out.data(), soft_dec_mode ? sizeof(float) : sizeof(uint8_t), (size_t)frames * Nbits, fout);
         if (piped) fflush(fout);                                             /* fsk_demod.c:409-412 */
+#endif
         buf.erase(buf.begin(), buf.begin() + (size_t)consumed * bps);
         if (frames == 0 && eof) break;
     }
     fclose(fin);
     fclose(fout);
+#ifdef WENET_FUSED
+    fprintf(stderr, "packets: %d packet_errors: %d PER: %4.3f\n", packets, packet_errors, (float)packet_errors / packets);   /* drs232_ldpc.c:280-281 */
+    wenet_deframer_destroy(dfr);
+#endif
     wenet_fsk_destroy(fsk);
     return 0;
 }

@@ -2,6 +2,7 @@
 // `wenet_ldpc` (WENET_FRAMING=2) executables (src/drs232_ldpc.c:105-285, src/wenet_ldpc.c): same argv,
 // float32 symbols in, CRC-valid 256-byte packets out with a flush after each, same stderr lines.
 #include <errno.h>
+#include <fcntl.h>
 #include <poll.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -58,6 +59,9 @@ int main(int argc, char *argv[]) {
     std::vector<uint8_t> pk(((block / 2584) + 4) * 258);
     std::vector<wenet_packet_info> info((block / 2584) + 4);
     const int fd = fileno(fin);
+#ifdef F_SETPIPE_SZ
+    (void)fcntl(fd, F_SETPIPE_SZ, 1 << 20);                                  // a pipe: let the upstream run 1 MiB ahead (bigger blocks per GPU call)
+#endif
     size_t partial = 0;                                                      /* bytes of an incomplete float */
     while (true) {
         ssize_t got = read(fd, (char *)buf.data() + partial, block * sizeof(float) - partial);

@@ -538,6 +538,8 @@ struct wenet_fsk {
     float snr_est = 0.f;           // fsk->stats->snr_est recursion (fsk.c:1021), host side
     float f_est_last[4] = {0, 0, 0, 0};
     std::vector<wenet_modem_stats> stats_out;
+    wenet_modem_stats last_stats;  // most recent snapshot (wenet_fsk_get_demod_stats)
+    bool have_last_stats = false;
     bool carried_cu8 = true;       // the carried samp_old[] are zeros or came from cu8 input (raw-ring variant allowed)
 };
 
@@ -689,6 +691,7 @@ extern "C" long wenet_fsk_demod_stream(wenet_fsk *f, int fmt, const void *raw, l
                 s.nfft_est = c.Ndft / 2;
                 memcpy(s.fft_est, d + neye, sizeof(float) * (c.Ndft / 2));
                 f->stats_out.push_back(s);
+                f->last_stats = s; f->have_last_stats = true;
                 di++; next_dump += f->stats_period;
             }
         }
@@ -706,6 +709,11 @@ extern "C" void wenet_fsk_demod(wenet_fsk *f, uint8_t rx_bits[], const wenet_com
     if (!f) return;
     long used = 0;
     (void)wenet_fsk_demod_stream(f, WENET_FMT_CF32, in, (long)f->hdr.nin, 0, rx_bits, 1, &used, nullptr);
+}
+
+extern "C" void wenet_fsk_get_demod_stats(wenet_fsk *f, wenet_modem_stats *stats) {
+    if (!stats) return;
+    if (f && f->have_last_stats) *stats = f->last_stats; else memset(stats, 0, sizeof(*stats));
 }
 
 extern "C" int wenet_fsk_get_stats(wenet_fsk *f, wenet_modem_stats *out, int cap) {

@@ -83,3 +83,9 @@ class Fsk:
         arr = (_lib.ModemStats * cap)()
         n = self._L.wenet_fsk_get_stats(self._h, arr, cap)
         return [arr[i] for i in range(n)]
+
+    def get_demod_stats(self):
+        """fsk_get_demod_stats (src/fsk.h:130): the statistics after the last frame a snapshot was kept for."""
+        st = _lib.ModemStats()
+        self._L.wenet_fsk_get_demod_stats(self._h, C.byref(st))
+        return st

@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_HERE, "libwenet_rx.so")
 EXPORTS = [
     "wenet_fsk_create_hbr", "wenet_fsk_create", "wenet_fsk_destroy", "wenet_fsk_set_est_limits", "wenet_fsk_nin",
     "wenet_fsk_demod", "wenet_fsk_demod_sd", "wenet_fsk_info", "wenet_fsk_demod_stream",
-    "wenet_fsk_enable_stats", "wenet_fsk_get_stats",
+    "wenet_fsk_enable_stats", "wenet_fsk_get_stats", "wenet_fsk_get_demod_stats",
     "wenet_run_ldpc_decoder", "wenet_sd_to_llr", "wenet_ldpc_decode_batch",
     "wenet_deframer_create", "wenet_deframer_destroy", "wenet_deframer_push",
     "wenet_rx_create", "wenet_rx_destroy", "wenet_rx_process", "wenet_rx_enqueue", "wenet_rx_collect",
@@ -87,6 +87,7 @@ def load():
     L.wenet_fsk_demod_stream.argtypes = [vp, i, vp, l, i, vp, l, C.POINTER(l), vp]
     L.wenet_fsk_enable_stats.argtypes = [vp, l, l]
     L.wenet_fsk_get_stats.argtypes = [vp, C.POINTER(ModemStats), i]
+    L.wenet_fsk_get_demod_stats.argtypes = [vp, C.POINTER(ModemStats)]
     L.wenet_run_ldpc_decoder.argtypes = [C.POINTER(LdpcStruct), vp, vp, C.POINTER(i)]
     L.wenet_sd_to_llr.argtypes = [vp, vp, i]
     L.wenet_ldpc_decode_batch.argtypes = [vp, i, i, vp, vp, vp]
