@@ -207,7 +207,9 @@ const char *wenet_rx_last_kernel(wenet_rx *rx);
  * what: 0 demod kernel, 1 deframe kernel, 2 decode kernel, 3 total */
 float wenet_rx_last_ms(wenet_rx *rx, int what);
 
-/* library / device info: 0 = device count, 1 = multiprocessor count of device 0 */
+/* library / device info: 0 = device count, 1 = multiprocessor count of the current device.
+ * One device per process: the library works on the HIP device that is current when it is first used (bench.py: one rank = one
+ * process = one GPU); calls made with another device current are refused. */
 int wenet_rx_device_info(int what);
 const char *wenet_rx_version(void);
 

@@ -738,7 +738,7 @@ __global__ __launch_bounds__(NT) void wenet_demod_kernel(WrDemodCfg cfg, const W
             tr[WR_TR_NIN] = (float)nin_next;
             tr[WR_TR_NRT] = norm_rx_timing_st;
             tr[WR_TR_PPM] = ppm;
-            tr[WR_TR_MEAN] = tr_mean;
+            tr[WR_TR_MEAN] = nan_frame ? __int_as_float(0x7fc00000) : tr_mean;   // NaN marks a frame the reference returned early from (fsk.c:878-880): the host leaves EbNodB / snr_est alone
             tr[WR_TR_STD] = tr_std;
             tr[WR_TR_RXT] = tr_rxt;
         }
@@ -778,14 +778,14 @@ extern "C" hipError_t wr_launch_demod_ex(const WrDemodCfg *cfg, const WrChan *d_
     if (cfg->pipe_ok && !cfg->big && prof != 2) return wr_launch_demod_pipe(cfg, d_chans, nchan, stream, prof);   // 8 waves per capture, pipelined
 #define WR_LAUNCH(MM, PP, TT, NN)                                                                                        \
     do {                                                                                                                   \
-        (void)hipFuncSetAttribute((const void *)wenet_demod_kernel<MM, PP, TT, NN>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                  cfg->lds_bytes);                                                                          \
+        wr_attr_ok(hipFuncSetAttribute((const void *)wenet_demod_kernel<MM, PP, TT, NN>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  cfg->lds_bytes));                                                                          \
         hipLaunchKernelGGL((wenet_demod_kernel<MM, PP, TT, NN>), dim3(nchan), dim3(NN), cfg->lds_bytes, stream, *cfg, d_chans, nchan); \
     } while (0)
 #define WR_LAUNCH5(MM, PP, TT, NN, BB)                                                                                   \
     do {                                                                                                                   \
-        (void)hipFuncSetAttribute((const void *)wenet_demod_kernel<MM, PP, TT, NN, BB>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                  cfg->lds_bytes);                                                                          \
+        wr_attr_ok(hipFuncSetAttribute((const void *)wenet_demod_kernel<MM, PP, TT, NN, BB>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  cfg->lds_bytes));                                                                          \
         hipLaunchKernelGGL((wenet_demod_kernel<MM, PP, TT, NN, BB>), dim3(nchan), dim3(NN), cfg->lds_bytes, stream, *cfg, d_chans, nchan); \
     } while (0)
 #define WR_LAUNCH_T(MM, PP, NN) do { if (cfg->tables_in_lds) WR_LAUNCH(MM, PP, true, NN); else WR_LAUNCH(MM, PP, false, NN); } while (0)
@@ -795,8 +795,12 @@ extern "C" hipError_t wr_launch_demod_ex(const WrDemodCfg *cfg, const WrChan *d_
         return hipGetLastError();
     }
     // profiling (prof) keeps the one-wavefront form whose phase timings the instrumentation was written for
+#ifdef WR_WITH_PROF
     if (cfg->M == 2) { if (prof) WR_LAUNCH_T(2, true, 64); else WR_LAUNCH_T(2, false, 512); }
     else             { if (prof) WR_LAUNCH_T(4, true, 64); else WR_LAUNCH_T(4, false, 512); }
+#else                                                                   // (the instrumented one-wavefront instantiations: make PROF=1)
+    if (cfg->M == 2) WR_LAUNCH_T(2, false, 512); else WR_LAUNCH_T(4, false, 512);
+#endif
 #undef WR_LAUNCH_T
 #undef WR_LAUNCH5
 #undef WR_LAUNCH

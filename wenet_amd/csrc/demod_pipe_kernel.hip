@@ -4,17 +4,23 @@
 
 extern "C" hipError_t wr_launch_demod_pipe_raw(const WrDemodCfg *cfg, const WrChan *d_chans, int nchan, hipStream_t stream);    // demod_pipe_raw.hip
 extern "C" hipError_t wr_launch_demod_tri(const WrDemodCfg *cfg, const WrChan *d_chans, int nchan, hipStream_t stream);          // demod_pipe_tri.hip
+#ifdef WR_WITH_PROF                                                     // development build only (make PROF=1): instrumented instantiations
 extern "C" hipError_t wr_launch_demod_pipe_prof(const WrDemodCfg *cfg, const WrChan *d_chans, int nchan, hipStream_t stream);   // demod_pipe_prof.hip
+#endif
 
 #define WP_LAUNCH(MM, PP, RR)                                                                                                    \
     do {                                                                                                                         \
-        (void)hipFuncSetAttribute((const void *)wenet_demod_pipe_kernel<MM, PP, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                  cfg->p_lds_bytes);                                                                              \
+        wr_attr_ok(hipFuncSetAttribute((const void *)wenet_demod_pipe_kernel<MM, PP, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  cfg->p_lds_bytes));                                                                              \
         hipLaunchKernelGGL((wenet_demod_pipe_kernel<MM, PP, RR>), dim3(nchan), dim3(WP_THREADS), cfg->p_lds_bytes, stream, *cfg, d_chans, nchan);   \
     } while (0)
 extern "C" hipError_t wr_launch_demod_pipe(const WrDemodCfg *cfg, const WrChan *d_chans, int nchan, hipStream_t stream, int prof) {
     if (nchan <= 0) return hipSuccess;
+#ifdef WR_WITH_PROF
     if (prof) return wr_launch_demod_pipe_prof(cfg, d_chans, nchan, stream);
+#else
+    if (prof) fprintf(stderr, "libwenet_rx: WENET_RX_PROFILE=1 needs the development build (make -C wenet_amd/csrc PROF=1); running the production kernel\n");
+#endif
     // cfg->p_raw: the caller guarantees every capture is cu8 (and carried samples came from cu8) and has put the
     // raw-ring LDS layout into cfg->p_off_*
     if (cfg->p_tri) return wr_launch_demod_tri(cfg, d_chans, nchan, stream);

@@ -3,8 +3,8 @@
 
 #define WP_LAUNCH(MM, PP, RR)                                                                                                    \
     do {                                                                                                                         \
-        (void)hipFuncSetAttribute((const void *)wenet_demod_pipe_kernel<MM, PP, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                  cfg->p_lds_bytes);                                                                              \
+        wr_attr_ok(hipFuncSetAttribute((const void *)wenet_demod_pipe_kernel<MM, PP, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  cfg->p_lds_bytes));                                                                              \
         hipLaunchKernelGGL((wenet_demod_pipe_kernel<MM, PP, RR>), dim3(nchan), dim3(WP_THREADS), cfg->p_lds_bytes, stream, *cfg, d_chans, nchan);   \
     } while (0)
 extern "C" hipError_t wr_launch_demod_pipe_prof(const WrDemodCfg *cfg, const WrChan *d_chans, int nchan, hipStream_t stream) {

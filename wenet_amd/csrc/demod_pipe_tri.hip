@@ -6,7 +6,7 @@ extern "C" hipError_t wr_launch_demod_tri(const WrDemodCfg *cfg, const WrChan *d
     const int groups = (nchan + WT_CAPS - 1) / WT_CAPS;
 #define WT_LAUNCH(MM)                                                                                                          \
     do {                                                                                                                       \
-        (void)hipFuncSetAttribute((const void *)wenet_demod_tri_kernel<MM>, hipFuncAttributeMaxDynamicSharedMemorySize, cfg->p_lds_bytes); \
+        wr_attr_ok(hipFuncSetAttribute((const void *)wenet_demod_tri_kernel<MM>, hipFuncAttributeMaxDynamicSharedMemorySize, cfg->p_lds_bytes)); \
         hipLaunchKernelGGL((wenet_demod_tri_kernel<MM>), dim3(groups), dim3(WP_THREADS), cfg->p_lds_bytes, stream, *cfg, d_chans, nchan);    \
     } while (0)
     if (cfg->M == 2) WT_LAUNCH(2); else WT_LAUNCH(4);

@@ -690,7 +690,7 @@ __global__ __launch_bounds__(WP_THREADS, 4) void wenet_demod_tri_kernel(WrDemodC
             tr[WR_TR_NIN] = (float)nin_next;
             tr[WR_TR_NRT] = norm_rx_timing_st;
             tr[WR_TR_PPM] = ppm;
-            tr[WR_TR_MEAN] = tr_mean;
+            tr[WR_TR_MEAN] = nan_frame ? __int_as_float(0x7fc00000) : tr_mean;   // NaN marks a frame the reference returned early from (fsk.c:878-880): the host leaves EbNodB / snr_est alone
             tr[WR_TR_STD] = tr_std;
             tr[WR_TR_RXT] = tr_rxt;
         }

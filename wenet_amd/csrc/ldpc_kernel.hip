@@ -484,7 +484,7 @@ extern "C" hipError_t wr_launch_decode(const WrDecodeArgs *args, hipStream_t str
         else hipLaunchKernelGGL(wenet_llr_stats_kernel<false>, sgrid, dim3(64), 0, stream, *args);
     }
     const int lds = WR_DEC_LDS_BYTES;
-    (void)hipFuncSetAttribute((const void *)wenet_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    wr_attr_ok(hipFuncSetAttribute((const void *)wenet_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipLaunchKernelGGL(wenet_decode_kernel, dim3(args->max_pk, args->nchan), dim3(WR_DEC_THREADS), lds, stream, *args);
     if (!args->stop_after_llr && args->out)
         hipLaunchKernelGGL(wenet_crc_kernel, dim3(blocks), dim3(256), 0, stream, *args);

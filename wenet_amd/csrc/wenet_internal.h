@@ -1,6 +1,10 @@
 // wenet_internal.h -- layouts shared by the host side and the gfx950 kernels of libwenet_rx.so.
 #pragma once
 #include <stdint.h>
+#include <stdio.h>
+
+// a rejected launch attribute (e.g. more dynamic LDS than the device has) is reported where it happens, not as a generic launch error later
+#define wr_attr_ok(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) fprintf(stderr, "libwenet_rx: %s: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
 
 #define WR_M_MAX        4
 #define WR_MAX_STAGES   12

@@ -63,16 +63,20 @@ struct DevBuf {
     template <typename T> T *as() const { return (T *)p; }
 };
 
+int g_device = -1;          // the device the process works on (set once; include/wenet_rx.h: one device per process)
 bool device_ready() {
-    static int state = 0;   // 0 unknown, 1 ok, -1 absent
-    if (state == 0) {
+    static std::once_flag once;
+    static bool ok = false;
+    std::call_once(once, [] {
         int n = 0;
         if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
             fprintf(stderr, "libwenet_rx: no HIP device available -- this library has no CPU fallback\n");
-            state = -1;
-        } else state = 1;
-    }
-    return state == 1;
+            return;
+        }
+        if (hipGetDevice(&g_device) != hipSuccess) g_device = 0;
+        ok = true;
+    });
+    return ok;
 }
 
 struct cpx { float r, i; };
@@ -672,8 +676,10 @@ extern "C" long wenet_fsk_demod_stream(wenet_fsk *f, int fmt, const void *raw, l
         for (long k = 0; k < frames; k++) {
             const float *t = &tr[(size_t)k * WR_TRACE_FLOATS];
             const float meanebno = t[WR_TR_MEAN], stdebno = t[WR_TR_STD];
-            const float EbNodB = -6 + (20 * log10f((float)((1e-6 + meanebno) / (1e-6 + stdebno))));
-            f->snr_est = (float)(.5 * f->snr_est + .5 * EbNodB);
+            if (meanebno == meanebno) {                                 // (NaN: the reference returned before fsk.c:1009/1021 on this frame)
+                const float EbNodB = -6 + (20 * log10f((float)((1e-6 + meanebno) / (1e-6 + stdebno))));
+                f->snr_est = (float)(.5 * f->snr_est + .5 * EbNodB);
+            }
             for (int m = 0; m < 4; m++) f->f_est_last[m] = t[WR_TR_FEST + m];
             if (di < got && k == next_dump) {
                 wenet_modem_stats s;
@@ -954,6 +960,14 @@ extern "C" long long wenet_rx_fast_reruns(wenet_rx *rx) { return rx ? rx->fast_f
 static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const long long *nsamples, int fmt, void *stream_v,
                       const void *const *host_src) {
     if (!rx || nchan <= 0 || fmt < 0 || fmt > 3) return -1;
+    if (rx->pending && wenet_rx_collect(rx) < 0) return -1;            // a batch still in flight owns the buffers: finish it first
+    {   // one device per process: the code tables live on the device that was current when the library first ran
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess || (g_device >= 0 && dev != g_device)) {
+            fprintf(stderr, "libwenet_rx: the current HIP device (%d) is not the one the library was initialised on (%d)\n", dev, g_device);
+            return -1;
+        }
+    }
     LdpcTables *t = ldpc_tables();
     if (!t) return -1;
     const WrDemodCfg &c = rx->tab.cfg;
@@ -1187,12 +1201,14 @@ extern "C" int wenet_rx_process(wenet_rx *rx, int nchan, const void *const *raw,
     return rc < 0 ? rc : wenet_rx_collect(rx);
 }
 
+// results belong to the last COLLECTED batch: while an enqueue is pending (rx->nchan etc. already describe the batch in flight) every
+// getter refuses
 extern "C" long long wenet_rx_frames(wenet_rx *rx, int ch) {
-    if (!rx || ch < 0 || ch >= rx->nchan) return -1;
+    if (!rx || rx->pending || ch < 0 || ch >= rx->nchan || (size_t)(ch + 1) * rx->tab.cfg.st_floats > rx->h_states.size()) return -1;
     return ((const WrChanHdr *)&rx->h_states[(size_t)ch * rx->tab.cfg.st_floats])->frames_call;
 }
 extern "C" long long wenet_rx_packets(wenet_rx *rx, int ch) {
-    if (!rx || ch < 0 || ch >= rx->nchan || rx->h_dstates.empty()) return -1;
+    if (!rx || rx->pending || ch < 0 || ch >= rx->nchan || (size_t)ch >= rx->h_dstates.size()) return -1;
     return rx->h_dstates[ch].npackets;
 }
 extern "C" long long wenet_rx_get_packets(wenet_rx *rx, int ch, uint8_t *pkt_bytes, wenet_packet_info *info, long long cap) {
@@ -1314,7 +1330,9 @@ extern "C" int wenet_rx_device_info(int what) {
     if (what == 0) return n;
     if (n <= 0) return -1;
     hipDeviceProp_t p;
-    if (hipGetDeviceProperties(&p, 0) != hipSuccess) return -1;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    if (hipGetDeviceProperties(&p, dev) != hipSuccess) return -1;
     if (what == 1) return p.multiProcessorCount;
     return -1;
 }
