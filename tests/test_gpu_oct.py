@@ -120,3 +120,35 @@ def test_fast_mode_within_tolerance(name):
           f"max |d sd| / frame max {worst_sd:.3g}, max |d LLR| {worst_llr_abs:.3g} abs, {worst_llr_rel:.3g} of the packet's largest")
     assert worst_nrt < 2e-5 and worst_sd < 1e-4 and worst_llr_rel < 1e-4
     rx.close()
+
+
+def test_exact_mode_4fsk_ts32_equals_oracle(monkeypatch):
+    """The large geometry of the batch kernel (BASELINE config 4: 4-FSK, Rs 57 600, Fs 1 843 200 -> Ts 32, 1024-point estimator, two
+    soft decisions per symbol), forced here: every capture equals the oracle bit for bit, slips and ragged ends included."""
+    monkeypatch.setenv("WENET_RX_OCT", "2")
+    cfg = siggen.config_4fsk()
+    spec = ((4, 8.0, 0.0), (2, 12.0, 150.0), (3, 6.5, -300.0), (1, 20.0, 0.0), (2, 9.0, 2000.0), (2, 7.0, -2500.0))
+    caps = [siggen.make_capture(cfg, n, eb, seed=740 + i, ppm=ppm)[0] for i, (n, eb, ppm) in enumerate(spec)]
+    caps.insert(2, np.zeros(0, np.uint8))
+    caps.append(caps[0][:2 * cfg.Ts * 48 * 5 + 7])
+    rx = RxBatch(cfg.Fs, cfg.Rs, cfg.M, framing=cfg.mode, max_iter=50)
+    rx.enable_trace()
+    rx.enable_llr_dump()
+    rx.process(caps, "cu8")
+    assert rx.last_kernel() == "wenet_demod_oct_kernel"
+    slips = 0
+    for i, c in enumerate(caps):
+        if not c.size:
+            assert rx.frames(i) == 0
+            continue
+        sd, tr = ol.oracle_demod(c, "cu8", cfg.Fs, cfg.Rs, cfg.M, want_trace=True)
+        assert bits_equal(rx.soft(i), sd), i
+        assert bits_equal(np.ascontiguousarray(rx.trace(i)[:, :7]), np.ascontiguousarray(tr[:, :7])), i
+        ref = ol.oracle_deframe(sd, cfg.mode, max_iter=50, want_llr=True)
+        p = rx.packets(i)
+        assert p["n"] == ref["n"]
+        if ref["n"]:
+            assert (p["bytes"] == ref["bytes"]).all() and (p["iter"] == ref["iter"]).all() and bits_equal(rx.llrs(i), ref["llr"])
+        slips += int((tr[:, 4] != cfg.Ts * 48).sum())
+    assert slips > 10
+    rx.close()

@@ -9,6 +9,7 @@ sys.path.insert(0, ROOT)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 7
 secs = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
 caps = sys.argv[3] if len(sys.argv) > 3 else "7"
+cfgname = sys.argv[4] if len(sys.argv) > 4 else "v2"
 os.environ["WENET_RX_PROFILE"] = "4"
 os.environ["WENET_RX_OCT"] = caps
 import numpy as np
@@ -17,7 +18,7 @@ from wenet_amd import siggen
 from wenet_amd.rx import RxBatch
 from wenet_amd.tx import Tx
 
-cfg = siggen.config_v2()
+cfg = siggen.CONFIGS[cfgname]()
 dev = torch.device("cuda", 0)
 nsym = int(secs * cfg.Rs); nsamp = nsym * cfg.Ts
 tx = Tx.from_config(cfg)

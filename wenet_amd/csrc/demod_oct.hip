@@ -6,15 +6,17 @@ extern "C" hipError_t wr_launch_demod_oct(const WrDemodCfg *cfg, const WrChan *d
     if (!cfg->o_ok) return hipErrorInvalidValue;
     const int groups = (nchan + cfg->o_caps - 1) / cfg->o_caps;
     const int threads = (cfg->o_caps + (fast ? 0 : 1)) * 64;
-#define WO_LAUNCH(TT, FF)                                                                                                          \
+#define WO_LAUNCH(MM, TT, NN, FF)                                                                                                         \
     do {                                                                                                                           \
-        hipError_t e = hipFuncSetAttribute((const void *)wenet_demod_oct_kernel<2, TT, FF>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+        hipError_t e = hipFuncSetAttribute((const void *)wenet_demod_oct_kernel<MM, TT, NN, FF>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                            cfg->o_lds_bytes);                                                                      \
         if (e != hipSuccess) return e;                                                                                             \
-        hipLaunchKernelGGL((wenet_demod_oct_kernel<2, TT, FF>), dim3(groups), dim3(threads), cfg->o_lds_bytes, stream, *cfg, d_chans, nchan); \
+        hipLaunchKernelGGL((wenet_demod_oct_kernel<MM, TT, NN, FF>), dim3(groups), dim3(threads), cfg->o_lds_bytes, stream, *cfg, d_chans, nchan); \
     } while (0)
-    if (cfg->Ts == 10) { if (fast) WO_LAUNCH(10, true); else WO_LAUNCH(10, false); }
-    else               { if (fast) WO_LAUNCH(8, true);  else WO_LAUNCH(8, false); }
+    if (cfg->M == 2 && cfg->Ts == 10 && cfg->Ndft == 256)       { if (fast) WO_LAUNCH(2, 10, 256, true); else WO_LAUNCH(2, 10, 256, false); }
+    else if (cfg->M == 2 && cfg->Ts == 8 && cfg->Ndft == 256)   { if (fast) WO_LAUNCH(2, 8, 256, true);  else WO_LAUNCH(2, 8, 256, false); }
+    else if (cfg->M == 4 && cfg->Ts == 32 && cfg->Ndft == 1024) { if (fast) WO_LAUNCH(4, 32, 1024, true); else WO_LAUNCH(4, 32, 1024, false); }
+    else return hipErrorInvalidValue;
 #undef WO_LAUNCH
     return hipGetLastError();
 }

@@ -45,9 +45,11 @@
 
 namespace {
 
-enum { OC_NIN = 0, OC_ALIVE = 1, OC_FBIN = 2 /* [2] this frame */, OC_FBINP = 4 /* [2] previous frame, first-run rule applied (fsk.c:750-753) */,
-       OC_FBINN = 6 /* [2] next frame (estimated ahead, see the frame loop) */, OC_TC = 10 /* float re, im: timing sum */,
-       OC_SEQ = 12 /* frames whose nin, bins and alive flag are published: the duty wave starts a frame's chains on it */, OC_INTS = 16 };
+enum { OC_NIN = 0, OC_ALIVE = 1,
+       OC_SEQ = 2 /* frames whose nin, bins and alive flag are published: the duty wave starts a frame's chains on it */,
+       OC_TC = 4 /* float re, im: timing sum */,
+       OC_FBIN = 8 /* [4] tone bins of this frame */, OC_FBINP = 12 /* [4] previous frame's, first-run rule applied (fsk.c:750-753) */,
+       OC_FBINN = 16 /* [4] next frame's (estimated ahead, see the frame loop) */, OC_INTS = 32 };
 
 typedef __attribute__((address_space(3))) float oct_lds_f32;
 
@@ -73,19 +75,30 @@ template <int N>
 __device__ __forceinline__ v2f nco_steps(v2f phi, v2f d) {           // N steps phi *= d (cmul_pk) in one asm block: no padding between them
     v2f t1, t2;
 #define WO_NCO1 "v_pk_mul_f32 %1, %0, %3 op_sel_hi:[1,0]\n\tv_pk_mul_f32 %2, %0, %3 op_sel:[1,1] op_sel_hi:[0,1]\n\tv_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]\n\t"
-    static_assert(N == 4 || N == 5, "half a symbol of Ts 8 or 10");
-    if (N == 4) asm(WO_NCO1 WO_NCO1 WO_NCO1 WO_NCO1 : "+v"(phi), "=&v"(t1), "=&v"(t2) : "v"(d));
-    else asm(WO_NCO1 WO_NCO1 WO_NCO1 WO_NCO1 WO_NCO1 : "+v"(phi), "=&v"(t1), "=&v"(t2) : "v"(d));
+    static_assert(N == 4 || N == 5 || N == 16, "half a symbol of Ts 8, 10 or 32");
+    if (N == 5) asm(WO_NCO1 WO_NCO1 WO_NCO1 WO_NCO1 WO_NCO1 : "+v"(phi), "=&v"(t1), "=&v"(t2) : "v"(d));
+    else {
+#pragma unroll
+        for (int k = 0; k < N / 4; k++) asm(WO_NCO1 WO_NCO1 WO_NCO1 WO_NCO1 : "+v"(phi), "=&v"(t1), "=&v"(t2) : "v"(d));
+    }
 #undef WO_NCO1
     return phi;
 }
 
 }  // namespace
 
-template <int M, int TS, bool FAST>
-__global__ __launch_bounds__(1024, WO_WAVES_PER_EU) void wenet_demod_oct_kernel(WrDemodCfg cfg, const WrChan *chans, int nchan) {
-    static_assert(M == 2, "two tones (four would need two soft decisions per lane)");
+// Geometries: (M 2, TS 8 | 10, NDFT 256) = Wenet v1 / v2; (M 4, TS 32, NDFT 1024) = BASELINE config 4 (4-FSK, Fs 1 843 200).  The small ones keep every
+// table in LDS and fetch their samples a frame ahead; the large one reads three of the tables through the caches and loads its samples
+// where it uses them (the registers they would sit in are worth more than the microsecond in a 35 us frame).
+template <int M, int TS, int NDFT, bool FAST>
+// (launch bounds: the LDS of the large geometry allows <= 10 wavefronts per CU anyway, so it may have 256 VGPRs)
+__global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WAVES_PER_EU) void wenet_demod_oct_kernel(WrDemodCfg cfg, const WrChan *chans, int nchan) {
+    static_assert(M == 2 || M == 4, "two or four tones");
+    static_assert(NDFT == 256 || NDFT == 1024, "a power of four: radix-4 stages only");
     constexpr int H = TS / 2;                                            // checkpoint spacing = the unit of a timing slip
+    constexpr bool SMALL = (NDFT == 256);                                // all tables in LDS, samples fetched a frame ahead
+    constexpr unsigned ALLOUT = TS == 32 ? 0xffffffffu : (1u << TS) - 1u;
+    constexpr int NSD = M == 2 ? 1 : 2;                                  // soft decisions per symbol (fsk.c:955-980)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int G = cfg.o_caps;                                            // captures (= capture waves) of this workgroup
@@ -106,17 +119,19 @@ __global__ __launch_bounds__(1024, WO_WAVES_PER_EU) void wenet_demod_oct_kernel(
     int    *CT = (int *)(smem + cfg.o_off_CT);
     const float2 *tw_t = (const float2 *)(smem_all + cfg.o_off_TW);
     const float  *hann_t = (const float *)(smem_all + cfg.o_off_HANN);
-    const int    *src_t = (const int *)(smem_all + cfg.o_off_SRC);
     const float2 *dphi_t = (const float2 *)(smem_all + cfg.o_off_DPHI);
-    const float2 *pft_t = (const float2 *)(smem_all + cfg.o_off_PFT);
-    const float2 *back_t = (const float2 *)(smem_all + cfg.o_off_BACK);
+    const int    *src_t = SMALL ? (const int *)(smem_all + cfg.o_off_SRC) : cfg.fft_src;
+    const float2 *pft_t = SMALL ? (const float2 *)(smem_all + cfg.o_off_PFT) : cfg.phi_ft;
+    const float2 *back_t = SMALL ? (const float2 *)(smem_all + cfg.o_off_BACK) : cfg.backoff_tab;
     const int ctw = cfg.o_cap_stride / 4;
     const int *CT0 = (const int *)(smem_all + cfg.o_off_CT);
 
-    const int N = cfg.N, Nmem = cfg.Nmem, nstash = cfg.nstash, Ndft = cfg.Ndft, NH = cfg.Ndft / 2, L = cfg.L, NI = cfg.NI;
+    constexpr int Ndft = NDFT, NH = NDFT / 2;
+    const int N = cfg.N, Nmem = cfg.Nmem, nstash = cfg.nstash, L = cfg.L, NI = cfg.NI;
     const int NIq = (NI + 3) & ~3, NHB = cfg.o_nhb;
     const int NOUT = NI / TS;                                            // lanes that own integrator outputs (NI = (Nsym+1)*TS)
-    constexpr int NE = 4;                                                // estimator samples per lane (Ndft = 256)
+    constexpr int NE = NDFT / 64;                                        // estimator points per lane
+    constexpr int NBF = NDFT / 256;                                      // radix-4 butterflies per lane and stage
 
     WrChanHdr *hdr = (WrChanHdr *)C.state;
     float *st_fft = C.state + cfg.st_fft_est;
@@ -128,17 +143,22 @@ __global__ __launch_bounds__(1024, WO_WAVES_PER_EU) void wenet_demod_oct_kernel(
     // ---- shared tables and carried state -> LDS / registers ------------------------------------
     {
         float2 *tw_w = (float2 *)(smem_all + cfg.o_off_TW); float *hann_w = (float *)(smem_all + cfg.o_off_HANN);
-        int *src_w = (int *)(smem_all + cfg.o_off_SRC); float2 *dphi_w = (float2 *)(smem_all + cfg.o_off_DPHI);
-        float2 *pft_w = (float2 *)(smem_all + cfg.o_off_PFT);
+        float2 *dphi_w = (float2 *)(smem_all + cfg.o_off_DPHI);
         const int nt = blockDim.x;
-        for (int i = tid; i < Ndft; i += nt) { tw_w[i] = cfg.tw[i]; hann_w[i] = cfg.hann[i]; src_w[i] = cfg.fft_src[i]; }
+        for (int i = tid; i < Ndft; i += nt) { tw_w[i] = cfg.tw[i]; hann_w[i] = cfg.hann[i]; }
         for (int i = tid; i < NH; i += nt) dphi_w[i] = cfg.dphi_tab[i];
-        for (int i = tid; i < NI; i += nt) pft_w[i] = cfg.phi_ft[i];
-        float2 *back_w = (float2 *)(smem_all + cfg.o_off_BACK);
-        for (int i = tid; i < 3 * NH; i += nt) back_w[i] = cfg.backoff_tab[i];
+        if (SMALL) {
+            int *src_w = (int *)(smem_all + cfg.o_off_SRC); float2 *pft_w = (float2 *)(smem_all + cfg.o_off_PFT);
+            float2 *back_w = (float2 *)(smem_all + cfg.o_off_BACK);
+            for (int i = tid; i < Ndft; i += nt) src_w[i] = cfg.fft_src[i];
+            for (int i = tid; i < NI; i += nt) pft_w[i] = cfg.phi_ft[i];
+            for (int i = tid; i < 3 * NH; i += nt) back_w[i] = cfg.backoff_tab[i];
+        }
     }
     int nin = N;
-    float sdl = 0.f;                                                     // this lane's last soft decision (re-emitted by a NaN frame, fsk.c:878-880)
+    float sdl[NSD];                                                      // this lane's last soft decision(s) (re-emitted by a NaN frame, fsk.c:878-880)
+#pragma unroll
+    for (int b = 0; b < NSD; b++) sdl[b] = 0.f;
     float norm_rx_timing_st = 0.f, ppm = 0.f;
     long long off = 0, frames = 0;
     int nslip = 0, nuncertain = 0;
@@ -146,7 +166,10 @@ __global__ __launch_bounds__(1024, WO_WAVES_PER_EU) void wenet_demod_oct_kernel(
     if (is_cap) {
         for (int i = lane; i < NH; i += 64) FE2[i] = present ? st_fft[i] : 0.f;
         if (present) {
-            if (lane < cfg.Nbits) sdl = st_sd[lane];
+            if (lane < WR_NSYM) {
+#pragma unroll
+                for (int b = 0; b < NSD; b++) sdl[b] = st_sd[lane * NSD + b];
+            }
             nin = __builtin_amdgcn_readfirstlane(hdr->nin);
             norm_rx_timing_st = hdr->norm_rx_timing; ppm = hdr->ppm;
         }
@@ -173,26 +196,28 @@ __global__ __launch_bounds__(1024, WO_WAVES_PER_EU) void wenet_demod_oct_kernel(
     };
 
     // ================================ capture-wave stages ======================================
-    unsigned epre[NE];                                                   // estimator samples of the NEXT frame (its start is known a frame ahead)
+    unsigned epre[SMALL ? NE : 1];                                       // estimator samples of the NEXT frame (its start is known a frame ahead)
     unsigned xr[TS / 2 + 1];                                             // this lane's symbol slot of the frame about to be mixed, two cu8 samples per dword
     const int NBLK = (L + TS - 1) / TS;                                  // lanes that own samples
     // The lane number, opaque to the optimiser: per-lane LDS / global addresses derived from it are recomputed where they are used
     // (a handful of integer instructions) instead of being hoisted out of the frame loop into dozens of registers that then spill.
-    auto fresh_lane = [&]() -> int { int l = lane; asm volatile("" : "+v"(l)); return l; };
-    auto prefetch_est = [&](long long off_j) {
+    auto fresh_lane = [&]() __attribute__((always_inline)) -> int { int l = lane; asm volatile("" : "+v"(l)); return l; };
+    long long est_off = 0;                                               // large geometry: first sample of the frame estimate_fft() windows
+    auto prefetch_est = [&](long long off_j) __attribute__((always_inline)) {
+        if (!SMALL) { est_off = off_j; return; }                         // (loaded inside estimate_fft)
         const int ln = fresh_lane();
         if (off_j + Ndft <= C.nsamples) {                                // the whole transform window is inside the capture: no index clamping
             const unsigned short *p = raw16 + off_j;
 #pragma unroll
-            for (int j = 0; j < NE; j++) epre[j] = p[src_t[4 * ln + j]];
+            for (int j = 0; j < NE; j++) epre[j] = p[src_t[4 * (ln + 64 * (j >> 2)) + (j & 3)]];
         } else {                                                         // (a run ahead of the capture's end: its result is never used)
 #pragma unroll
-            for (int j = 0; j < NE; j++) { long long a = off_j + src_t[4 * ln + j]; epre[j] = raw16[a < last_smp ? a : last_smp]; }
+            for (int j = 0; j < NE; j++) { long long a = off_j + src_t[4 * (ln + 64 * (j >> 2)) + (j & 3)]; epre[j] = raw16[a < last_smp ? a : last_smp]; }
         }
     };
     // The lane's symbol slot as TS/2 + 1 aligned dwords (two cu8 samples each) starting at the even sample at or below its first
     // one; slot_align() shifts them down by a sample when the first one is odd -- at the point of use, so the loads stay in flight.
-    auto prefetch_slot = [&](long long off_j, int nin_j) {
+    auto prefetch_slot = [&](long long off_j, int nin_j) __attribute__((always_inline)) {
         const int ln = fresh_lane(), slot = ln < NBLK ? ln : NBLK - 1;    // (idle lanes repeat the last slot: always inside the frame)
         const long long b0 = off_j - (Nmem - nin_j);                     // buffer position 0 (negative only in a launch's first frame)
         if (b0 >= 0 && b0 + Nmem + 1 <= C.nsamples) {                    // positions 0 .. Nmem (one past the window) are samples of the capture
@@ -218,13 +243,13 @@ __global__ __launch_bounds__(1024, WO_WAVES_PER_EU) void wenet_demod_oct_kernel(
             }
         }
     };
-    auto slot_align = [&](long long off_j, int nin_j) {
+    auto slot_align = [&](long long off_j, int nin_j) __attribute__((always_inline)) {
         if ((off_j - (Nmem - nin_j)) & 1) {
 #pragma unroll
             for (int u = 0; u < TS / 2; u++) xr[u] = __builtin_amdgcn_alignbit(xr[u + 1], xr[u], 16);
         }
     };
-    auto slot_sample = [&](int u) -> v2f {                               // sample u of the (aligned) slot -> COMP, fsk_demod.c:283-284
+    auto slot_sample = [&](int u) __attribute__((always_inline)) -> v2f {                               // sample u of the (aligned) slot -> COMP, fsk_demod.c:283-284
         const unsigned w = xr[u >> 1] >> (16 * (u & 1));
         // ((float)u8 - 127) / 128 is exact in float, and so is the one-rounding form u8/128 - 127/128: one instruction per component
         return (v2f){__builtin_fmaf((float)(w & 0xffu), 0.0078125f, -0.9921875f), __builtin_fmaf((float)((w >> 8) & 0xffu), 0.0078125f, -0.9921875f)};
@@ -234,11 +259,11 @@ __global__ __launch_bounds__(1024, WO_WAVES_PER_EU) void wenet_demod_oct_kernel(
     int fecur = 0;                                                       // FE2[fecur]: spectrum after the estimator run of the frame in work
     // E(j) in two parts: estimate_fft (window + FFT, leaves the spectrum in FB) and estimate_pick (magnitude, smoothing, tone
     // search: reads FE2[fecur], leaves FE2[fecur ^ 1] and the bins in OC_FBINN)
-    // 256 points = four radix-4 stages of kiss_fft's decimation-in-time recursion (kiss_fft.c:237-302, kf_bfly4 :44-90), innermost
+    // Ndft = 4^k points = k radix-4 stages of kiss_fft's decimation-in-time recursion (kiss_fft.c:237-302, kf_bfly4 :44-90), innermost
     // butterflies first.  Lane b loads the four digit-reversed inputs of ITS first butterfly (elements 4b .. 4b+3), so the window
     // goes straight into stage one; that stage's twiddles are all tw[0] = (1, -0), a multiplication that changes nothing but the
     // sign of a zero (which no later sum or |.|^2 can see); of the last stage only the Ndft/2 outputs the spectrum reads are formed.
-    auto bfly4 = [&](float2 f0, float2 s0, float2 s1, float2 s2, float2 &o0, float2 &o1, float2 &o2, float2 &o3) {
+    auto bfly4 = [&](float2 f0, float2 s0, float2 s1, float2 s2, float2 &o0, float2 &o1, float2 &o2, float2 &o3) __attribute__((always_inline)) {
         const float2 s5 = make_float2(f0.x - s1.x, f0.y - s1.y);
         f0 = make_float2(f0.x + s1.x, f0.y + s1.y);
         const float2 s3 = make_float2(s0.x + s2.x, s0.y + s2.y);
@@ -248,49 +273,65 @@ __global__ __launch_bounds__(1024, WO_WAVES_PER_EU) void wenet_demod_oct_kernel(
         o1 = make_float2(s5.x + s4.y, s5.y - s4.x);
         o3 = make_float2(s5.x - s4.y, s5.y + s4.x);
     };
-    auto estimate_fft = [&](int nin_j) {
+    auto estimate_fft = [&](int nin_j) __attribute__((always_inline)) {
         const int fft_samps = nin_j - Ndft;                              // fsk.c:583-584 with fft_loops == 1
         const int ln = fresh_lane();
-        float2 v[4];
+#pragma unroll(NBF > 2 ? 1 : NBF)                                       // (large transform: one butterfly at a time -- more in flight spill)
+        for (int jb = 0; jb < NBF; jb++) {                               // first stage (m = 1) straight from the window, butterfly bf = ln + 64 jb
+            const int bf = ln + 64 * jb;
+            float2 v[4];
 #pragma unroll
-        for (int j = 0; j < NE; j++) {                                   // fsk.c:587-603: half-Hann window, zero padding
-            const int idx = src_t[4 * ln + j];
-            v[j] = make_float2(0.f, 0.f);
-            if (idx < fft_samps) { const float h = hann_t[idx]; const float2 x = cvt(epre[j]); v[j] = make_float2(h * x.x, h * x.y); }
-        }
-        {
+            for (int i = 0; i < 4; i++) {                                // fsk.c:587-603: half-Hann window, zero padding
+                const int idx = src_t[4 * bf + i];
+                v[i] = make_float2(0.f, 0.f);
+                if (idx < fft_samps) {
+                    const float h = hann_t[idx];
+                    const float2 x = cvt(SMALL ? epre[SMALL ? 4 * jb + i : 0] : (unsigned)raw16[est_off + idx < last_smp ? est_off + idx : last_smp]);
+                    v[i] = make_float2(h * x.x, h * x.y);
+                }
+            }
             float2 o0, o1, o2, o3;
             bfly4(v[0], v[1], v[2], v[3], o0, o1, o2, o3);
-            float4 *F4 = (float4 *)(FB + 4 * ln);
+            float4 *F4 = (float4 *)(FB + 4 * bf);
             F4[0] = make_float4(o0.x, o0.y, o1.x, o1.y);
             F4[1] = make_float4(o2.x, o2.y, o3.x, o3.y);
         }
         wave_sync();
+        constexpr int NST = NDFT == 256 ? 4 : 5;                         // radix-4 stages
 #pragma unroll
-        for (int st = 0; st < 2; st++) {                                 // m = 4, fstride 16;  m = 16, fstride 4
-            const int lgm = st ? 4 : 2, m = 1 << lgm, fs = st ? 4 : 16;
-            const int blk = ln >> lgm, k = ln & (m - 1);
-            float2 *F = FB + blk * m * 4 + k;
-            const float2 s0 = cmul(F[m], tw_t[k * fs]);
-            const float2 s1 = cmul(F[2 * m], tw_t[k * fs * 2]);
-            const float2 s2 = cmul(F[3 * m], tw_t[k * fs * 3]);
-            float2 o0, o1, o2, o3;
-            bfly4(F[0], s0, s1, s2, o0, o1, o2, o3);
-            F[0] = o0; F[m] = o1; F[2 * m] = o2; F[3 * m] = o3;
+        for (int st = 1; st < NST - 1; st++) {                           // m = 4, 16, (64): fstride = Ndft / (4 m)
+            const int lgm = 2 * st, m = 1 << lgm, fs = NDFT >> (lgm + 2);
+#pragma unroll(NBF > 2 ? 1 : NBF)
+            for (int jb = 0; jb < NBF; jb++) {
+                const int bf = ln + 64 * jb;
+                const int blk = bf >> lgm, k = bf & (m - 1);
+                float2 *F = FB + blk * m * 4 + k;
+                const float2 s0 = cmul(F[m], tw_t[k * fs]);
+                const float2 s1 = cmul(F[2 * m], tw_t[k * fs * 2]);
+                const float2 s2 = cmul(F[3 * m], tw_t[k * fs * 3]);
+                float2 o0, o1, o2, o3;
+                bfly4(F[0], s0, s1, s2, o0, o1, o2, o3);
+                F[0] = o0; F[m] = o1; F[2 * m] = o2; F[3 * m] = o3;
+            }
             wave_sync();
         }
-        {                                                                // m = 64, fstride 1: outputs 0 .. Ndft/2 - 1 only
-            float2 *F = FB + ln;
-            const float2 s0 = cmul(F[64], tw_t[ln]);
-            const float2 s1 = cmul(F[128], tw_t[2 * ln]);
-            const float2 s2 = cmul(F[192], tw_t[3 * ln]);
-            float2 o0, o1, o2, o3;
-            bfly4(F[0], s0, s1, s2, o0, o1, o2, o3);
-            F[0] = o0; F[64] = o1;
+        {                                                                // last stage, m = Ndft / 4, fstride 1: outputs 0 .. Ndft/2 - 1 only
+            constexpr int m = NDFT / 4;
+#pragma unroll(NBF > 2 ? 1 : NBF)
+            for (int jb = 0; jb < NBF; jb++) {
+                const int k = ln + 64 * jb;
+                float2 *F = FB + k;
+                const float2 s0 = cmul(F[m], tw_t[k]);
+                const float2 s1 = cmul(F[2 * m], tw_t[2 * k]);
+                const float2 s2 = cmul(F[3 * m], tw_t[3 * k]);
+                float2 o0, o1, o2, o3;
+                bfly4(F[0], s0, s1, s2, o0, o1, o2, o3);
+                F[0] = o0; F[m] = o1;
+            }
             wave_sync();
         }
     };
-    auto estimate_pick = [&]() {
+    auto estimate_pick = [&]() __attribute__((always_inline)) {
         const float *FEin = FE2 + fecur * NH;
         float *FEout = FE2 + (fecur ^ 1) * NH;
         const int ln = fresh_lane();
@@ -327,14 +368,22 @@ __global__ __launch_bounds__(1024, WO_WAVES_PER_EU) void wenet_demod_oct_kernel(
             wave_sync();
             fbin[k] = imax;
         }
-        if (fbin[0] > fbin[1]) { const int t = fbin[0]; fbin[0] = fbin[1]; fbin[1] = t; }     // fsk.c:658-667 (M == 2)
-        if (lane == 0) { CT[OC_FBINN] = fbin[0]; CT[OC_FBINN + 1] = fbin[1]; }
+#pragma unroll
+        for (int a = 1; a < M; a++) {                                    // fsk.c:658-667: ascending
+#pragma unroll
+            for (int b = a; b > 0; b--)
+                if (fbin[b - 1] > fbin[b]) { const int t = fbin[b]; fbin[b] = fbin[b - 1]; fbin[b - 1] = t; }
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int m = 0; m < M; m++) CT[OC_FBINN + m] = fbin[m];
+        }
         wave_sync();
     };
-    auto estimate = [&](int nin_j) { estimate_fft(nin_j); estimate_pick(); };
+    auto estimate = [&](int nin_j) __attribute__((always_inline)) { estimate_fft(nin_j); estimate_pick(); };
     // the frame whose estimator run is in OC_FBINN / FE2[fecur ^ 1] becomes the frame in work.  First-run rule (fsk.c:750-753): while
     // the stored estimate of tone 0 is below 1 Hz the old part of the frame is mixed with the NEW estimates
-    auto commit_estimate = [&]() {
+    auto commit_estimate = [&]() __attribute__((always_inline)) {
         if (lane == 0) {
             const bool first = CT[OC_FBIN] < cfg.o_first_bins;                // bin_freq[stored bin of tone 0] < 1.0f
 #pragma unroll
@@ -355,29 +404,48 @@ __global__ __launch_bounds__(1024, WO_WAVES_PER_EU) void wenet_demod_oct_kernel(
     // breaks the prediction is integrated a second time with the full mask before the next frame's chains overwrite the checkpoints.
     // (Keeping the four in registers instead was tried: 16 more live VGPRs spill, +18 % frame time.)
     float2 *Fscr = (float2 *)C.big;
-    unsigned omask = (1u << TS) - 1;                                     // outputs parked by the mix / integrate stage of the frame in work
+    unsigned omask = ALLOUT;                                     // outputs parked by the mix / integrate stage of the frame in work
     float pv_r = 0.f, pv_i = 0.f;                                        // the previous frame's timing vector (0, 0: none)
     // D(j): mix, integrate, timing products
     // omask: which of the TS outputs per tone are parked (bit r); realign = false when the slot dwords were aligned by an earlier call
-    auto dstage = [&](long long off_j, int nin_j, unsigned omask, bool realign) {
+    auto dstage = [&](long long off_j, int nin_j, unsigned omask, bool realign) __attribute__((always_inline)) {
         const int nold = Nmem - nin_j;
-        if (realign) slot_align(off_j, nin_j);
+        if (realign) { if (!SMALL) prefetch_slot(off_j, nin_j); slot_align(off_j, nin_j); }
         const int ln = fresh_lane(), slot = ln < NBLK ? ln : NBLK - 1;
-        char *fbase[3];
-        fbase[0] = (char *)(Fscr + ln);
+        constexpr bool FT1_LDS = TS > 10;                                // the per-output power sums: registers, or (large slots) the products' re row
+        float ft1[FT1_LDS ? 1 : TS];
+        float pw[FT1_LDS ? TS : 1];
+        v2f xs[SMALL ? 1 : TS];                                          // large geometry (256 VGPRs): the slot's samples converted once for all tones
+        if (!SMALL) {
 #pragma unroll
-        for (int k = 1; k < 3; k++) { fbase[k] = fbase[k - 1] + 4096; asm volatile("" : "+v"(fbase[k])); }
-        float ft1[TS];
+            for (int u = 0; u < TS; u++) xs[SMALL ? 0 : u] = slot_sample(u);
+        }
+        float *Trow = TPf + TS * ln;
+        char *fbase[3];
+        if (!FT1_LDS) {
+            fbase[0] = (char *)(Fscr + ln);
+#pragma unroll
+            for (int k = 1; k < 3; k++) { fbase[k] = fbase[k - 1] + 4096; asm volatile("" : "+v"(fbase[k])); }
+        }
         auto put_out = [&](int m, int r, v2f f) __attribute__((always_inline)) {
-            // value (m, r) sits 512 (m TS + r) bytes above the lane's first one: reached from three lane pointers 4 KB apart with the
-            // store's immediate offset (left to itself the compiler materialises -- and spills -- twenty 64-bit addresses)
-            const int byte = (m * TS + r) * 512;
-            if ((omask >> r) & 1) *(float2 *)(fbase[byte >> 12] + (byte & 4095)) = make_float2(f.x, f.y);
+            if ((omask >> r) & 1) {                                      // (wave-uniform)
+                if (!FT1_LDS) {
+                    // value (m, r) sits 512 (m TS + r) bytes above the lane's first one: reached from three lane pointers 4 KB apart with the
+                    // store's immediate offset (left to itself the compiler materialises -- and spills -- twenty 64-bit addresses)
+                    const int byte = (m * TS + r) * 512;
+                    *(float2 *)(fbase[byte >> 12] + (byte & 4095)) = make_float2(f.x, f.y);
+                } else {
+                    int l2 = ln;
+                    asm volatile("" : "+v"(l2));                         // (address formed here, under the branch: four of them per tone, not 128 hoisted ones)
+                    Fscr[(m * TS + r) * 64 + l2] = make_float2(f.x, f.y);
+                }
+            }
             const v2f sq = f * f;                                        // fsk.c:862-868
             const float a = sq.x + sq.y;
-            ft1[r] = (m == 0) ? a : ft1[r] + a;
+            if (!FT1_LDS) ft1[r] = (m == 0) ? a : ft1[r] + a;
+            else pw[r] = a;                                              // (this tone's powers; added to the row after the tone, in one go)
         };
-#pragma unroll
+#pragma unroll(FT1_LDS ? 1 : M)                                         // (large slots: one tone's code, run M times -- d[] alone is 2 TS registers)
         for (int m = 0; m < M; m++) {
             v2f d[TS];
             if (!FAST) {
@@ -391,7 +459,7 @@ __global__ __launch_bounds__(1024, WO_WAVES_PER_EU) void wenet_demod_oct_kernel(
                     const v2f dd = {segA ? dA2.x : dB2.x, segA ? dA2.y : dB2.y};
 #pragma unroll
                     for (int u = 0; u < H; u++) {
-                        d[hh * H + u] = cmul_conj_pk(slot_sample(hh * H + u), phi);                       // fsk.c:796 / :822
+                        d[hh * H + u] = cmul_conj_pk(SMALL ? slot_sample(hh * H + u) : xs[SMALL ? 0 : hh * H + u], phi);   // fsk.c:796 / :822
                         if (u < H - 1) phi = cmul_pk(phi, dd);                                     // fsk.c:798 / :824 (replayed from the checkpoint)
                     }
                 }
@@ -412,21 +480,29 @@ __global__ __launch_bounds__(1024, WO_WAVES_PER_EU) void wenet_demod_oct_kernel(
                 // phase-continuous at s = nold (fsk.c:756-764,785-788); angles are multiples of 2 pi / Ndft
                 const int bp = CT[OC_FBINP + m], bc = CT[OC_FBIN + m];
                 const int s0 = TS * ln;
+                v2f tot = {0.f, 0.f};
 #pragma unroll
                 for (int u = 0; u < TS; u++) {
                     const int s = s0 + u;
                     const int k = (s < nold) ? bp * s : bp * nold + bc * (s - nold);
                     const float2 w = tw_t[k & (Ndft - 1)];                // e^{-j 2 pi k / Ndft} = conj(phasor)
-                    const v2f x = slot_sample(u);
+                    const v2f x = SMALL ? slot_sample(u) : xs[SMALL ? 0 : u];
                     d[u] = (v2f){x.x * w.x - x.y * w.y, x.x * w.y + x.y * w.x};
+                    tot = tot + d[u];
                 }
-                v2f P[TS + 1];
-                P[1] = d[0];
+                put_out(m, 0, tot);
+                v2f run = d[0];                                          // window r = (this block without its first r samples) + (the next block's first r)
 #pragma unroll
-                for (int n = 1; n < TS; n++) P[n + 1] = P[n] + d[n];
-                put_out(m, 0, P[TS]);
+                for (int r = 1; r < TS; r++) { put_out(m, r, (tot - run) + lane_up(run)); run = run + d[r]; }
+            }
+            if (FT1_LDS && ln < NOUT) {                                  // ft1 += this tone's powers (fsk.c:866), four outputs per LDS access
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                v4f *T4 = (v4f *)Trow;
 #pragma unroll
-                for (int r = 1; r < TS; r++) put_out(m, r, (P[TS] - P[r]) + lane_up(P[r]));
+                for (int r4 = 0; r4 < TS / 4; r4++) {
+                    const v4f p = {pw[FT1_LDS ? 4 * r4 : 0], pw[FT1_LDS ? 4 * r4 + 1 : 0], pw[FT1_LDS ? 4 * r4 + 2 : 0], pw[FT1_LDS ? 4 * r4 + 3 : 0]};
+                    T4[r4] = (m == 0) ? p : T4[r4] + p;
+                }
             }
         }
         if (!FAST) {
@@ -434,7 +510,8 @@ __global__ __launch_bounds__(1024, WO_WAVES_PER_EU) void wenet_demod_oct_kernel(
 #pragma unroll
                 for (int r = 0; r < TS; r += 2) {                        // fsk.c:870-871: the products; the duty wave adds them in order
                     const float2 pa = pft_t[TS * ln + r], pb = pft_t[TS * ln + r + 1];
-                    const v2f ta = (v2f){ft1[r], ft1[r]} * (v2f){pa.x, pa.y}, tb = (v2f){ft1[r + 1], ft1[r + 1]} * (v2f){pb.x, pb.y};
+                    const float fa = FT1_LDS ? Trow[r] : ft1[FT1_LDS ? 0 : r], fb = FT1_LDS ? Trow[r + 1] : ft1[FT1_LDS ? 0 : r + 1];
+                    const v2f ta = (v2f){fa, fa} * (v2f){pa.x, pa.y}, tb = (v2f){fb, fb} * (v2f){pb.x, pb.y};
                     *(float2 *)(TPf + TS * ln + r) = make_float2(ta.x, tb.x);
                     *(float2 *)(TPf + NIq + TS * ln + r) = make_float2(ta.y, tb.y);
                 }
@@ -443,7 +520,11 @@ __global__ __launch_bounds__(1024, WO_WAVES_PER_EU) void wenet_demod_oct_kernel(
             float sr = 0.f, si = 0.f;
             if (ln < NOUT) {
 #pragma unroll
-                for (int r = 0; r < TS; r++) { const float2 pf = pft_t[TS * ln + r]; sr += ft1[r] * pf.x; si += ft1[r] * pf.y; }
+                for (int r = 0; r < TS; r++) {
+                    const float2 pf = pft_t[TS * ln + r];
+                    const float fa = FT1_LDS ? Trow[r] : ft1[FT1_LDS ? 0 : r];
+                    sr += fa * pf.x; si += fa * pf.y;
+                }
             }
 #pragma unroll
             for (int sh = 32; sh >= 1; sh >>= 1) { sr += __shfl_xor(sr, sh, 64); si += __shfl_xor(si, sh, 64); }
@@ -456,14 +537,16 @@ __global__ __launch_bounds__(1024, WO_WAVES_PER_EU) void wenet_demod_oct_kernel(
     // T(j) in two parts.  tstage1: timing estimate and nin of the next frame (fsk.c:876-907) -- everything the next frame's NCO
     // chain waits for; tstage2: resampling, decisions, outputs (fsk.c:913-993).
     float t_rxt = 0.f, t_fract = 0.f;
-    int t_low = 0, t_high = 0, t_nin_next = 0, t_bins[M] = {0, 0};      // (t_bins: tone bins of the frame, for the trace)
+    int t_low = 0, t_high = 0, t_nin_next = 0, t_bins[M];               // (t_bins: tone bins of the frame, for the trace)
+#pragma unroll
+    for (int m = 0; m < M; m++) t_bins[m] = 0;
     bool t_nan = false;
     // nin(k+1) first: norm_rx_timing = (float)((double)atan2f / 2 pi) is monotone in the atan2f value, so "norm_rx_timing > 0.25f"
     // is the same predicate as "atan2f > o_at_hi" (the host finds the float where it flips, DemodTables::oct_cfg): the double
     // division leaves the path the next frame's NCO chain waits on
     float t_at = 0.f, t_tcr = 0.f, t_tci = 0.f;
     bool t_have_at = false;
-    auto tstage1a = [&]() -> int {
+    auto tstage1a = [&]() __attribute__((always_inline)) -> int {
         const float tcr = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(((const float *)CT)[OC_TC])));
         const float tci = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(((const float *)CT)[OC_TC + 1])));
         t_nan = (tcr != tcr) || (tci != tci);                            // fsk.c:878-880
@@ -482,7 +565,7 @@ __global__ __launch_bounds__(1024, WO_WAVES_PER_EU) void wenet_demod_oct_kernel(
         t_nin_next = __builtin_amdgcn_readfirstlane(nin_next);
         return t_nin_next;
     };
-    auto tstage1b = [&]() {
+    auto tstage1b = [&]() __attribute__((always_inline)) {
         t_rxt = 0.f;
         if (!t_nan) {
             if (!t_have_at) t_at = wg_atan2f(t_tci, t_tcr);
@@ -505,20 +588,20 @@ __global__ __launch_bounds__(1024, WO_WAVES_PER_EU) void wenet_demod_oct_kernel(
     };
     // the four outputs frame k+1 parks if frame k's rx_timing is rt (low = floor(rt)): offsets low-1 .. low+2 cover every
     // rx_timing within 0.94 samples of rt
-    auto window_mask = [&](int low) -> unsigned {
+    auto window_mask = [&](int low) __attribute__((always_inline)) -> unsigned {
         unsigned mk = 0;
 #pragma unroll
         for (int j = -1; j <= 2; j++) mk |= 1u << (((low + j) % TS + TS) % TS);
         return mk;
     };
-    // is this frame's timing vector within 34 degrees of the previous frame's?  (36 degrees = one sample of rx_timing at P = 10,
-    // 45 at P = 8; all of this is wave-uniform arithmetic with two degrees to spare for its rounding)
-    auto timing_near_previous = [&]() -> bool {
+    // is this frame's timing vector within 0.94 samples of rx_timing (0.94 * 360 / P degrees: 34 at P = 10) of the previous frame's?
+    // (o_near_cos2 = cos^2 of that angle; all of this is wave-uniform arithmetic with 6 % of a sample to spare for its rounding)
+    auto timing_near_previous = [&]() __attribute__((always_inline)) -> bool {
         const float dot = t_tcr * pv_r + t_tci * pv_i;
         const float n2 = (t_tcr * t_tcr + t_tci * t_tci) * (pv_r * pv_r + pv_i * pv_i);
-        return !t_nan && dot > 0.f && dot * dot > 0.6873f * n2;          // cos^2(34 deg); false for a zero or NaN vector
+        return !t_nan && dot > 0.f && dot * dot > cfg.o_near_cos2 * n2;     // false for a zero or NaN vector
     };
-    auto tstage2 = [&](long long fr) {
+    auto tstage2 = [&](long long fr) __attribute__((always_inline)) {
         if (!t_nan) {
             const float fract = t_fract, omf = 1 - fract;
             const int ln = fresh_lane();
@@ -536,9 +619,23 @@ __global__ __launch_bounds__(1024, WO_WAVES_PER_EU) void wenet_demod_oct_kernel(
                 ti = ti + fract * b.y;
                 tmax[m] = (tr * tr) + (ti * ti);
             }
-            if (lane < WR_NSYM) sdl = sqrtf(tmax[0]) - sqrtf(tmax[1]);   // fsk.c:955-966
+            if (lane < WR_NSYM) {
+#pragma unroll
+                for (int m = 0; m < M; m++) tmax[m] = sqrtf(tmax[m]);
+                if (M == 2) sdl[0] = tmax[0] - tmax[1];                  // fsk.c:955-966
+                else {                                                   // fsk.c:969-980: [0] -> rx_sd[2i], [NSD-1] -> rx_sd[2i+1]
+                    float s1 = -tmax[0], s0 = -tmax[0];
+                    s1 += tmax[1 % M];  s0 += -tmax[1 % M];
+                    s1 += -tmax[2 % M]; s0 += tmax[2 % M];
+                    s1 += tmax[3 % M];  s0 += tmax[3 % M];
+                    sdl[0] = s0; sdl[NSD - 1] = s1;
+                }
+            }
         }
-        if (C.sd_out && lane < WR_NSYM) C.sd_out[fr * WR_NSYM + lane] = sdl;
+        if (C.sd_out && lane < WR_NSYM) {
+            if (NSD == 1) C.sd_out[fr * WR_NSYM + lane] = sdl[0];
+            else *(float2 *)(C.sd_out + (fr * WR_NSYM + lane) * 2) = make_float2(sdl[0], sdl[NSD - 1]);
+        }
         if (C.trace && lane == 0) {
             float *tr = C.trace + fr * WR_TRACE_FLOATS;
 #pragma unroll
@@ -554,7 +651,7 @@ __global__ __launch_bounds__(1024, WO_WAVES_PER_EU) void wenet_demod_oct_kernel(
 
     // ================================ narrow stages (exact mode) ===============================
     // C(j) of the captures in `mask`: lanes 2M c .. 2M c + 2M - 1
-    auto chain = [&](int mask) {
+    auto chain = [&](int mask) __attribute__((always_inline)) {
         const int cc = lane / M;
         if (cc >= G || !((mask >> cc) & 1)) return;
         const int m = lane % M;
@@ -570,10 +667,10 @@ __global__ __launch_bounds__(1024, WO_WAVES_PER_EU) void wenet_demod_oct_kernel(
         v2f d = {d0.x, d0.y};
         const int hsw = nold / H;                                        // 3, 4 or 5: the half symbol that starts with the new samples
         int hb = 0;
-        auto blocks = [&](int upto) {
+        auto blocks = [&](int upto) __attribute__((always_inline)) {
             for (; hb < upto; hb++) { ck[hb] = own; own = nco_steps<H>(own, d); }
         };
-        auto swtch = [&]() {                                             // fsk.c:785-788: normalise, continue with this frame's estimate
+        auto swtch = [&]() __attribute__((always_inline)) {                                             // fsk.c:785-788: normalise, continue with this frame's estimate
             if (hb == hsw) {
                 const float av = sqrtf(own.x * own.x + own.y * own.y);
                 own = (v2f){own.x / av, own.y / av};
@@ -594,7 +691,7 @@ __global__ __launch_bounds__(1024, WO_WAVES_PER_EU) void wenet_demod_oct_kernel(
     };
 
     // ordered timing sums (fsk.c:870-874) of the captures in `mask`: lanes 2c / 2c+1 add the re / im products of capture c
-    auto tsum = [&](int mask) {
+    auto tsum = [&](int mask) __attribute__((always_inline)) {
         typedef float v4f __attribute__((ext_vector_type(4)));
         int sc = lane >> 1;
         const bool mine = sc < G && ((mask >> sc) & 1);
@@ -626,7 +723,7 @@ __global__ __launch_bounds__(1024, WO_WAVES_PER_EU) void wenet_demod_oct_kernel(
         if (mine) ((float *)(smem_all + sc * cfg.o_cap_stride + cfg.o_off_CT))[OC_TC + (lane & 1)] = acc;
     };
 
-    auto alive_mask = [&]() {
+    auto alive_mask = [&]() __attribute__((always_inline)) {
         int mk = 0;
         for (int c = 0; c < G; c++) mk |= (__builtin_amdgcn_readfirstlane(CT0[c * ctw + OC_ALIVE]) ? 1 : 0) << c;
         return mk;
@@ -642,7 +739,7 @@ __global__ __launch_bounds__(1024, WO_WAVES_PER_EU) void wenet_demod_oct_kernel(
     //   D  capture waves: timing estimate and nin(k+1); if nin(k+1) != N the estimator run of frame k+1 is repeated with the true
     //      nin (it reads the untouched spectrum of frame k); frame k+1 becomes the frame in work and is published
     int ran = 0;                                                         // duty wave: captures that demodulated at least one frame
-    auto publish = [&](int nn, bool more, long long seq) {               // inputs of the next frame are final: its chain may start
+    auto publish = [&](int nn, bool more, long long seq) __attribute__((always_inline)) {               // inputs of the next frame are final: its chain may start
         if (lane == 0) {
             CT[OC_NIN] = nn; CT[OC_ALIVE] = more ? 1 : 0;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -650,28 +747,29 @@ __global__ __launch_bounds__(1024, WO_WAVES_PER_EU) void wenet_demod_oct_kernel(
         }
     };
     if (is_cap) {
-        if (alive) { prefetch_est(0); prefetch_slot(0, nin); estimate(nin); commit_estimate(); if (!FAST) prefetch_est(nin); }
+        if (alive) { prefetch_est(0); if (SMALL) prefetch_slot(0, nin); estimate(nin); commit_estimate(); if (!FAST && SMALL) prefetch_est(nin); }
         if (!FAST) publish(nin, alive, 1);
     }
     if (FAST) {
         // no shared stages: every capture wave runs on its own
         while (alive) {
             const long long off1 = off + nin;
-            prefetch_est(off1);
+            if (SMALL) prefetch_est(off1);
             dstage(off, nin, omask, true);
-            t_bins[0] = CT[OC_FBIN]; t_bins[1] = CT[OC_FBIN + 1];
+#pragma unroll
+            for (int m = 0; m < M; m++) t_bins[m] = CT[OC_FBIN + m];
             const int nn = tstage1a();
             tstage1b();
             if (!t_nan && !(((omask >> (t_low >= 0 ? t_low : TS + t_low)) & (omask >> (t_high >= 0 ? t_high : TS + t_high))) & 1))
-                dstage(off, nin, (1u << TS) - 1, false);                 // prediction missed: integrate again, park everything
-            omask = (!t_nan && timing_near_previous()) ? window_mask(t_low) : (1u << TS) - 1;
+                dstage(off, nin, ALLOUT, false);                 // prediction missed: integrate again, park everything
+            omask = (!t_nan && timing_near_previous()) ? window_mask(t_low) : ALLOUT;
             pv_r = t_nan ? 0.f : t_tcr; pv_i = t_nan ? 0.f : t_tci;
             tstage2(frames);
             const bool more = off1 + nn <= C.nsamples && frames + 1 < C.cap_frames;
             nslip += (nn != N) ? 1 : 0;
             off = off1; nin = nn; frames++;
             alive = more;
-            if (alive) { prefetch_slot(off, nin); estimate(nin); commit_estimate(); }
+            if (alive) { if (SMALL) prefetch_slot(off, nin); else prefetch_est(off); estimate(nin); commit_estimate(); }
         }
     } else {
         if (is_chain) __builtin_amdgcn_s_setprio(2);                     // the serial wave wins VALU arbitration against the wide ones
@@ -696,7 +794,9 @@ __global__ __launch_bounds__(1024, WO_WAVES_PER_EU) void wenet_demod_oct_kernel(
                 if (m2) { chain(m2); ran |= m2; }
                 WO_STAMP(1);
             } else if (alive) {
-                estimate_fft(N); prefetch_est(off + nin + N);            // E(k+1) ahead, first half; then the samples of E(k+2), one frame ahead again
+                if (!SMALL) prefetch_est(off + nin);                     // (large geometry: the samples are loaded where they are used)
+                estimate_fft(N);                                         // E(k+1) ahead, first half ...
+                if (SMALL) prefetch_est(off + nin + N);                  // ... then the samples of E(k+2), one frame ahead again
                 if (pp) { pt[4] += (long long)__builtin_readcyclecounter() - t0; }
             }
             lds_barrier();                                               // checkpoints of frame k; every capture's flags are final
@@ -712,7 +812,8 @@ __global__ __launch_bounds__(1024, WO_WAVES_PER_EU) void wenet_demod_oct_kernel(
             lds_barrier();                                               // timing sums
             WO_STAMP(is_chain ? 3 : 2);
             if (is_cap && alive) {
-                t_bins[0] = CT[OC_FBIN]; t_bins[1] = CT[OC_FBIN + 1];
+    #pragma unroll
+            for (int m = 0; m < M; m++) t_bins[m] = CT[OC_FBIN + m];
                 __builtin_amdgcn_s_setprio(1);
                 const int nn = tstage1a();
                 // do the parked outputs cover this frame's resampling points?  Sure if everything was parked or the timing vector is
@@ -720,10 +821,10 @@ __global__ __launch_bounds__(1024, WO_WAVES_PER_EU) void wenet_demod_oct_kernel(
                 // next frame's chains may overwrite the checkpoints
                 bool did_1b = false;
                 const bool near_prev = timing_near_previous();
-                if (omask != (1u << TS) - 1 && !near_prev) {
+                if (omask != ALLOUT && !near_prev) {
                     tstage1b(); did_1b = true;
                     if (!t_nan && !(((omask >> (t_low >= 0 ? t_low : TS + t_low)) & (omask >> (t_high >= 0 ? t_high : TS + t_high))) & 1))
-                        dstage(off, nin, (1u << TS) - 1, false);
+                        dstage(off, nin, ALLOUT, false);
                 }
                 const bool more = off1 + nn <= C.nsamples && frames + 1 < C.cap_frames;
                 if (more) {
@@ -733,11 +834,11 @@ __global__ __launch_bounds__(1024, WO_WAVES_PER_EU) void wenet_demod_oct_kernel(
                 publish(nn, more, kf + 2);                               // -> the duty wave starts the chains of frame k+1 ...
                 __builtin_amdgcn_s_setprio(0);
                 if (!did_1b) tstage1b();
-                omask = (!t_nan && near_prev) ? window_mask(t_low) : (1u << TS) - 1;
+                omask = (!t_nan && near_prev) ? window_mask(t_low) : ALLOUT;
                 pv_r = t_nan ? 0.f : t_tcr; pv_i = t_nan ? 0.f : t_tci;
                 if (pp) { const long long t1 = (long long)__builtin_readcyclecounter(); pt[3] += t1 - t0; }
                 tstage2(frames);                                         // ... while this wave resamples, decides and writes frame k
-                if (more) { prefetch_slot(off1, nn); if (nn != N) prefetch_est(off1 + nn); }
+                if (more && SMALL) { prefetch_slot(off1, nn); if (nn != N) prefetch_est(off1 + nn); }
                 if (pp) { const long long t1 = (long long)__builtin_readcyclecounter(); pt[5] += t1 - t0; }
                 nslip += (nn != N) ? 1 : 0;
                 off = off1; nin = nn; frames++;
@@ -754,7 +855,10 @@ __global__ __launch_bounds__(1024, WO_WAVES_PER_EU) void wenet_demod_oct_kernel(
         if (frames > 0) {
             for (int i = lane; i < NH; i += 64) st_fft[i] = FE2[fecur * NH + i];
             for (int i = lane; i < nstash; i += 64) st_old[i] = cvt(raw16[off - nstash + i]);     // fsk.c:851 (off >= nin > nstash)
-            if (lane < cfg.Nbits) st_sd[lane] = sdl;
+            if (lane < WR_NSYM) {
+#pragma unroll
+                for (int b = 0; b < NSD; b++) st_sd[lane * NSD + b] = sdl[b];
+            }
             if (lane < M) hdr->f_bin[lane] = CT[OC_FBIN + lane];
         }
         if (lane == 0) {

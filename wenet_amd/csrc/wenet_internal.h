@@ -71,6 +71,7 @@ struct WrDemodCfg {
     int o_ok, o_caps, o_cap_stride, o_lds_bytes, o_nhb, o_first_bins;
     int o_off_FB, o_off_TP, o_off_FE, o_off_FW, o_off_CK, o_off_CT;
     int o_off_TW, o_off_HANN, o_off_SRC, o_off_DPHI, o_off_PFT, o_off_BACK;
+    float o_near_cos2;                   // cos^2 of the angle the timing vector may turn between frames while the parked outputs stay valid
     float o_at_hi, o_at_lo;              // atan2f values beyond which norm_rx_timing > 0.25f / < -0.25f (fsk.c:883,900-903)
     // per-channel state block layout (floats from the block start)
     int st_fft_est, st_samp_old, st_sd_last, st_floats;

@@ -173,13 +173,12 @@ struct DemodTables {
     WrDemodCfg oct_cfg(int caps) const {
         WrDemodCfg c = cfg;
         c.o_ok = 0;
-        if (cfg.big || cfg.M != 2 || (cfg.Ts != 8 && cfg.Ts != 10) || cfg.P != cfg.Ts || cfg.Ndft != 256 || cfg.Nsym != WR_NSYM ||
+        const bool small = cfg.M == 2 && (cfg.Ts == 8 || cfg.Ts == 10) && cfg.Ndft == 256;       // Wenet v1 / v2
+        const bool large = cfg.M == 4 && cfg.Ts == 32 && cfg.Ndft == 1024;                        // BASELINE config 4 (4-FSK, Fs 1 843 200)
+        if (cfg.big || !(small || large) || cfg.P != cfg.Ts || cfg.Nsym != WR_NSYM ||
             cfg.N < cfg.Ndft + cfg.Ts / 2 || cfg.N + cfg.Ts / 2 >= 2 * cfg.Ndft || getenv("WENET_RX_NO_OCT") != nullptr)
             return c;
-        if (caps < 1) caps = 1;
-        if (caps > 15) caps = 15;
         const int NH = cfg.Ndft / 2, NIq = (cfg.NI + 3) & ~3, H = cfg.Ts / 2;
-        c.o_caps = caps;
         c.o_nhb = (cfg.L + H - 1) / H;
         int t = 0;
         c.o_off_FB = t;  t = align16(t + cfg.Ndft * 8);
@@ -187,16 +186,29 @@ struct DemodTables {
         c.o_off_FE = t;  t = align16(t + 2 * NH * 4);
         c.o_off_FW = t;  t = align16(t + NH * 4);
         c.o_off_CK = t;  t = align16(t + cfg.M * c.o_nhb * 8);
-        c.o_off_CT = t;  t = align16(t + 16 * 4);
+        c.o_off_CT = t;  t = align16(t + 32 * 4);
         c.o_cap_stride = (t + 127) & ~127;
-        t = caps * c.o_cap_stride;
-        c.o_off_TW = t;   t = align16(t + cfg.Ndft * 8);
-        c.o_off_HANN = t; t = align16(t + cfg.Ndft * 4);
-        c.o_off_SRC = t;  t = align16(t + cfg.Ndft * 4);
-        c.o_off_DPHI = t; t = align16(t + NH * 8);
-        c.o_off_PFT = t;  t = align16(t + cfg.NI * 8);
-        c.o_off_BACK = t; t = align16(t + 3 * NH * 8);
-        c.o_lds_bytes = t;
+        int tab = 0;                                                    // tables behind the capture blocks; the large geometry reads three of them through the caches
+        const int o_tw = tab;   tab = align16(tab + cfg.Ndft * 8);
+        const int o_hann = tab; tab = align16(tab + cfg.Ndft * 4);
+        const int o_dphi = tab; tab = align16(tab + NH * 8);
+        int o_src = 0, o_pft = 0, o_back = 0;
+        if (small) {
+            o_src = tab;  tab = align16(tab + cfg.Ndft * 4);
+            o_pft = tab;  tab = align16(tab + cfg.NI * 8);
+            o_back = tab; tab = align16(tab + 3 * NH * 8);
+        }
+        const int max_caps = (160 * 1024 - tab) / c.o_cap_stride;
+        if (caps < 1) caps = 1;
+        if (caps > 15) caps = 15;
+        if (caps > max_caps) caps = max_caps;
+        if (large && caps > 7) caps = 7;                                // (its kernel is built for workgroups of <= 512 threads: 256 VGPRs)
+        if (caps < 1) return c;
+        c.o_caps = caps;
+        const int base = caps * c.o_cap_stride;
+        c.o_off_TW = base + o_tw; c.o_off_HANN = base + o_hann; c.o_off_DPHI = base + o_dphi;
+        c.o_off_SRC = base + o_src; c.o_off_PFT = base + o_pft; c.o_off_BACK = base + o_back;
+        c.o_lds_bytes = base + tab;
         c.o_first_bins = 0;
         while (c.o_first_bins < NH && host_binf[c.o_first_bins] < 1.0f) c.o_first_bins++;                 // fsk.c:750 "f_est[0] < 1"
         {   // largest float a with (float)((double)a / 2 pi) <= 0.25f, smallest with >= -0.25f (the map is monotone)
@@ -210,7 +222,11 @@ struct DemodTables {
             while (nrt(a) < -0.25f) a = nextafterf(a, INFINITY);
             c.o_at_lo = a;
         }
-        c.o_ok = t <= 160 * 1024 ? 1 : 0;
+        {   // a timing vector within 0.94 samples of rx_timing (0.94 * 2 pi / P) of the previous one: cos^2 of that angle
+            const double ang = 0.94 * 2 * M_PI / cfg.P;
+            c.o_near_cos2 = (float)(cos(ang) * cos(ang));
+        }
+        c.o_ok = 1;
         return c;
     }
 
@@ -1066,7 +1082,10 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const lon
         // measured (tools/gpu_batch_sweep.py, 2 s captures): up to 6 captures per CU the pipelined kernels win (20.8 ms per 3 captures
         // per CU); 6..12 per CU: three workgroups of four captures per CU (44 ms for 2048); beyond: two of seven (55 ms for 3584)
         if (force) oct_caps = atoi(force) > 0 ? atoi(force) : 7;
-        else if (!rx->want_trace && nchan >= 6 * wenet_rx_device_info(1)) oct_caps = nchan > 12 * wenet_rx_device_info(1) ? 7 : 4;
+        else if (!rx->want_trace && c.M == 2 && nchan >= 6 * wenet_rx_device_info(1)) oct_caps = nchan > 12 * wenet_rx_device_info(1) ? 7 : 4;
+        // the 4-FSK / Ts 32 geometry (BASELINE config 4): 30 KB of LDS per capture = four captures per CU as two workgroups of two;
+        // from two captures per CU on it beats the sequential kernel's one capture per CU (34 vs 11.5 Gsamples/s at 1024 captures)
+        else if (!rx->want_trace && c.M == 4 && nchan >= 2 * wenet_rx_device_info(1)) oct_caps = 2;
     }
     WrDemodCfg oct_cfg;
     bool use_oct = false;
