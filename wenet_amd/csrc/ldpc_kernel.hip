@@ -112,7 +112,8 @@ __device__ __forceinline__ float phi0_dev(float xf, const uint4 *lut) {
     const int b = __float_as_int(xf);                           // (thresholds and keys carry the 2^16 of x = (int)(xf*65536), phi0.c:10,14)
     // clamp the raw key (one v_med3_i32) and fold the bias into the table base: four instructions to the LDS read instead of six
     const int key = min(max(b >> 18, WR_PHI0_KEY_BIAS), WR_PHI0_KEY_BIAS + WR_PHI0_LUT_ENTRIES - 1);
-    const uint4 e = *(const uint4 *)((const char *)lut + (key - WR_PHI0_KEY_BIAS) * 16);
+    typedef unsigned v3u __attribute__((ext_vector_type(3)));          // 12 of the entry's 16 bytes: a 96-bit LDS read (6 clocks per wavefront instead of 8)
+    const v3u e = *(const v3u *)((const char *)lut + (key - WR_PHI0_KEY_BIAS) * 16);
     return __uint_as_float((b >= (int)e.x) ? e.z : e.y);
 }
 
@@ -269,33 +270,61 @@ __global__ __launch_bounds__(256) void wenet_crc_kernel(WrDecodeArgs A) {
     }
 }
 
-__global__ __launch_bounds__(WR_DEC_THREADS) void wenet_decode_kernel(WrDecodeArgs A) {
-    const int pk = blockIdx.x, ch = blockIdx.y;
+// Persistent workgroups: the grid is sized to the device (four workgroups per CU); each workgroup loads the phi0 table and its
+// threads' variable placement once and then takes packet slots from a shared counter until none is left -- the per-packet set-up
+// (10 KB of table through L2, 18 edge addresses per thread) was a third of a packet's time at ~6 iterations.  (Round 1 tried a FIXED
+// four packets per workgroup: slower, because iteration counts differ; the counter has no such imbalance.)
+__global__ __launch_bounds__(WR_DEC_THREADS, 8) void wenet_decode_kernel(WrDecodeArgs A) {      // (8 waves per SIMD = four workgroups per CU: 64 VGPRs)
     const int tid = threadIdx.x;
-    const int slot = ch * A.max_pk + pk;
-
-    // ---- how many packets does this channel have?  (uniform early exit) ----------------------
-    long long npk;
-    const float *sd_stream = nullptr;
-    long long start = 0;
-    if (A.input_kind == WR_DEC_IN_STREAM) {
-        const WrDeframeChan D = A.dchans[ch];
-        npk = D.state->npackets;
-        if (pk >= npk) return;
-        sd_stream = D.sd;
-        start = D.starts[pk];
-    } else {
-        npk = A.npk_direct[ch];
-        if (pk >= npk) return;
-    }
-    const int n = (A.input_kind == WR_DEC_IN_SD64) ? A.n_sd : WR_NCODE;
-
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // float msg[14*516] | uint4 lut[642] | bit/byte staging
     float    *msg  = (float *)smem;
     uint4    *lut  = (uint4 *)(smem + WR_DEC_OFF_LUT);
     uint8_t  *bitbuf = (uint8_t *)(smem + WR_DEC_OFF_BITS);                        // [2580] decoded bits, then [258] bytes
     int      *red = (int *)(smem + WR_DEC_OFF_RED);                                // [parity of the iteration][0: satisfied checks, 1: any data bit set]
+    int      *next_slot = red + 4;                                                 // the packet slot this workgroup works on
+
+    // ---- once per workgroup: phi0 LUT into LDS; this thread's variables (LdpcTables::place_variables: the data variables are dealt
+    //      to the positions tid + 512 t so that the variable pass loads the LDS banks evenly) and their edge addresses into registers.
+    //      Positions t = 0..3 hold data bits (degree 3) for every thread; t = 4 straddles the data/parity boundary, t = 5 is parity or nothing.
+    for (int i = tid; i < WR_PHI0_LUT_ENTRIES; i += WR_DEC_THREADS) lut[i] = A.phi0_lut[i];
+    int ea[WR_VARS_PER_THREAD][3], deg[WR_VARS_PER_THREAD];
+    // (the variable numbers themselves are needed twice per packet only -- LLR in, bit out -- and are re-read there: six registers
+    //  held across the iterations would cost the fourth workgroup per CU)
+    auto var_at = [&](int t) -> int { const int p = tid + t * WR_DEC_THREADS; return (p < WR_NCODE) ? (int)A.vpos[p] : WR_NCODE; };
+#pragma unroll
+    for (int t = 0; t < WR_VARS_PER_THREAD; t++) {
+        const int v = var_at(t);
+        deg[t] = (v < WR_NCODE) ? var_degree(v) : 0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) ea[t][k] = (k < deg[t]) ? var_edge(v, k, A.vedge) : 0;
+    }
+    const bool data4 = var_at(4) < WR_NDATA;                                      // position t = 4 holds a data bit (positions t < 4 always do, t = 5 never)
+    const long long nslots = (long long)A.nchan * A.max_pk;
+
+  for (;;) {
+    __syncthreads();                                                               // (the previous packet's staging is read out; LUT is in place)
+    if (tid == 0) *next_slot = (int)atomicAdd(A.work, 1u);
+    __syncthreads();
+    const long long slot = *next_slot;
+    if (slot >= nslots) break;
+    const int ch = (int)(slot / A.max_pk), pk = (int)(slot - (long long)ch * A.max_pk);
+
+    // ---- does this slot hold a packet?  (uniform) ----------------------------------------------
+    long long npk;
+    const float *sd_stream = nullptr;
+    long long start = 0;
+    if (A.input_kind == WR_DEC_IN_STREAM) {
+        const WrDeframeChan D = A.dchans[ch];
+        npk = D.state->npackets;
+        if (pk >= npk) continue;
+        sd_stream = D.sd;
+        start = D.starts[pk];
+    } else {
+        npk = A.npk_direct[ch];
+        if (pk >= npk) continue;
+    }
+    const int n = (A.input_kind == WR_DEC_IN_SD64) ? A.n_sd : WR_NCODE;
 
     float llr[WR_VARS_PER_THREAD];
     WrPacketOut *out = A.out ? &A.out[slot] : nullptr;
@@ -305,31 +334,19 @@ __global__ __launch_bounds__(WR_DEC_THREADS) void wenet_decode_kernel(WrDecodeAr
         const double estEsN0 = A.esn0[slot];
 #pragma unroll
         for (int t = 0; t < WR_VARS_PER_THREAD; t++) {
-            const int i = tid + t * WR_DEC_THREADS;
+            const int i = (n == WR_NCODE) ? var_at(t) : tid + t * WR_DEC_THREADS;   // (sd_to_llr API with another n: plain order, no decoding follows)
             llr[t] = (i < n) ? wx_llr(estEsN0, packet_symbol(A, sd_stream, start, slot, n, i)) : 0.f;
             if (A.llr_out && i < n) A.llr_out[(long long)slot * n + i] = llr[t];
         }
     } else {
 #pragma unroll
         for (int t = 0; t < WR_VARS_PER_THREAD; t++) {
-            const int i = tid + t * WR_DEC_THREADS;
+            const int i = var_at(t);
             llr[t] = (i < WR_NCODE) ? A.llr_in[(long long)slot * WR_NCODE + i] : 0.f;
         }
     }
-    if (A.stop_after_llr) return;
+    if (A.stop_after_llr) continue;
 
-    // ---- tables: phi0 LUT into LDS; this thread's edge addresses into registers (the same six variables at
-    //      most, every iteration).  Variables tid + 512 t, t = 0..3, are data bits of degree 3 for every thread;
-    //      t = 4 straddles the data/parity boundary at 2064 and t = 5 is parity (degree 2, the last one 1) or nothing.
-    for (int i = tid; i < WR_PHI0_LUT_ENTRIES; i += WR_DEC_THREADS) lut[i] = A.phi0_lut[i];
-    int ea[WR_VARS_PER_THREAD][3], deg[WR_VARS_PER_THREAD];
-#pragma unroll
-    for (int t = 0; t < WR_VARS_PER_THREAD; t++) {
-        const int v = tid + t * WR_DEC_THREADS;
-        deg[t] = (v < WR_NCODE) ? var_degree(v) : 0;
-#pragma unroll
-        for (int k = 0; k < 3; k++) ea[t][k] = (k < deg[t]) ? var_edge(v, k, A.vedge) : 0;
-    }
     if (tid == 0) msg[13 * WR_NPAR] = 0.f;                      // check 0 has 13 edges: its 14th slot stays a neutral +0
     __syncthreads();
 
@@ -419,7 +436,7 @@ __global__ __launch_bounds__(WR_DEC_THREADS) void wenet_decode_kernel(WrDecodeAr
                 }
                 const int b = Qi < 0.f;
                 bits |= (unsigned)b << t;
-                if (b && (t < WR_VARS_ALLDATA || tid + t * WR_DEC_THREADS < WR_NDATA)) any_data = 1;
+                if (b && (t < WR_VARS_ALLDATA || (t == 4 && data4))) any_data = 1;
 #pragma unroll
                 for (int k = 0; k < 3; k++) {
                     if (t < WR_VARS_ALLDATA || k < deg[t]) {
@@ -443,7 +460,7 @@ __global__ __launch_bounds__(WR_DEC_THREADS) void wenet_decode_kernel(WrDecodeAr
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < WR_VARS_PER_THREAD; t++) {
-        const int v = tid + t * WR_DEC_THREADS;
+        const int v = var_at(t);
         if (v < WR_NCODE) {
             bitbuf[v] = (uint8_t)((bits >> t) & 1u);
             if (A.bits_out) A.bits_out[(long long)slot * WR_NCODE + v] = (uint8_t)((bits >> t) & 1u);
@@ -463,6 +480,7 @@ __global__ __launch_bounds__(WR_DEC_THREADS) void wenet_decode_kernel(WrDecodeAr
         out->pcc = pcc;
         out->pcc_written = pcc_written;
     }
+  }
 }
 
 
@@ -485,7 +503,13 @@ extern "C" hipError_t wr_launch_decode(const WrDecodeArgs *args, hipStream_t str
     }
     const int lds = WR_DEC_LDS_BYTES;
     wr_attr_ok(hipFuncSetAttribute((const void *)wenet_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipLaunchKernelGGL(wenet_decode_kernel, dim3(args->max_pk, args->nchan), dim3(WR_DEC_THREADS), lds, stream, *args);
+    static int ncu = 0;
+    if (ncu == 0) { hipDeviceProp_t p; int dev = 0; (void)hipGetDevice(&dev); ncu = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }
+    const long long want = (long long)4 * ncu;                       // four workgroups (32 wavefronts) per CU fill it; they loop over the packet slots
+    const unsigned grid = (unsigned)(slots < want ? slots : want);
+    hipError_t e = hipMemsetAsync(args->work, 0, sizeof(unsigned), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(wenet_decode_kernel, dim3(grid), dim3(WR_DEC_THREADS), lds, stream, *args);
     if (!args->stop_after_llr && args->out)
         hipLaunchKernelGGL(wenet_crc_kernel, dim3(blocks), dim3(256), 0, stream, *args);
     return hipGetLastError();

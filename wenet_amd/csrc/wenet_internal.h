@@ -174,6 +174,8 @@ struct WrDecodeArgs {
     unsigned    *census;                // optional [nchan][WR_CENSUS_CLASSES]: CRC-valid packets by type byte (wenet_crc_kernel)
     // tables
     const uint16_t *vedge;              // [2064*3] edge address (slot*516+check) per data bit, socket order
+    const uint16_t *vpos;               // [2580] variable handled at position tid + 512 t of the variable pass (LdpcTables::place_variables)
+    unsigned       *work;               // persistent decode workgroups: next packet slot to take (zeroed before the launch)
     const uint4    *phi0_lut;           // [90]
     const uint8_t  *scramble;           // [125]
 };
@@ -215,4 +217,4 @@ static const float WR_PHI0_LT1_V[27] = {  // value when x > T[k] (and x <= T[k-1
 #define WR_DEC_OFF_LUT  (14 * WR_NPAR * 4)
 #define WR_DEC_OFF_BITS 0                                                   // bit / byte staging overlays the messages (dead after the last iteration)
 #define WR_DEC_OFF_RED  (WR_DEC_OFF_LUT + WR_PHI0_LUT_ENTRIES * 16)                 // [2][2] reduction cells: satisfied checks / any data bit set, by iteration parity
-#define WR_DEC_LDS_BYTES (WR_DEC_OFF_RED + 16)
+#define WR_DEC_LDS_BYTES (WR_DEC_OFF_RED + 32)                                       // + the workgroup's current packet slot

@@ -461,6 +461,8 @@ float phi0_x86(float xf) {                                              // phi0.
 struct LdpcTables {
     DevBuf blob;
     const uint16_t *d_vedge = nullptr;
+    const uint16_t *d_vpos = nullptr;
+    int place_cost0 = 0, place_cost = 0;                // bank overload of the variable pass before / after the placement search
     const uint4 *d_lut = nullptr;
     const uint8_t *d_scramble = nullptr;
     bool ok = false;
@@ -477,6 +479,49 @@ struct LdpcTables {
                 vedge[v * 3 + deg[v]++] = (uint16_t)(j * WR_NPAR + c);   // slot-major edge address
             }
         for (int v = 0; v < WR_NDATA; v++) if (deg[v] != 3) { fprintf(stderr, "libwenet_rx: code table: column weight != 3\n"); return false; }
+        // Which variable does thread tid handle as its t-th (position tid + 512 t)?  The variable pass reads and writes one message per
+        // lane and instruction at msg[edge address]; with the variables in natural order the 64 addresses of a wavefront hit the 32 LDS
+        // banks unevenly (the fullest bank serves ~5 of them where 2 would do).  The graph is static, so the data variables are dealt to
+        // the positions once, here, such that every (wavefront, t, socket) instruction loads each bank as evenly as a local search
+        // finds (deterministic: fixed seed).  Parity variables keep their places: their edge addresses are consecutive already.
+        std::vector<uint16_t> vpos(WR_NCODE);
+        for (int v = 0; v < WR_NCODE; v++) vpos[v] = (uint16_t)v;
+        {
+            const int NG = (WR_NDATA + 63) / 64;                        // instruction groups of 64 positions (the last one has 16)
+            std::vector<int> cnt((size_t)NG * 3 * 32, 0);
+            auto bank = [&](int v, int k) { return vedge[v * 3 + k] & 31; };
+            auto over = [](int c) { return c > 2 ? (c - 2) * (c - 2) : 0; };
+            long cost = 0;
+            for (int p = 0; p < WR_NDATA; p++) for (int k = 0; k < 3; k++) cnt[((size_t)(p / 64) * 3 + k) * 32 + bank(vpos[p], k)]++;
+            for (size_t i = 0; i < cnt.size(); i++) cost += over(cnt[i]);
+            place_cost0 = (int)cost;
+            uint64_t rng = 0x9E3779B97F4A7C15ull;
+            auto next = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return rng; };
+            for (long it = 0; it < 3000000 && cost > 0; it++) {
+                const int p = (int)(next() % WR_NDATA), q = (int)(next() % WR_NDATA);
+                const int gp = p / 64, gq = q / 64;
+                if (gp == gq) continue;
+                const int vp = vpos[p], vq = vpos[q];
+                long d = 0;
+                for (int k = 0; k < 3; k++) {
+                    const int bp = bank(vp, k), bq = bank(vq, k);
+                    if (bp == bq) continue;
+                    int *cp = &cnt[((size_t)gp * 3 + k) * 32], *cq = &cnt[((size_t)gq * 3 + k) * 32];
+                    d += over(cp[bp] - 1) - over(cp[bp]) + over(cp[bq] + 1) - over(cp[bq]);
+                    d += over(cq[bq] - 1) - over(cq[bq]) + over(cq[bp] + 1) - over(cq[bp]);
+                }
+                if (d > 0) continue;
+                for (int k = 0; k < 3; k++) {
+                    const int bp = bank(vp, k), bq = bank(vq, k);
+                    cnt[((size_t)gp * 3 + k) * 32 + bp]--; cnt[((size_t)gp * 3 + k) * 32 + bq]++;
+                    cnt[((size_t)gq * 3 + k) * 32 + bq]--; cnt[((size_t)gq * 3 + k) * 32 + bp]++;
+                }
+                vpos[p] = (uint16_t)vq; vpos[q] = (uint16_t)vp;
+                cost += d;
+            }
+            place_cost = (int)cost;
+            if (getenv("WENET_RX_NO_PLACE")) for (int v = 0; v < WR_NCODE; v++) vpos[v] = (uint16_t)v;     // development: natural order
+        }
         // phi0 LUT keyed by the float bits of y (see wenet_internal.h)
         std::vector<uint32_t> lut(WR_PHI0_LUT_ENTRIES * 4, 0);
         {
@@ -513,12 +558,14 @@ struct LdpcTables {
                 fprintf(stderr, "libwenet_rx: phi0 table self-check failed at xf=%g\n", (double)xf);
                 return false;
             }
-        size_t a_v = 0, a_l = (WR_NDATA * 3 * 2 + 255) & ~255, a_s = a_l + ((WR_PHI0_LUT_ENTRIES * 16 + 255) & ~255);
-        if (!blob.reserve(a_s + 256)) return false;
+        size_t a_v = 0, a_l = (WR_NDATA * 3 * 2 + 255) & ~255, a_s = a_l + ((WR_PHI0_LUT_ENTRIES * 16 + 255) & ~255), a_p = a_s + 256;
+        if (!blob.reserve(a_p + WR_NCODE * 2 + 256)) return false;
         char *base = blob.as<char>();
         WR_CHECK(hipMemcpy(base + a_v, vedge.data(), WR_NDATA * 3 * 2, hipMemcpyHostToDevice), false);
         WR_CHECK(hipMemcpy(base + a_l, lut.data(), WR_PHI0_LUT_ENTRIES * 16, hipMemcpyHostToDevice), false);
         WR_CHECK(hipMemcpy(base + a_s, kScramble, 125, hipMemcpyHostToDevice), false);
+        WR_CHECK(hipMemcpy(base + a_p, vpos.data(), WR_NCODE * 2, hipMemcpyHostToDevice), false);
+        d_vpos = (const uint16_t *)(base + a_p);
         d_vedge = (const uint16_t *)(base + a_v);
         d_lut = (const uint4 *)(base + a_l);
         d_scramble = (const uint8_t *)(base + a_s);
@@ -541,7 +588,7 @@ LdpcTables *ldpc_tables() {
 }
 
 void fill_decode_tables(WrDecodeArgs &a, const LdpcTables *t) {
-    a.vedge = t->d_vedge; a.phi0_lut = t->d_lut; a.scramble = t->d_scramble;
+    a.vedge = t->d_vedge; a.vpos = t->d_vpos; a.phi0_lut = t->d_lut; a.scramble = t->d_scramble;
 }
 
 }  // namespace
@@ -783,6 +830,7 @@ int run_dense(int kind, const void *in, int npk, int n, int mode, int max_iter, 
     a.llr_out = llr_host ? g_dec.d_llr.as<float>() : nullptr;
     a.bits_out = bits_host ? g_dec.d_bits.as<uint8_t>() : nullptr;
     a.esn0 = g_dec.d_esn0.as<double>();
+    a.work = (unsigned *)(g_dec.d_esn0.as<double>() + npk);            // (DevBuf::reserve leaves >= 256 bytes of slack)
     fill_decode_tables(a, t);
     WR_CHECK(wr_launch_decode(&a, 0), -4);
     WR_CHECK(hipDeviceSynchronize(), -4);
@@ -874,6 +922,7 @@ extern "C" long wenet_deframer_push(wenet_deframer *d, const float *symbols, lon
     a.dchans = d->d_chan.as<WrDeframeChan>();
     a.out = d->d_out.as<WrPacketOut>();
     a.esn0 = d->d_esn0.as<double>();
+    a.work = (unsigned *)(d->d_esn0.as<double>() + max_pk);
     fill_decode_tables(a, t);
     WR_CHECK(wr_launch_decode(&a, 0), -4);
     WR_CHECK(hipMemcpy(&st, d->d_state.p, sizeof(st), hipMemcpyDeviceToHost), -3);   // synchronises
@@ -1005,7 +1054,7 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const lon
     if (!rx->d_states.reserve(stb * nchan) || !rx->d_chans.reserve(sizeof(WrChan) * nchan) ||
         !rx->d_dchans.reserve(sizeof(WrDeframeChan) * nchan) || !rx->d_dstates.reserve(sizeof(WrDeframeState) * nchan) ||
         !rx->d_sd.reserve((size_t)rx->sd_off[nchan] * 4) || !rx->d_starts.reserve((size_t)nchan * max_pk * 8) ||
-        !rx->d_out.reserve((size_t)nchan * max_pk * sizeof(WrPacketOut)) || !rx->d_esn0.reserve((size_t)nchan * max_pk * 8) ||
+        !rx->d_out.reserve((size_t)nchan * max_pk * sizeof(WrPacketOut)) || !rx->d_esn0.reserve((size_t)nchan * max_pk * 8 + 4096) ||
         !rx->d_census.reserve((size_t)nchan * WR_CENSUS_CLASSES * 4))
         return -2;
     if (rx->want_trace && !rx->d_trace.reserve((size_t)(rx->sd_off[nchan] / c.Nbits) * WR_TRACE_FLOATS * 4)) return -2;
@@ -1125,6 +1174,7 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const lon
         ak.dchans = a.dchans + lo;
         ak.out = a.out + (size_t)lo * max_pk;
         ak.esn0 = a.esn0 + (size_t)lo * max_pk;
+        ak.work = (unsigned *)(a.esn0 + (size_t)nchan * max_pk) + k;    // one counter per sub-batch, behind the array
         ak.census = a.census + (size_t)lo * WR_CENSUS_CLASSES;
         if (a.llr_out) ak.llr_out = a.llr_out + (size_t)lo * max_pk * WR_NCODE;
         WR_CHECK(hipEventRecord(e.ev[0], stream), -4);
