@@ -49,7 +49,19 @@ enum { OC_NIN = 0, OC_ALIVE = 1,
        OC_SEQ = 2 /* frames whose nin, bins and alive flag are published: the duty wave starts a frame's chains on it */,
        OC_TC = 4 /* float re, im: timing sum */,
        OC_FBIN = 8 /* [4] tone bins of this frame */, OC_FBINP = 12 /* [4] previous frame's, first-run rule applied (fsk.c:750-753) */,
-       OC_FBINN = 16 /* [4] next frame's (estimated ahead, see the frame loop) */, OC_INTS = 32 };
+       OC_FBINN = 16 /* [4] next frame's (estimated ahead, see the frame loop) */,
+       // chain request of the run-ahead schedule (capture wave -> duty wave, valid once OC_SEQ says so)
+       OC_REQ = 3 /* OC_REQ_* */, OC_CNIN = 6 /* nin of the frame to chain */, OC_CREG = 7 /* checkpoint region to fill */,
+       OC_FLAGS = 16 /* capture -> duty wave.  bit 0: if nin stays N the capture certainly has another frame; bit 1: every integrator output of
+                        the frame in work is parked; bit 2: the frame in work is mixed in the coming phase A (its timing sum will be a real one) */,
+       OC_PV = 17 /* float re, im: the previous frame's timing vector */,
+       OC_ORD = 19 /* duty wave -> capture: the timing estimate of the frame (fsk.c:876-907), packed: bit 0 valid, bit 1 the next chain is started
+                      already (nin stays N, nothing to check), bit 2 timing vector near the previous one, bits 4-5 nin code (0: N - Ts/2, 1: N,
+                      2: N + Ts/2), bits 8-15 low_sample + 64, bits 16-23 high_sample + 64 */,
+       OC_O_NRT = 28 /* float norm_rx_timing */, OC_O_FRACT = 29 /* float fract */, OC_O_RXT = 30 /* float rx_timing */,
+       OC_CBC = 20 /* [4] its tone bins */, OC_CBP = 24 /* [4] the bins its old part turns with (first-run rule applied) */, OC_INTS = 32 };
+enum { OC_REQ_SPEC = 1 /* the frame after the one in work, assuming nin = N */, OC_REQ_TRUE = 2 /* the frame in work again, from the state before its last chain */,
+       OC_REQ_DEAD = 3 /* capture finished: the last (speculative) chain never happened */ };
 
 typedef __attribute__((address_space(3))) float oct_lds_f32;
 
@@ -85,6 +97,22 @@ __device__ __forceinline__ v2f nco_steps(v2f phi, v2f d) {           // N steps 
     return phi;
 }
 
+// the same N steps with the real and imaginary part of the phasor in neighbouring lanes (nco_step_split, demod_common.h): plain
+// instructions -- half the SIMD time of the packed form, which matters where other wavefronts have work for the SIMD meanwhile
+template <int N>
+__device__ __forceinline__ float nco_steps_split(float own, float k1, float k2) {
+    float t1, t2;
+#define WO_NCO1 "v_mul_f32 %1, %0, %3\n\ts_nop 0\n\tv_mul_f32_dpp %2, %0, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_add_f32 %0, %1, %2\n\t"
+    static_assert(N == 4 || N == 5 || N == 16, "half a symbol of Ts 8, 10 or 32");
+    if (N == 5) asm(WO_NCO1 WO_NCO1 WO_NCO1 WO_NCO1 WO_NCO1 : "+v"(own), "=&v"(t1), "=&v"(t2) : "v"(k1), "v"(k2));
+    else {
+#pragma unroll
+        for (int k = 0; k < N / 4; k++) asm(WO_NCO1 WO_NCO1 WO_NCO1 WO_NCO1 : "+v"(own), "=&v"(t1), "=&v"(t2) : "v"(k1), "v"(k2));
+    }
+#undef WO_NCO1
+    return own;
+}
+
 }  // namespace
 
 // Geometries: (M 2, TS 8 | 10, NDFT 256) = Wenet v1 / v2; (M 4, TS 32, NDFT 1024) = BASELINE config 4 (4-FSK, Fs 1 843 200).  The small ones keep every
@@ -97,6 +125,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
     static_assert(NDFT == 256 || NDFT == 1024, "a power of four: radix-4 stages only");
     constexpr int H = TS / 2;                                            // checkpoint spacing = the unit of a timing slip
     constexpr bool SMALL = (NDFT == 256);                                // all tables in LDS, samples fetched a frame ahead
+    constexpr bool AHEAD = SMALL && !FAST;                               // the run-ahead schedule of the frame loop (see there)
     constexpr unsigned ALLOUT = TS == 32 ? 0xffffffffu : (1u << TS) - 1u;
     constexpr int NSD = M == 2 ? 1 : 2;                                  // soft decisions per symbol (fsk.c:955-980)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -114,6 +143,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
     float2 *FB = (float2 *)(smem + cfg.o_off_FB);                        // [Ndft] estimator FFT buffer
     float  *TPf = (float *)(smem + cfg.o_off_TP);                        // the frame's timing products: a row of re, a row of im
     float  *FE2 = (float *)(smem + cfg.o_off_FE);                        // [2][Ndft/2] smoothed spectrum after this frame's estimator run | after the next one's
+                                                                         // (run-ahead schedule: a ring of three, frame f's in slot f % 3)
     float  *FW = (float *)(smem + cfg.o_off_FW);                         // [Ndft/2]
     float2 *CK = (float2 *)(smem + cfg.o_off_CK);                        // [M][o_nhb] phasor at the start of every half symbol
     int    *CT = (int *)(smem + cfg.o_off_CT);
@@ -121,8 +151,8 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
     const float  *hann_t = (const float *)(smem_all + cfg.o_off_HANN);
     const float2 *dphi_t = (const float2 *)(smem_all + cfg.o_off_DPHI);
     const int    *src_t = SMALL ? (const int *)(smem_all + cfg.o_off_SRC) : cfg.fft_src;
-    const float2 *pft_t = SMALL ? (const float2 *)(smem_all + cfg.o_off_PFT) : cfg.phi_ft;
-    const float2 *back_t = SMALL ? (const float2 *)(smem_all + cfg.o_off_BACK) : cfg.backoff_tab;
+    const float2 *pft_t = cfg.phi_ft;                                    // (read through the caches: one coalesced pass per frame)
+    const float2 *back_t = cfg.backoff_tab;                              // (one entry per chain)
     const int ctw = cfg.o_cap_stride / 4;
     const int *CT0 = (const int *)(smem_all + cfg.o_off_CT);
 
@@ -145,14 +175,13 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
         float2 *tw_w = (float2 *)(smem_all + cfg.o_off_TW); float *hann_w = (float *)(smem_all + cfg.o_off_HANN);
         float2 *dphi_w = (float2 *)(smem_all + cfg.o_off_DPHI);
         const int nt = blockDim.x;
-        for (int i = tid; i < Ndft; i += nt) { tw_w[i] = cfg.tw[i]; hann_w[i] = cfg.hann[i]; }
+        for (int i = tid; i < Ndft; i += nt) { if (i < cfg.o_ntw) tw_w[i] = cfg.tw[i]; hann_w[i] = cfg.hann[i]; }
         for (int i = tid; i < NH; i += nt) dphi_w[i] = cfg.dphi_tab[i];
         if (SMALL) {
-            int *src_w = (int *)(smem_all + cfg.o_off_SRC); float2 *pft_w = (float2 *)(smem_all + cfg.o_off_PFT);
+            int *src_w = (int *)(smem_all + cfg.o_off_SRC);
             float2 *back_w = (float2 *)(smem_all + cfg.o_off_BACK);
             for (int i = tid; i < Ndft; i += nt) src_w[i] = cfg.fft_src[i];
-            for (int i = tid; i < NI; i += nt) pft_w[i] = cfg.phi_ft[i];
-            for (int i = tid; i < 3 * NH; i += nt) back_w[i] = cfg.backoff_tab[i];
+            for (int i = tid; i < NH; i += nt) back_w[i] = cfg.backoff_tab[NH + i];             // (the nin = N row)
         }
     }
     int nin = N;
@@ -164,7 +193,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
     int nslip = 0, nuncertain = 0;
     bool alive = false;
     if (is_cap) {
-        for (int i = lane; i < NH; i += 64) FE2[i] = present ? st_fft[i] : 0.f;
+        for (int i = lane; i < NH; i += 64) FE2[(AHEAD ? 2 * NH : 0) + i] = present ? st_fft[i] : 0.f;   // (run-ahead: the frame before the launch's first = slot -1 % 3)
         if (present) {
             if (lane < WR_NSYM) {
 #pragma unroll
@@ -180,7 +209,16 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
     // duty wave: lane M c + m carries phi_c[m] of capture c, in registers, across the frames.  (Latency, not SIMD time, is what the
     // chain costs here -- the capture waves wait for it -- so it runs in the packed form: three dependent instructions per step.)
     v2f own = {1.f, 0.f};
-    if (is_chain) {
+    float own_s = 0.f;                                                   // run-ahead schedule: lane 2 (M c + m) + part carries one component (nco_steps_split)
+    if (is_chain && AHEAD) {
+        const int q = lane >> 1, cc = q / M, m = q % M;
+        const int chc = blockIdx.x * G + cc;
+        own_s = (lane & 1) ? 0.f : 1.f;
+        if (cc < G && chc < nchan) {
+            const WrChanHdr *h = (const WrChanHdr *)chans[chc].state;
+            own_s = (lane & 1) ? h->phi_c[m].y : h->phi_c[m].x;
+        }
+    } else if (is_chain) {
         const int cc = lane / M, m = lane % M;
         const int chc = blockIdx.x * G + cc;
         if (cc < G && chc < nchan) {
@@ -331,9 +369,9 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
             wave_sync();
         }
     };
-    auto estimate_pick = [&]() __attribute__((always_inline)) {
-        const float *FEin = FE2 + fecur * NH;
-        float *FEout = FE2 + (fecur ^ 1) * NH;
+    auto estimate_pick_to = [&](int slot_in, int slot_out, int *bins_out) __attribute__((always_inline)) {
+        const float *FEin = FE2 + slot_in * NH;
+        float *FEout = FE2 + slot_out * NH;
         const int ln = fresh_lane();
         for (int i = ln; i < NH; i += 64) {                            // fsk.c:612-628
             const float2 v = FB[i];
@@ -374,9 +412,15 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
             for (int b = a; b > 0; b--)
                 if (fbin[b - 1] > fbin[b]) { const int t = fbin[b]; fbin[b] = fbin[b - 1]; fbin[b - 1] = t; }
         }
+#pragma unroll
+        for (int m = 0; m < M; m++) bins_out[m] = fbin[m];
+    };
+    auto estimate_pick = [&]() __attribute__((always_inline)) {
+        int fb[M];
+        estimate_pick_to(fecur, fecur ^ 1, fb);
         if (lane == 0) {
 #pragma unroll
-            for (int m = 0; m < M; m++) CT[OC_FBINN + m] = fbin[m];
+            for (int m = 0; m < M; m++) CT[OC_FBINN + m] = fb[m];
         }
         wave_sync();
     };
@@ -404,6 +448,9 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
     // breaks the prediction is integrated a second time with the full mask before the next frame's chains overwrite the checkpoints.
     // (Keeping the four in registers instead was tried: 16 more live VGPRs spill, +18 % frame time.)
     float2 *Fscr = (float2 *)C.big;
+    constexpr int FSN = M * TS * 64;                                     // parked values per frame; the run-ahead schedule alternates between two such blocks
+    int fpar = 0;                                                        // ... the one the mix / integrate stage fills next
+    int ckpar = 0;                                                       // run-ahead schedule: checkpoint region of the frame in work
     unsigned omask = ALLOUT;                                     // outputs parked by the mix / integrate stage of the frame in work
     float pv_r = 0.f, pv_i = 0.f;                                        // the previous frame's timing vector (0, 0: none)
     // D(j): mix, integrate, timing products
@@ -423,7 +470,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
         float *Trow = TPf + TS * ln;
         char *fbase[3];
         if (!FT1_LDS) {
-            fbase[0] = (char *)(Fscr + ln);
+            fbase[0] = (char *)(Fscr + (AHEAD ? fpar * FSN : 0) + ln);
 #pragma unroll
             for (int k = 1; k < 3; k++) { fbase[k] = fbase[k - 1] + 4096; asm volatile("" : "+v"(fbase[k])); }
         }
@@ -437,7 +484,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
                 } else {
                     int l2 = ln;
                     asm volatile("" : "+v"(l2));                         // (address formed here, under the branch: four of them per tone, not 128 hoisted ones)
-                    Fscr[(m * TS + r) * 64 + l2] = make_float2(f.x, f.y);
+                    Fscr[(AHEAD ? fpar * FSN : 0) + (m * TS + r) * 64 + l2] = make_float2(f.x, f.y);
                 }
             }
             const v2f sq = f * f;                                        // fsk.c:862-868
@@ -453,7 +500,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
 #pragma unroll
                 for (int hh = 0; hh < 2; hh++) {
                     const int hb = 2 * slot + hh;
-                    const float2 p2 = CK[m * NHB + (hb < NHB ? hb : NHB - 1)];
+                    const float2 p2 = CK[(AHEAD ? ckpar * M * NHB : 0) + m * NHB + (hb < NHB ? hb : NHB - 1)];
                     v2f phi = {p2.x, p2.y};
                     const bool segA = hb * H < nold;
                     const v2f dd = {segA ? dA2.x : dB2.x, segA ? dA2.y : dB2.y};
@@ -545,6 +592,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
     // is the same predicate as "atan2f > o_at_hi" (the host finds the float where it flips, DemodTables::oct_cfg): the double
     // division leaves the path the next frame's NCO chain waits on
     float t_at = 0.f, t_tcr = 0.f, t_tci = 0.f;
+    float t_nrt_before = 0.f, t_ppm_before = 0.f;                        // (run-ahead schedule: what tstage1b() changed, for a frame that is mixed twice)
     bool t_have_at = false;
     auto tstage1a = [&]() __attribute__((always_inline)) -> int {
         const float tcr = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(((const float *)CT)[OC_TC])));
@@ -567,6 +615,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
     };
     auto tstage1b = [&]() __attribute__((always_inline)) {
         t_rxt = 0.f;
+        t_nrt_before = norm_rx_timing_st; t_ppm_before = ppm;
         if (!t_nan) {
             if (!t_have_at) t_at = wg_atan2f(t_tci, t_tcr);
             const float at = t_at;
@@ -601,19 +650,29 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
         const float n2 = (t_tcr * t_tcr + t_tci * t_tci) * (pv_r * pv_r + pv_i * pv_i);
         return !t_nan && dot > 0.f && dot * dot > cfg.o_near_cos2 * n2;     // false for a zero or NaN vector
     };
-    auto tstage2 = [&](long long fr) __attribute__((always_inline)) {
+    float2 t2a[M], t2b[M];                                               // the parked outputs the frame's symbols are resampled from
+    auto tstage2_load = [&](int fp) __attribute__((always_inline)) {
         if (!t_nan) {
-            const float fract = t_fract, omf = 1 - fract;
             const int ln = fresh_lane();
             // symbol `lane` is resampled between f_int[.][(lane+1)*P + low_sample] and [.. + high_sample]: for an offset o >= 0
             // that is output o of the NEXT lane's slot, for o < 0 output TS + o of this lane's
             const int r_lo = t_low >= 0 ? t_low : TS + t_low, r_hi = t_high >= 0 ? t_high : TS + t_high;
-            float tmax[M];
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (this wave's own parked outputs: stores before the loads below)
+            // (the values were stored by this wavefront: no wait needed -- a wave's accesses to an address reach the memory pipeline in
+            // program order -- and a vmcnt(0) here would wait for every store still on its way to L2)
 #pragma unroll
             for (int m = 0; m < M; m++) {
-                const float2 a = Fscr[(m * TS + r_lo) * 64 + ln + (t_low >= 0 ? 1 : 0)];     // (lane 63 has no symbol)
-                const float2 b = Fscr[(m * TS + r_hi) * 64 + ln + (t_high >= 0 ? 1 : 0)];
+                t2a[m] = Fscr[fp * FSN + (m * TS + r_lo) * 64 + ln + (t_low >= 0 ? 1 : 0)];     // (lane 63 has no symbol)
+                t2b[m] = Fscr[fp * FSN + (m * TS + r_hi) * 64 + ln + (t_high >= 0 ? 1 : 0)];
+            }
+        }
+    };
+    auto tstage2_finish = [&](long long fr) __attribute__((always_inline)) {
+        if (!t_nan) {
+            const float fract = t_fract, omf = 1 - fract;
+            float tmax[M];
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                const float2 a = t2a[m], b = t2b[m];
                 float tr = omf * a.x, ti = omf * a.y;
                 tr = tr + fract * b.x;
                 ti = ti + fract * b.y;
@@ -648,6 +707,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
             tr[WR_TR_RXT] = t_rxt;
         }
     };
+    auto tstage2 = [&](long long fr, int fp = 0) __attribute__((always_inline)) { tstage2_load(fp); tstage2_finish(fr); };
 
     // ================================ narrow stages (exact mode) ===============================
     // C(j) of the captures in `mask`: lanes 2M c .. 2M c + 2M - 1
@@ -656,12 +716,12 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
         if (cc >= G || !((mask >> cc) & 1)) return;
         const int m = lane % M;
         const int *CTc = CT0 + cc * ctw;
-        v2f *ck = (v2f *)(smem_all + cc * cfg.o_cap_stride + cfg.o_off_CK) + m * NHB;
-        const int nin_j = CTc[OC_NIN];
+        v2f *ck = (v2f *)(smem_all + cc * cfg.o_cap_stride + cfg.o_off_CK) + (AHEAD ? CTc[OC_CREG] * M * NHB : 0) + m * NHB;
+        const int nin_j = CTc[AHEAD ? OC_CNIN : OC_NIN];
         const int nold = Nmem - nin_j;
-        const int bc = CTc[OC_FBIN + m], bp = CTc[OC_FBINP + m];
+        const int bc = CTc[(AHEAD ? OC_CBC : OC_FBIN) + m], bp = CTc[(AHEAD ? OC_CBP : OC_FBINP) + m];
         const int ncase = (nin_j < N) ? 0 : ((nin_j > N) ? 2 : 1);
-        const float2 bo = back_t[ncase * NH + bp];
+        const float2 bo = (SMALL && ncase == 1) ? ((const float2 *)(smem_all + cfg.o_off_BACK))[bp] : back_t[ncase * NH + bp];
         own = cmul_pk((v2f){bo.x, bo.y}, own);                           // fsk.c:758-759
         const float2 d0 = dphi_t[bp], d1 = dphi_t[bc];
         v2f d = {d0.x, d0.y};
@@ -690,8 +750,51 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
         }
     };
 
+    // the same chain in the lane-split form (run-ahead schedule: the capture waves of the duty wave's SIMD mix their frames meanwhile)
+    auto chain_split = [&](int mask) __attribute__((always_inline)) {
+        const int q = lane >> 1, part = lane & 1;
+        const int cc = q / M;
+        if (cc >= G || !((mask >> cc) & 1)) return;
+        const int m = q % M;
+        const int *CTc = CT0 + cc * ctw;
+        float *ck = (float *)((v2f *)(smem_all + cc * cfg.o_cap_stride + cfg.o_off_CK) + CTc[OC_CREG] * M * NHB + m * NHB) + part;
+        const int nin_j = CTc[OC_CNIN];
+        const int nold = Nmem - nin_j;
+        const int bc = CTc[OC_CBC + m], bp = CTc[OC_CBP + m];
+        const int ncase = (nin_j < N) ? 0 : ((nin_j > N) ? 2 : 1);
+        const float2 bo = (ncase == 1) ? ((const float2 *)(smem_all + cfg.o_off_BACK))[bp] : back_t[ncase * NH + bp];
+        own_s = nco_step_split(own_s, bo.x, part ? bo.y : -bo.y);       // fsk.c:758-759: the products and sums of cmul_pk(bo, own)
+        const float2 d0 = dphi_t[bp], d1 = dphi_t[bc];
+        float k1 = d0.x, k2 = part ? d0.y : -d0.y;
+        const int hsw = nold / H;
+        int hb = 0;
+        auto blocks = [&](int upto) __attribute__((always_inline)) {
+            for (; hb < upto; hb++) { ck[2 * hb] = own_s; own_s = nco_steps_split<H>(own_s, k1, k2); }
+        };
+        auto swtch = [&]() __attribute__((always_inline)) {                                             // fsk.c:785-788
+            if (hb == hsw) {
+                const float oth = __shfl_xor(own_s, 1, 64);
+                const float re = part ? oth : own_s, im = part ? own_s : oth;
+                const float av = sqrtf(re * re + im * im);
+                own_s = own_s / av;
+                k1 = d1.x; k2 = part ? d1.y : -d1.y;
+            }
+        };
+        blocks(3); swtch(); blocks(4); swtch(); blocks(5); swtch();
+        const int full = L / H;
+        for (; hb + 8 <= full; hb += 8) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) { ck[2 * (hb + k)] = own_s; own_s = nco_steps_split<H>(own_s, k1, k2); }
+        }
+        blocks(full);
+        if (full * H < L) {
+            ck[2 * hb] = own_s;
+            for (int s = full * H; s < L; s++) own_s = nco_step_split(own_s, k1, k2);
+        }
+    };
+
     // ordered timing sums (fsk.c:870-874) of the captures in `mask`: lanes 2c / 2c+1 add the re / im products of capture c
-    auto tsum = [&](int mask) __attribute__((always_inline)) {
+    auto tsum = [&](int mask) __attribute__((always_inline)) -> float {
         typedef float v4f __attribute__((ext_vector_type(4)));
         int sc = lane >> 1;
         const bool mine = sc < G && ((mask >> sc) & 1);
@@ -721,6 +824,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
 #pragma unroll
         for (int i = NB * 16; i < NIc; i++) acc = acc + row[i];
         if (mine) ((float *)(smem_all + sc * cfg.o_cap_stride + cfg.o_off_CT))[OC_TC + (lane & 1)] = acc;
+        return acc;
     };
 
     auto alive_mask = [&]() __attribute__((always_inline)) {
@@ -746,10 +850,11 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
             __hip_atomic_store(&CT[OC_SEQ], (int)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     };
-    if (is_cap) {
+    if (is_cap && !AHEAD) {
         if (alive) { prefetch_est(0); if (SMALL) prefetch_slot(0, nin); estimate(nin); commit_estimate(); if (!FAST && SMALL) prefetch_est(nin); }
         if (!FAST) publish(nin, alive, 1);
     }
+    int sw = 0;                                                          // run-ahead schedule: ring slot (FE2) of the spectrum after the frame in work's estimator run
     if (FAST) {
         // no shared stages: every capture wave runs on its own
         while (alive) {
@@ -771,6 +876,286 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
             alive = more;
             if (alive) { if (SMALL) prefetch_slot(off, nin); else prefetch_est(off); estimate(nin); commit_estimate(); }
         }
+    } else if (AHEAD) {
+        // ---- the run-ahead schedule (small geometries, exact mode) ---------------------------------------------------------------
+        // A capture's frames form one dependency chain: NCO chain(k) -> mix / integrate(k) -> ordered timing sum(k) -> nin(k+1) ->
+        // chain(k+1).  Run in that order (the loop below this one) the duty wave idles through the wide stage and the capture waves
+        // through the chain.  Here the duty wave runs chain(k+1) DURING mix / integrate(k), assuming nin(k+1) = N -- true for all but the
+        // frames with a timing slip -- so an iteration is two phases and two workgroup barriers:
+        //     A   capture waves: mix / integrate(k), then the FFT of E(k+2)      | duty wave: chain(k+1), speculative, into the other checkpoint region
+        //     B   capture waves: tone search of E(k+2), decisions / outputs(k-1) | duty wave: ordered timing sums(k)
+        //     C   (no barrier) capture waves: nin(k+1) from the sums, bookkeeping, next request to the duty wave (LDS sequence word)
+        // The estimator therefore runs two frames ahead (three spectra in a ring), the decisions one frame behind (two blocks of parked
+        // integrator outputs).  A capture whose nin(k+1) != N spends ONE iteration without a frame: the duty wave chains frame k+1 again
+        // with the true nin (from the state before the speculative chain, with the tone bins the run-ahead estimator found -- a guess that
+        // is checked) while the capture wave repeats E(k+1) and E(k+2) on the shifted windows; the other captures of the workgroup are not
+        // held up.  Everything a frame computes is computed by the same statements in the same order as in the plain schedule.
+        // Capture-wave state: `ready` = the frame in work has its checkpoints (region ckpar), it is mixed in the next phase A.  Not ready:
+        //   redo_e   its estimator run is to be (re)done first (launch start; after a slip) -- then the bins the duty wave chained it with
+        //            are compared with the result, and the chain is requested again if they differ (at launch start there is no guess: always)
+        //   en_valid the next frame's estimator run is done already (the iteration after such a second request)
+        //   redo_d   (ready) the parked integrator outputs did not cover the resampling points: mix the frame again, parking everything
+        if (is_chain) __builtin_amdgcn_s_setprio(2);
+#ifdef WR_WITH_PROF
+        const bool pp = C.prof != nullptr && lane == 0 && (wave == 0 || is_chain);
+        long long *pr = C.prof + (is_chain ? 8 : 0);
+        long long pt[6] = {0, 0, 0, 0, 0, 0}, t0 = pp ? (long long)__builtin_readcyclecounter() : 0;
+#define WO_STAMP(k) do { if (pp) { const long long t1 = (long long)__builtin_readcyclecounter(); pt[k] += t1 - t0; t0 = t1; } } while (0)
+#define WO_SUB(k) do { if (pp) { const long long t1 = (long long)__builtin_readcyclecounter(); pt[k] += t1 - t0; } } while (0)   /* since the last WO_STAMP */
+#else
+#define WO_STAMP(k) do { } while (0)
+#define WO_SUB(k) do { } while (0)
+#endif
+        int b_w[M], b_n[M], b_nn[M], b_pv[M], guess[M];                  // tone bins (wave-uniform): frame in work, next, after next, previous; the duty wave's guess
+#pragma unroll
+        for (int m = 0; m < M; m++) { b_w[m] = b_n[m] = b_nn[m] = 0; guess[m] = -1; b_pv[m] = is_cap ? __builtin_amdgcn_readfirstlane(CT[OC_FBIN + m]) : 0; }
+        bool ready = false, redo_e = true, en_valid = false, redo_d = false;
+        // bins of the frame in work -> the words the mix stage reads (first-run rule, fsk.c:750-753)
+        auto set_work_bins = [&]() __attribute__((always_inline)) {
+            if (lane == 0) {
+                const bool first = b_pv[0] < cfg.o_first_bins;
+#pragma unroll
+                for (int m = 0; m < M; m++) { CT[OC_FBIN + m] = b_w[m]; CT[OC_FBINP + m] = first ? b_w[m] : b_pv[m]; }
+            }
+        };
+        // request to the duty wave: chain a frame of nin_c samples with bins bc (previous frame's: pv) into checkpoint region `region`
+        auto request = [&](int kind, int nin_c, const int *bc, const int *pv, int region, bool more, long long seq) __attribute__((always_inline)) {
+            if (lane == 0) {
+                const bool first = pv[0] < cfg.o_first_bins;
+                CT[OC_REQ] = kind; CT[OC_CNIN] = nin_c; CT[OC_CREG] = region; CT[OC_ALIVE] = more ? 1 : 0; CT[OC_NIN] = nin_c;
+#pragma unroll
+                for (int m = 0; m < M; m++) { CT[OC_CBC + m] = bc[m]; CT[OC_CBP + m] = first ? bc[m] : pv[m]; }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __hip_atomic_store(&CT[OC_SEQ], (int)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        };
+        if (is_cap) {
+            if (lane == 0) { CT[OC_FLAGS] = 0; CT[OC_ORD] = 0; ((float *)CT)[OC_PV] = 0.f; ((float *)CT)[OC_PV + 1] = 0.f; }
+            if (alive) { prefetch_est(0); prefetch_slot(0, nin); }       // frame 0 starts like a frame after a slip, without a guess
+            request(0, nin, b_w, b_pv, ckpar, alive, 1);
+        }
+        // One copy of the loop per role: a wave never changes its role, so inside its copy only that role's values are live.
+        if (is_chain) {
+            float own_m1 = own_s;                                        // the phasors before the last chain that was run
+            int mask = (1 << G) - 1;
+            int selfmask = 0;                                            // captures whose next chain is the speculative one they wrote down beforehand
+            for (long long kf = 0;; kf++) {
+                for (int c = 0; c < G; c++)
+                    if (((mask & ~selfmask) >> c) & 1)
+                        while (__hip_atomic_load((int *)&CT0[c * ctw + OC_SEQ], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (int)(kf + 1)) __builtin_amdgcn_s_sleep(1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                WO_STAMP(0);
+                const int cc = lane / (2 * M);
+                int req = 0;
+                if (cc < G && ((mask >> cc) & 1)) req = CT0[cc * ctw + OC_REQ];
+                if (req == OC_REQ_SPEC) own_m1 = own_s;
+                else if (req == OC_REQ_TRUE || req == OC_REQ_DEAD) own_s = own_m1;
+                const unsigned long long bal = __ballot(req == OC_REQ_SPEC || req == OC_REQ_TRUE);
+                int m2 = 0;
+                for (int c = 0; c < G; c++) m2 |= (int)((bal >> (c * 2 * M)) & 1ull) << c;
+                if (m2) { chain_split(m2); ran |= m2; }
+                WO_STAMP(1);
+                lds_barrier();                                           // timing products of the frames in work; checkpoints of the requested chains
+                WO_STAMP(2);
+                mask &= alive_mask();
+                if (!mask) break;
+                // The sums, and straight away the timing estimate of every capture (one lane each: atan2f, the double division, nin -- once
+                // per workgroup instead of once per capture wave).  If nin stays N and the capture said beforehand that it then has another
+                // frame and that its parked outputs are sure to cover the resampling points (all parked, or the timing vector near the
+                // previous one), its next request can only be the speculative chain it wrote down in phase B: the duty wave starts that
+                // without waiting for the capture wave.
+                const float acc = tsum(mask);
+                const float oth = __shfl_xor(acc, 1, 64);
+                bool self = false;
+                {
+                    const int sc = lane >> 1;
+                    if (sc < G && ((mask >> sc) & 1) && !(lane & 1)) {
+                        int *CTc = (int *)(smem_all + sc * cfg.o_cap_stride + cfg.o_off_CT);
+                        const int fl = CTc[OC_FLAGS];
+                        int ord = 0;
+                        const float tcr = acc, tci = oth;
+                        if ((fl & 4) && !((tcr != tcr) || (tci != tci))) {       // (a NaN frame, fsk.c:878-880, is left to the capture wave)
+                            const float pvr = ((const float *)CTc)[OC_PV], pvi = ((const float *)CTc)[OC_PV + 1];
+                            const float dot = tcr * pvr + tci * pvi;
+                            const float n2 = (tcr * tcr + tci * tci) * (pvr * pvr + pvi * pvi);
+                            const bool near = dot > 0.f && dot * dot > cfg.o_near_cos2 * n2;
+                            const float at = wg_atan2f(tci, tcr);                                           // fsk.c:884
+                            const float nrt = (float)((double)at / (2 * 3.14159265358979323846));
+                            const float rxt = nrt * cfg.P_f;
+                            const int low = (int)floorf(rxt), high = (int)ceilf(rxt);
+                            const int nnc = at > cfg.o_at_hi ? 2 : (at < cfg.o_at_lo ? 0 : 1);               // fsk.c:900-907 (see tstage1a)
+                            self = (fl & 1) && nnc == 1 && ((fl & 2) || near);
+                            ord = 1 | (self ? 2 : 0) | (near ? 4 : 0) | (nnc << 4) | ((low + 64) << 8) | ((high + 64) << 16);
+                            ((float *)CTc)[OC_O_NRT] = nrt; ((float *)CTc)[OC_O_FRACT] = rxt - (float)low; ((float *)CTc)[OC_O_RXT] = rxt;
+                        }
+                        CTc[OC_ORD] = ord;
+                    }
+                }
+                const unsigned long long sb = __ballot(self);
+                selfmask = 0;
+                for (int c = 0; c < G; c++) selfmask |= (int)((sb >> (2 * c)) & 1ull) << c;
+                lds_barrier();                                           // timing sums
+                WO_STAMP(3);
+            }
+        } else {
+            int mask = (1 << G) - 1;
+            for (long long kf = 0;; kf++) {
+                if (alive) {
+                    if (ready) {
+                        dstage(off, nin, omask, true);
+                        prefetch_slot(off + nin, N);                     // the next frame's samples, assuming nin = N (fetched again after a slip)
+                    }
+                    // estimator runs of this phase: after a slip E(k) with the true nin (tone search included), then -- always, unless it is done
+                    // already -- the FFT of the newest frame the schedule looks at, assuming it (and the frames before it) have nin = N
+                    for (int e = (!ready && redo_e) ? 0 : 1; e < 2; e++) {
+                        if (e == 1 && (ready ? redo_d : en_valid)) break;
+                        estimate_fft(e == 0 ? nin : N);
+                        if (e == 0) { estimate_pick_to((sw + 2) % 3, sw, b_w); prefetch_est(off + nin); }
+                        // (the samples of the run after it are fetched at the end of phase B)
+                    }
+                }
+                lds_barrier();
+                WO_STAMP(0);
+                mask &= alive_mask();
+                if (!mask) break;
+                if (alive) {
+                    const bool ran_fft = ready ? !redo_d : !en_valid;
+                    if (ran_fft) {
+                        int fb[M];
+                        const int si = ready ? (sw + 1) % 3 : sw;
+                        estimate_pick_to(si, (si + 1) % 3, fb);
+#pragma unroll
+                        for (int m = 0; m < M; m++) { if (ready) b_nn[m] = fb[m]; else b_n[m] = fb[m]; }
+                        if (ready && lane == 0) {                        // the request of the next iteration if nin stays N (see the duty wave's loop)
+                            const bool first = b_n[0] < cfg.o_first_bins;
+                            CT[OC_REQ] = OC_REQ_SPEC; CT[OC_CNIN] = N; CT[OC_CREG] = ckpar;
+#pragma unroll
+                            for (int m = 0; m < M; m++) { CT[OC_CBC + m] = b_nn[m]; CT[OC_CBP + m] = first ? b_nn[m] : b_n[m]; }
+                        }
+                    }
+                    // the samples of the estimator run after the one just done (a capture that mixes frames fetches them at the end of phase C:
+                    // a load in flight there would make the wait for the parked outputs a wait for HBM)
+                    if (ran_fft && !ready) prefetch_est(off + nin + N);
+                }
+                lds_barrier();
+                WO_STAMP(1);
+                if (alive) {
+                    if (ready) {
+#pragma unroll
+                        for (int m = 0; m < M; m++) t_bins[m] = b_w[m];
+                        __builtin_amdgcn_s_setprio(1);
+                        const int ordw = __builtin_amdgcn_readfirstlane(CT[OC_ORD]);
+                        const bool ordered = (ordw & 1) != 0;            // the duty wave formed the timing estimate
+                        const bool self = (ordw & 2) != 0;               // ... and has started the next chain already: nin stays N, nothing to check
+                        int nn = N;
+                        bool did_1b = false, near_prev = false;
+                        float o_nrt = 0.f;
+                        if (ordered) {
+                            t_tcr = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(((const float *)CT)[OC_TC])));
+                            t_tci = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(((const float *)CT)[OC_TC + 1])));
+                            o_nrt = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(((const float *)CT)[OC_O_NRT])));
+                            t_fract = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(((const float *)CT)[OC_O_FRACT])));
+                            t_rxt = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(((const float *)CT)[OC_O_RXT])));
+                            t_low = ((ordw >> 8) & 0xff) - 64; t_high = ((ordw >> 16) & 0xff) - 64;
+                            nn = N + (((ordw >> 4) & 3) - 1) * (TS / 2);
+                            t_nan = false; t_have_at = false; t_nin_next = nn;
+                            near_prev = (ordw & 4) != 0;
+                            did_1b = true;
+                        } else {
+                            nn = tstage1a();
+                            near_prev = timing_near_previous();
+                        }
+                        // do the parked outputs cover this frame's resampling points?  Sure if everything was parked or the timing vector is near
+                        // the previous one's; otherwise look (exact rx_timing) and, on a miss, spend the next iteration on mixing the frame again
+                        bool miss = false;
+                        if (!self && omask != ALLOUT && !near_prev) {
+                            if (!did_1b) { tstage1b(); did_1b = true; }
+                            miss = !t_nan && !(((omask >> (t_low >= 0 ? t_low : TS + t_low)) & (omask >> (t_high >= 0 ? t_high : TS + t_high))) & 1);
+                        }
+                        redo_d = miss;
+                        if (miss) {
+                            omask = ALLOUT;
+                            if (!ordered) { norm_rx_timing_st = t_nrt_before; ppm = t_ppm_before; }    // (the estimate is formed again after the second pass)
+                            if (lane == 0) CT[OC_FLAGS] = 0;
+                            request(0, nin, b_w, b_pv, ckpar, true, kf + 2);
+                            prefetch_slot(off, nin);                     // (this frame's samples again)
+                        } else {
+                            if (ordered) {                               // the rest of tstage1b(): fsk.c:887-896
+                                const float d_nrt = o_nrt - norm_rx_timing_st;
+                                norm_rx_timing_st = o_nrt;
+                                if (C.trace && (double)fabsf(d_nrt) < .2) {
+                                    const float appm = (float)(1e6 * (double)d_nrt / (double)cfg.nsym_f);
+                                    ppm = (float)(.9 * (double)ppm + .1 * (double)appm);
+                                }
+                            } else if (!did_1b) tstage1b();
+                            WO_SUB(3);
+                            tstage2_load(0);                             // the frame's resampling points (parked in this iteration's phase A: L2)
+                            const long long off1 = off + nin;
+                            const bool more = self || (off1 + nn <= C.nsamples && frames + 1 < C.cap_frames);
+                            if (!more) request(OC_REQ_DEAD, nn, b_w, b_pv, ckpar, false, kf + 2);
+                            else {
+#pragma unroll
+                                for (int m = 0; m < M; m++) { b_pv[m] = b_w[m]; b_w[m] = b_n[m]; b_n[m] = b_nn[m]; }
+                                sw = (sw + 1) % 3;
+                                ckpar ^= 1;
+                                set_work_bins();
+                                if (self) { }                            // (requested already: the words written in phase B)
+                                else if (nn == N) request(OC_REQ_SPEC, N, b_n, b_w, ckpar ^ 1, true, kf + 2);
+                                else {                                       // a timing slip: the speculative chain of this frame is void
+#pragma unroll
+                                    for (int m = 0; m < M; m++) guess[m] = b_w[m];
+                                    request(OC_REQ_TRUE, nn, b_w, b_pv, ckpar, true, kf + 2);
+                                    ready = false; redo_e = true; en_valid = false;
+                                }
+                            }
+                            __builtin_amdgcn_s_setprio(0);
+                            omask = (!t_nan && near_prev && nn == N) ? window_mask(t_low) : ALLOUT;
+                            pv_r = t_nan ? 0.f : t_tcr; pv_i = t_nan ? 0.f : t_tci;
+                            if (lane == 0) {                             // what the duty wave needs for its estimate of the next frame
+                                const bool fastok = more && ready && off1 + nn + N <= C.nsamples && frames + 2 < C.cap_frames;
+                                CT[OC_FLAGS] = (fastok ? 1 : 0) | (omask == ALLOUT ? 2 : 0) | (more && ready ? 4 : 0);
+                                ((float *)CT)[OC_PV] = pv_r; ((float *)CT)[OC_PV + 1] = pv_i;
+                            }
+                            if (more && nn != N) { prefetch_slot(off1, nn); prefetch_est(off1); }
+                            WO_SUB(4);
+                            tstage2_finish(frames);
+                            WO_SUB(5);
+                            nslip += (nn != N) ? 1 : 0;
+                            off = off1; nin = nn; frames++;
+                            alive = more;
+                            if (alive && ready) prefetch_est(off + nin + N);
+                        }
+                        __builtin_amdgcn_s_setprio(0);
+                    } else {
+                        bool same = true;
+                        if (redo_e) {
+#pragma unroll
+                            for (int m = 0; m < M; m++) same = same && (b_w[m] == guess[m]);
+                        }
+                        if (same) {                                          // the frame in work has its checkpoints: from the next iteration on it runs
+                            ready = true; redo_e = false; en_valid = false;
+                            if (lane == 0) {
+                                const bool fastok = off + nin + N <= C.nsamples && frames + 1 < C.cap_frames;
+                                CT[OC_FLAGS] = (fastok ? 1 : 0) | (omask == ALLOUT ? 2 : 0) | 4;
+                                ((float *)CT)[OC_PV] = pv_r; ((float *)CT)[OC_PV + 1] = pv_i;
+                            }
+                            request(OC_REQ_SPEC, N, b_n, b_w, ckpar ^ 1, true, kf + 2);
+                        } else {                                             // (launch start; or the shifted window moved a tone bin: chain with the bins it has now)
+                            set_work_bins();
+                            request(OC_REQ_TRUE, nin, b_w, b_pv, ckpar, true, kf + 2);
+                            redo_e = false; en_valid = true;
+                        }
+                    }
+                    wave_sync();
+                }
+                WO_STAMP(2);
+            }
+        }
+#ifdef WR_WITH_PROF
+        if (pp) { for (int k = 0; k < 6; k++) pr[k] = pt[k]; if (!is_chain) pr[6] = frames; }
+#endif
+#undef WO_STAMP
+#undef WO_SUB
     } else {
         if (is_chain) __builtin_amdgcn_s_setprio(2);                     // the serial wave wins VALU arbitration against the wide ones
         // development (WENET_RX_PROFILE=4): cycles of wave 0 and of the duty wave per section, summed over the frames:
@@ -812,7 +1197,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
             lds_barrier();                                               // timing sums
             WO_STAMP(is_chain ? 3 : 2);
             if (is_cap && alive) {
-    #pragma unroll
+#pragma unroll
             for (int m = 0; m < M; m++) t_bins[m] = CT[OC_FBIN + m];
                 __builtin_amdgcn_s_setprio(1);
                 const int nn = tstage1a();
@@ -853,7 +1238,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
     // ================================ save carried state =======================================
     if (is_cap && present) {
         if (frames > 0) {
-            for (int i = lane; i < NH; i += 64) st_fft[i] = FE2[fecur * NH + i];
+            for (int i = lane; i < NH; i += 64) st_fft[i] = FE2[(AHEAD ? sw : fecur) * NH + i];
             for (int i = lane; i < nstash; i += 64) st_old[i] = cvt(raw16[off - nstash + i]);     // fsk.c:851 (off >= nin > nstash)
             if (lane < WR_NSYM) {
 #pragma unroll
@@ -872,7 +1257,14 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
             hdr->consumed_call = off;
         }
     }
-    if (is_chain) {                                                      // un-normalised, as saved at fsk.c:846
+    if (is_chain && AHEAD) {
+        const int q = lane >> 1, cc = q / M, m = q % M;
+        const int chc = blockIdx.x * G + cc;
+        if (cc < G && chc < nchan && ((ran >> cc) & 1)) {
+            WrChanHdr *h = (WrChanHdr *)chans[chc].state;
+            ((float *)&h->phi_c[m])[lane & 1] = own_s;
+        }
+    } else if (is_chain) {                                               // un-normalised, as saved at fsk.c:846
         const int cc = lane / M, m = lane % M;
         const int chc = blockIdx.x * G + cc;
         if (cc < G && chc < nchan && ((ran >> cc) & 1)) {

@@ -68,7 +68,7 @@ struct WrDemodCfg {
     int p_off_TW, p_off_HANN, p_off_SRC, p_off_PFT, p_off_DPHI;
     // batch kernel, one wavefront per capture (demod_oct_impl.h): o_caps captures per workgroup, each with an LDS block of
     // o_cap_stride bytes (o_off_FB .. o_off_CT inside it), the tables once behind the blocks; o_ok = geometry supported
-    int o_ok, o_caps, o_cap_stride, o_lds_bytes, o_nhb, o_first_bins;
+    int o_ok, o_caps, o_cap_stride, o_lds_bytes, o_nhb, o_first_bins, o_ntw;
     int o_off_FB, o_off_TP, o_off_FE, o_off_FW, o_off_CK, o_off_CT;
     int o_off_TW, o_off_HANN, o_off_SRC, o_off_DPHI, o_off_PFT, o_off_BACK;
     float o_near_cos2;                   // cos^2 of the angle the timing vector may turn between frames while the parked outputs stay valid

@@ -170,7 +170,7 @@ struct DemodTables {
 
     // configuration copy for the batch kernel with one wavefront per capture (demod_oct_impl.h), caps captures per workgroup;
     // o_ok == 0 in it if the geometry is not one it was written for (two tones, Ts 8 or 10 with P = Ts, one 256-point FFT per frame)
-    WrDemodCfg oct_cfg(int caps) const {
+    WrDemodCfg oct_cfg(int caps, bool fast = false) const {
         WrDemodCfg c = cfg;
         c.o_ok = 0;
         const bool small = cfg.M == 2 && (cfg.Ts == 8 || cfg.Ts == 10) && cfg.Ndft == 256;       // Wenet v1 / v2
@@ -181,22 +181,27 @@ struct DemodTables {
         const int NH = cfg.Ndft / 2, NIq = (cfg.NI + 3) & ~3, H = cfg.Ts / 2;
         c.o_nhb = (cfg.L + H - 1) / H;
         int t = 0;
+        // The small geometries' exact kernel runs the run-ahead schedule (demod_oct_impl.h): three spectra, two checkpoint regions, and a
+        // layout squeezed so that two workgroups of seven captures still share a CU's 160 KB: the tone-search copy of the spectrum lives in
+        // the upper half of the FFT buffer (dead after the last stage), only the twiddles the transform reaches are copied (3 * 63 < 192).
+        const bool ahead = small && !fast;
         c.o_off_FB = t;  t = align16(t + cfg.Ndft * 8);
+        if (ahead) c.o_off_FW = c.o_off_FB + NH * 8;
         c.o_off_TP = t;  t = align16(t + 2 * NIq * 4);
-        c.o_off_FE = t;  t = align16(t + 2 * NH * 4);
-        c.o_off_FW = t;  t = align16(t + NH * 4);
-        c.o_off_CK = t;  t = align16(t + cfg.M * c.o_nhb * 8);
+        c.o_off_FE = t;  t = align16(t + (ahead ? 3 : 2) * NH * 4);
+        if (!ahead) { c.o_off_FW = t;  t = align16(t + NH * 4); }
+        c.o_off_CK = t;  t = align16(t + (ahead ? 2 : (fast ? 0 : 1)) * cfg.M * c.o_nhb * 8);
         c.o_off_CT = t;  t = align16(t + 32 * 4);
-        c.o_cap_stride = (t + 127) & ~127;
-        int tab = 0;                                                    // tables behind the capture blocks; the large geometry reads three of them through the caches
-        const int o_tw = tab;   tab = align16(tab + cfg.Ndft * 8);
+        c.o_cap_stride = ahead ? ((t + 31) & ~31) : ((t + 127) & ~127);
+        c.o_ntw = ahead ? 192 : cfg.Ndft;
+        int tab = 0;                                                    // tables behind the capture blocks; the others are read through the caches
+        const int o_tw = tab;   tab = align16(tab + c.o_ntw * 8);
         const int o_hann = tab; tab = align16(tab + cfg.Ndft * 4);
         const int o_dphi = tab; tab = align16(tab + NH * 8);
         int o_src = 0, o_pft = 0, o_back = 0;
         if (small) {
             o_src = tab;  tab = align16(tab + cfg.Ndft * 4);
-            o_pft = tab;  tab = align16(tab + cfg.NI * 8);
-            o_back = tab; tab = align16(tab + 3 * NH * 8);
+            o_back = tab; tab = align16(tab + NH * 8);                 // the back-off phasors of the nin = N case (backoff_tab row 1)
         }
         const int max_caps = (160 * 1024 - tab) / c.o_cap_stride;
         if (caps < 1) caps = 1;
@@ -1061,7 +1066,7 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const lon
     if (rx->want_llr && !rx->d_llr.reserve((size_t)nchan * max_pk * WR_NCODE * 4)) return -2;
     rx->profile = getenv("WENET_RX_PROFILE") != nullptr;
     if (rx->profile && !rx->d_prof.reserve((size_t)nchan * 32 * 8)) return -2;
-    const size_t oct_scr = (size_t)c.M * c.Ts * 64 * 8 + 64;            // demod_oct_impl.h: integrator outputs of one frame, [tone][output][lane] float2
+    const size_t oct_scr = 2 * (size_t)c.M * c.Ts * 64 * 8 + 64;        // demod_oct_impl.h: integrator outputs of one frame, [tone][output][lane] float2, twice (run-ahead schedule)
     if (c.big && !rx->d_big.reserve((size_t)nchan * c.big_bytes)) return -2;           // frame scratch, geometries beyond LDS
     if (!c.big && !rx->d_big.reserve((size_t)nchan * oct_scr)) return -2;
     // fresh modem + deframer state per capture
@@ -1139,7 +1144,7 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const lon
     WrDemodCfg oct_cfg;
     bool use_oct = false;
     if (oct_caps > 0 || rx->fast) {
-        oct_cfg = rx->tab.oct_cfg(oct_caps > 0 ? oct_caps : 7);
+        oct_cfg = rx->tab.oct_cfg(oct_caps > 0 ? oct_caps : 7, rx->fast != 0);
         use_oct = oct_cfg.o_ok != 0 && fmt == WENET_FMT_CU8;
     }
     const int oct_fast = use_oct && rx->fast ? 1 : 0;
@@ -1200,7 +1205,10 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const lon
                 WR_CHECK(hipMemcpyAsync(rx->d_chans2.p, redo.data(), sizeof(WrChan) * redo.size(), hipMemcpyHostToDevice, stream), -3);
                 WR_CHECK(hipStreamSynchronize(stream), -3);                  // (redo goes out of scope)
                 const int nr = (int)redo.size();
-                if (nr >= 4 * ncu) WR_CHECK(wr_launch_demod_oct(&oct_cfg, rx->d_chans2.as<WrChan>(), nr, stream, 0), -4);
+                if (nr >= 4 * ncu) {
+                    const WrDemodCfg exact_cfg = rx->tab.oct_cfg(oct_cfg.o_caps, false);                 // (the exact kernel has its own LDS layout)
+                    WR_CHECK(wr_launch_demod_oct(&exact_cfg, rx->d_chans2.as<WrChan>(), nr, stream, 0), -4);
+                }
                 else {
                     WrDemodCfg rc = (2 * nr >= 3 * ncu) ? rx->tab.tri_cfg() : (nr > 2 * ncu ? rx->tab.raw_cfg() : rx->tab.cfg);
                     rc.p_tsum_split = (rc.p_tri || nr > ncu) ? 1 : 0;
