@@ -124,6 +124,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
     static_assert(M == 2 || M == 4, "two or four tones");
     static_assert(NDFT == 256 || NDFT == 1024, "a power of four: radix-4 stages only");
     constexpr int H = TS / 2;                                            // checkpoint spacing = the unit of a timing slip
+    constexpr WoLayout LY = wo_layout(M, TS, NDFT, FAST);                // LDS carve-up (wenet_internal.h; the host fills cfg.o_* from the same function)
     constexpr bool SMALL = (NDFT == 256);                                // all tables in LDS, samples fetched a frame ahead
     constexpr bool AHEAD = SMALL && !FAST;                               // the run-ahead schedule of the frame loop (see there)
     constexpr unsigned ALLOUT = TS == 32 ? 0xffffffffu : (1u << TS) - 1u;
@@ -139,27 +140,29 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
     if (!present) { C.nsamples = 0; C.cap_frames = 0; C.sd_out = nullptr; C.trace = nullptr; }
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
-    unsigned char *smem = smem_all + cap * cfg.o_cap_stride;
-    float2 *FB = (float2 *)(smem + cfg.o_off_FB);                        // [Ndft] estimator FFT buffer
-    float  *TPf = (float *)(smem + cfg.o_off_TP);                        // the frame's timing products: a row of re, a row of im
-    float  *FE2 = (float *)(smem + cfg.o_off_FE);                        // [2][Ndft/2] smoothed spectrum after this frame's estimator run | after the next one's
+    unsigned char *smem = smem_all + cap * LY.stride;
+    float2 *FB = (float2 *)(smem + LY.FB);                        // [Ndft] estimator FFT buffer
+    float  *TPf = (float *)(smem + LY.TP);                        // the frame's timing products: a row of re, a row of im
+    float  *FE2 = (float *)(smem + LY.FE);                        // [2][Ndft/2] smoothed spectrum after this frame's estimator run | after the next one's
                                                                          // (run-ahead schedule: a ring of three, frame f's in slot f % 3)
-    float  *FW = (float *)(smem + cfg.o_off_FW);                         // [Ndft/2]
-    float2 *CK = (float2 *)(smem + cfg.o_off_CK);                        // [M][o_nhb] phasor at the start of every half symbol
-    int    *CT = (int *)(smem + cfg.o_off_CT);
-    const float2 *tw_t = (const float2 *)(smem_all + cfg.o_off_TW);
-    const float  *hann_t = (const float *)(smem_all + cfg.o_off_HANN);
-    const float2 *dphi_t = (const float2 *)(smem_all + cfg.o_off_DPHI);
-    const int    *src_t = SMALL ? (const int *)(smem_all + cfg.o_off_SRC) : cfg.fft_src;
+    float  *FW = (float *)(smem + LY.FW);                         // [Ndft/2]
+    float2 *CK = (float2 *)(smem + LY.CK);                        // [M][o_nhb] phasor at the start of every half symbol
+    int    *CT = (int *)(smem + LY.CT);
+    const float2 *tw_t = (const float2 *)(smem_all + (G * LY.stride + LY.TW));
+    const float  *hann_t = (const float *)(smem_all + (G * LY.stride + LY.HANN));
+    const float2 *dphi_t = (const float2 *)(smem_all + (G * LY.stride + LY.DPHI));
+    const int    *src_t = SMALL ? (const int *)(smem_all + (G * LY.stride + LY.SRC)) : cfg.fft_src;
     const float2 *pft_t = cfg.phi_ft;                                    // (read through the caches: one coalesced pass per frame)
     const float2 *back_t = cfg.backoff_tab;                              // (one entry per chain)
-    const int ctw = cfg.o_cap_stride / 4;
-    const int *CT0 = (const int *)(smem_all + cfg.o_off_CT);
+    const int ctw = LY.stride / 4;
+    const int *CT0 = (const int *)(smem_all + LY.CT);
 
     constexpr int Ndft = NDFT, NH = NDFT / 2;
-    const int N = cfg.N, Nmem = cfg.Nmem, nstash = cfg.nstash, L = cfg.L, NI = cfg.NI;
-    const int NIq = (NI + 3) & ~3, NHB = cfg.o_nhb;
-    const int NOUT = NI / TS;                                            // lanes that own integrator outputs (NI = (Nsym+1)*TS)
+    // frame geometry: functions of TS alone here (DemodTables::oct_cfg admits P == Ts, Nsym == WR_NSYM only) -- compile-time constants, not
+    // scalar registers loaded from the argument block (the frame loop is short of those)
+    constexpr int N = TS * WR_NSYM, Nmem = N + 2 * TS, nstash = 4 * TS, L = Nmem - 1, NI = (WR_NSYM + 1) * TS;    // fsk.c:135-160 with q = Ts / P = 1
+    constexpr int NIq = (NI + 3) & ~3, NHB = (L + H - 1) / H;
+    constexpr int NOUT = NI / TS;                                        // lanes that own integrator outputs (NI = (Nsym+1)*TS)
     constexpr int NE = NDFT / 64;                                        // estimator points per lane
     constexpr int NBF = NDFT / 256;                                      // radix-4 butterflies per lane and stage
 
@@ -172,14 +175,14 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
 
     // ---- shared tables and carried state -> LDS / registers ------------------------------------
     {
-        float2 *tw_w = (float2 *)(smem_all + cfg.o_off_TW); float *hann_w = (float *)(smem_all + cfg.o_off_HANN);
-        float2 *dphi_w = (float2 *)(smem_all + cfg.o_off_DPHI);
+        float2 *tw_w = (float2 *)(smem_all + (G * LY.stride + LY.TW)); float *hann_w = (float *)(smem_all + (G * LY.stride + LY.HANN));
+        float2 *dphi_w = (float2 *)(smem_all + (G * LY.stride + LY.DPHI));
         const int nt = blockDim.x;
-        for (int i = tid; i < Ndft; i += nt) { if (i < cfg.o_ntw) tw_w[i] = cfg.tw[i]; hann_w[i] = cfg.hann[i]; }
+        for (int i = tid; i < Ndft; i += nt) { if (i < LY.ntw) tw_w[i] = cfg.tw[i]; hann_w[i] = cfg.hann[i]; }
         for (int i = tid; i < NH; i += nt) dphi_w[i] = cfg.dphi_tab[i];
         if (SMALL) {
-            int *src_w = (int *)(smem_all + cfg.o_off_SRC);
-            float2 *back_w = (float2 *)(smem_all + cfg.o_off_BACK);
+            int *src_w = (int *)(smem_all + (G * LY.stride + LY.SRC));
+            float2 *back_w = (float2 *)(smem_all + (G * LY.stride + LY.BACK));
             for (int i = tid; i < Ndft; i += nt) src_w[i] = cfg.fft_src[i];
             for (int i = tid; i < NH; i += nt) back_w[i] = cfg.backoff_tab[NH + i];             // (the nin = N row)
         }
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
     // ================================ capture-wave stages ======================================
     unsigned epre[SMALL ? NE : 1];                                       // estimator samples of the NEXT frame (its start is known a frame ahead)
     unsigned xr[TS / 2 + 1];                                             // this lane's symbol slot of the frame about to be mixed, two cu8 samples per dword
-    const int NBLK = (L + TS - 1) / TS;                                  // lanes that own samples
+    constexpr int NBLK = (L + TS - 1) / TS;                              // lanes that own samples
     // The lane number, opaque to the optimiser: per-lane LDS / global addresses derived from it are recomputed where they are used
     // (a handful of integer instructions) instead of being hoisted out of the frame loop into dozens of registers that then spill.
     auto fresh_lane = [&]() __attribute__((always_inline)) -> int { int l = lane; asm volatile("" : "+v"(l)); return l; };
@@ -263,22 +266,18 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
 #pragma unroll
             for (int u = 0; u < TS / 2 + 1; u++) xr[u] = p[u];
         } else {                                                         // first frame (window starts in the carried samp_old[]) / capture's last sample
-            unsigned w[TS];
-#pragma unroll
-            for (int u = 0; u < TS; u++) {
-                const long long a = b0 + TS * slot + u;
-                if (a < 0) {                                             // carried samples came from cu8 input (or are the zeros of a reset): exact inverse
+            // the same dwords sample by sample: position e of the capture, from the carried samples (they came from cu8 input or are the
+            // zeros of a reset: exact inverse of the conversion) below 0, the capture's last sample repeated beyond it (never used)
+            auto samp = [&](long long a) __attribute__((always_inline)) -> unsigned {
+                if (a < 0) {
                     const float2 v = present ? st_old[nstash + a] : make_float2(0.f, 0.f);
-                    w[u] = (unsigned)(int)(v.x * 128.0f + 127.0f) | ((unsigned)(int)(v.y * 128.0f + 127.0f) << 8);
-                } else w[u] = raw16[a < last_smp ? a : last_smp];
-            }
-            const bool odd = (b0 & 1) != 0;                              // leave them as slot_align() expects them
+                    return (unsigned)(int)(v.x * 128.0f + 127.0f) | ((unsigned)(int)(v.y * 128.0f + 127.0f) << 8);
+                }
+                return raw16[a < last_smp ? a : last_smp];
+            };
+            const long long e0 = (b0 & ~1LL) + TS * slot;
 #pragma unroll
-            for (int u = 0; u < TS / 2 + 1; u++) {
-                const unsigned lo = odd ? (2 * u - 1 >= 0 && 2 * u - 1 < TS ? w[2 * u - 1 < 0 ? 0 : (2 * u - 1 < TS ? 2 * u - 1 : 0)] : 0u) : (2 * u < TS ? w[2 * u < TS ? 2 * u : 0] : 0u);
-                const unsigned hi = odd ? (2 * u < TS ? w[2 * u < TS ? 2 * u : 0] : 0u) : (2 * u + 1 < TS ? w[2 * u + 1 < TS ? 2 * u + 1 : 0] : 0u);
-                xr[u] = lo | (hi << 16);
-            }
+            for (int u = 0; u < TS / 2 + 1; u++) xr[u] = samp(e0 + 2 * u) | (samp(e0 + 2 * u + 1) << 16);
         }
     };
     auto slot_align = [&](long long off_j, int nin_j) __attribute__((always_inline)) {
@@ -448,8 +447,6 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
     // breaks the prediction is integrated a second time with the full mask before the next frame's chains overwrite the checkpoints.
     // (Keeping the four in registers instead was tried: 16 more live VGPRs spill, +18 % frame time.)
     float2 *Fscr = (float2 *)C.big;
-    constexpr int FSN = M * TS * 64;                                     // parked values per frame; the run-ahead schedule alternates between two such blocks
-    int fpar = 0;                                                        // ... the one the mix / integrate stage fills next
     int ckpar = 0;                                                       // run-ahead schedule: checkpoint region of the frame in work
     unsigned omask = ALLOUT;                                     // outputs parked by the mix / integrate stage of the frame in work
     float pv_r = 0.f, pv_i = 0.f;                                        // the previous frame's timing vector (0, 0: none)
@@ -470,7 +467,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
         float *Trow = TPf + TS * ln;
         char *fbase[3];
         if (!FT1_LDS) {
-            fbase[0] = (char *)(Fscr + (AHEAD ? fpar * FSN : 0) + ln);
+            fbase[0] = (char *)(Fscr + ln);
 #pragma unroll
             for (int k = 1; k < 3; k++) { fbase[k] = fbase[k - 1] + 4096; asm volatile("" : "+v"(fbase[k])); }
         }
@@ -484,7 +481,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
                 } else {
                     int l2 = ln;
                     asm volatile("" : "+v"(l2));                         // (address formed here, under the branch: four of them per tone, not 128 hoisted ones)
-                    Fscr[(AHEAD ? fpar * FSN : 0) + (m * TS + r) * 64 + l2] = make_float2(f.x, f.y);
+                    Fscr[(m * TS + r) * 64 + l2] = make_float2(f.x, f.y);
                 }
             }
             const v2f sq = f * f;                                        // fsk.c:862-868
@@ -640,7 +637,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
     auto window_mask = [&](int low) __attribute__((always_inline)) -> unsigned {
         unsigned mk = 0;
 #pragma unroll
-        for (int j = -1; j <= 2; j++) mk |= 1u << (((low + j) % TS + TS) % TS);
+        for (int j = -1; j <= 2; j++) { const int x = low + j + TS; mk |= 1u << ((x >= TS ? x - TS : x) % TS); }   // (low >= -TS/2: x >= 0; the % folds away for x < 2 TS)
         return mk;
     };
     // is this frame's timing vector within 0.94 samples of rx_timing (0.94 * 360 / P degrees: 34 at P = 10) of the previous frame's?
@@ -651,7 +648,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
         return !t_nan && dot > 0.f && dot * dot > cfg.o_near_cos2 * n2;     // false for a zero or NaN vector
     };
     float2 t2a[M], t2b[M];                                               // the parked outputs the frame's symbols are resampled from
-    auto tstage2_load = [&](int fp) __attribute__((always_inline)) {
+    auto tstage2_load = [&]() __attribute__((always_inline)) {
         if (!t_nan) {
             const int ln = fresh_lane();
             // symbol `lane` is resampled between f_int[.][(lane+1)*P + low_sample] and [.. + high_sample]: for an offset o >= 0
@@ -661,8 +658,8 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
             // program order -- and a vmcnt(0) here would wait for every store still on its way to L2)
 #pragma unroll
             for (int m = 0; m < M; m++) {
-                t2a[m] = Fscr[fp * FSN + (m * TS + r_lo) * 64 + ln + (t_low >= 0 ? 1 : 0)];     // (lane 63 has no symbol)
-                t2b[m] = Fscr[fp * FSN + (m * TS + r_hi) * 64 + ln + (t_high >= 0 ? 1 : 0)];
+                t2a[m] = Fscr[(m * TS + r_lo) * 64 + ln + (t_low >= 0 ? 1 : 0)];     // (lane 63 has no symbol)
+                t2b[m] = Fscr[(m * TS + r_hi) * 64 + ln + (t_high >= 0 ? 1 : 0)];
             }
         }
     };
@@ -707,7 +704,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
             tr[WR_TR_RXT] = t_rxt;
         }
     };
-    auto tstage2 = [&](long long fr, int fp = 0) __attribute__((always_inline)) { tstage2_load(fp); tstage2_finish(fr); };
+    auto tstage2 = [&](long long fr) __attribute__((always_inline)) { tstage2_load(); tstage2_finish(fr); };
 
     // ================================ narrow stages (exact mode) ===============================
     // C(j) of the captures in `mask`: lanes 2M c .. 2M c + 2M - 1
@@ -716,18 +713,19 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
         if (cc >= G || !((mask >> cc) & 1)) return;
         const int m = lane % M;
         const int *CTc = CT0 + cc * ctw;
-        v2f *ck = (v2f *)(smem_all + cc * cfg.o_cap_stride + cfg.o_off_CK) + (AHEAD ? CTc[OC_CREG] * M * NHB : 0) + m * NHB;
+        v2f *ck = (v2f *)(smem_all + cc * LY.stride + LY.CK) + (AHEAD ? CTc[OC_CREG] * M * NHB : 0) + m * NHB;
         const int nin_j = CTc[AHEAD ? OC_CNIN : OC_NIN];
         const int nold = Nmem - nin_j;
         const int bc = CTc[(AHEAD ? OC_CBC : OC_FBIN) + m], bp = CTc[(AHEAD ? OC_CBP : OC_FBINP) + m];
         const int ncase = (nin_j < N) ? 0 : ((nin_j > N) ? 2 : 1);
-        const float2 bo = (SMALL && ncase == 1) ? ((const float2 *)(smem_all + cfg.o_off_BACK))[bp] : back_t[ncase * NH + bp];
+        const float2 bo = (SMALL && ncase == 1) ? ((const float2 *)(smem_all + (G * LY.stride + LY.BACK)))[bp] : back_t[ncase * NH + bp];
         own = cmul_pk((v2f){bo.x, bo.y}, own);                           // fsk.c:758-759
         const float2 d0 = dphi_t[bp], d1 = dphi_t[bc];
         v2f d = {d0.x, d0.y};
         const int hsw = nold / H;                                        // 3, 4 or 5: the half symbol that starts with the new samples
         int hb = 0;
         auto blocks = [&](int upto) __attribute__((always_inline)) {
+#pragma unroll 1
             for (; hb < upto; hb++) { ck[hb] = own; own = nco_steps<H>(own, d); }
         };
         auto swtch = [&]() __attribute__((always_inline)) {                                             // fsk.c:785-788: normalise, continue with this frame's estimate
@@ -739,6 +737,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
         };
         blocks(3); swtch(); blocks(4); swtch(); blocks(5); swtch();
         const int full = L / H;
+#pragma unroll 1
         for (; hb + 8 <= full; hb += 8) {                                // eight checkpoints per trip: a taken branch costs ~16 cycles
 #pragma unroll
             for (int k = 0; k < 8; k++) { ck[hb + k] = own; own = nco_steps<H>(own, d); }
@@ -757,18 +756,19 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
         if (cc >= G || !((mask >> cc) & 1)) return;
         const int m = q % M;
         const int *CTc = CT0 + cc * ctw;
-        float *ck = (float *)((v2f *)(smem_all + cc * cfg.o_cap_stride + cfg.o_off_CK) + CTc[OC_CREG] * M * NHB + m * NHB) + part;
+        float *ck = (float *)((v2f *)(smem_all + cc * LY.stride + LY.CK) + CTc[OC_CREG] * M * NHB + m * NHB) + part;
         const int nin_j = CTc[OC_CNIN];
         const int nold = Nmem - nin_j;
         const int bc = CTc[OC_CBC + m], bp = CTc[OC_CBP + m];
         const int ncase = (nin_j < N) ? 0 : ((nin_j > N) ? 2 : 1);
-        const float2 bo = (ncase == 1) ? ((const float2 *)(smem_all + cfg.o_off_BACK))[bp] : back_t[ncase * NH + bp];
+        const float2 bo = (ncase == 1) ? ((const float2 *)(smem_all + (G * LY.stride + LY.BACK)))[bp] : back_t[ncase * NH + bp];
         own_s = nco_step_split(own_s, bo.x, part ? bo.y : -bo.y);       // fsk.c:758-759: the products and sums of cmul_pk(bo, own)
         const float2 d0 = dphi_t[bp], d1 = dphi_t[bc];
         float k1 = d0.x, k2 = part ? d0.y : -d0.y;
         const int hsw = nold / H;
         int hb = 0;
         auto blocks = [&](int upto) __attribute__((always_inline)) {
+#pragma unroll 1
             for (; hb < upto; hb++) { ck[2 * hb] = own_s; own_s = nco_steps_split<H>(own_s, k1, k2); }
         };
         auto swtch = [&]() __attribute__((always_inline)) {                                             // fsk.c:785-788
@@ -782,7 +782,8 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
         };
         blocks(3); swtch(); blocks(4); swtch(); blocks(5); swtch();
         const int full = L / H;
-        for (; hb + 8 <= full; hb += 8) {
+#pragma unroll 1
+        for (; hb + 8 <= full; hb += 8) {                                // (eight checkpoints per trip, no more: the trip count is a constant, and a fully unrolled chain is 10 KB of code)
 #pragma unroll
             for (int k = 0; k < 8; k++) { ck[2 * (hb + k)] = own_s; own_s = nco_steps_split<H>(own_s, k1, k2); }
         }
@@ -799,7 +800,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
         int sc = lane >> 1;
         const bool mine = sc < G && ((mask >> sc) & 1);
         if (!mine) sc = __builtin_ctz(mask);
-        const float *row = (const float *)(smem_all + sc * cfg.o_cap_stride + cfg.o_off_TP) + (lane & 1) * NIq;
+        const float *row = (const float *)(smem_all + sc * LY.stride + LY.TP) + (lane & 1) * NIq;
         const v4f *T4 = (const v4f *)row;
         float acc = 0.f;
         // Straight-line code, the products fetched 32 ahead of the adds (three buffers of four 128-bit reads): the compiler waits
@@ -823,7 +824,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
         }
 #pragma unroll
         for (int i = NB * 16; i < NIc; i++) acc = acc + row[i];
-        if (mine) ((float *)(smem_all + sc * cfg.o_cap_stride + cfg.o_off_CT))[OC_TC + (lane & 1)] = acc;
+        if (mine) ((float *)(smem_all + sc * LY.stride + LY.CT))[OC_TC + (lane & 1)] = acc;
         return acc;
     };
 
@@ -970,7 +971,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
                 {
                     const int sc = lane >> 1;
                     if (sc < G && ((mask >> sc) & 1) && !(lane & 1)) {
-                        int *CTc = (int *)(smem_all + sc * cfg.o_cap_stride + cfg.o_off_CT);
+                        int *CTc = (int *)(smem_all + sc * LY.stride + LY.CT);
                         const int fl = CTc[OC_FLAGS];
                         int ord = 0;
                         const float tcr = acc, tci = oth;
@@ -1051,32 +1052,31 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
                         bool did_1b = false, near_prev = false;
                         float o_nrt = 0.f;
                         if (ordered) {
-                            t_tcr = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(((const float *)CT)[OC_TC])));
-                            t_tci = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(((const float *)CT)[OC_TC + 1])));
-                            o_nrt = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(((const float *)CT)[OC_O_NRT])));
-                            t_fract = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(((const float *)CT)[OC_O_FRACT])));
-                            t_rxt = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(((const float *)CT)[OC_O_RXT])));
+                            const float2 tc2 = *(const float2 *)((const float *)CT + OC_TC);             // (two LDS reads for the five values)
+                            const float4 o4 = *(const float4 *)((const float *)CT + OC_O_NRT);
+                            t_tcr = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(tc2.x)));
+                            t_tci = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(tc2.y)));
+                            o_nrt = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(o4.x)));
+                            t_fract = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(o4.y)));
+                            t_rxt = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(o4.z)));
                             t_low = ((ordw >> 8) & 0xff) - 64; t_high = ((ordw >> 16) & 0xff) - 64;
                             nn = N + (((ordw >> 4) & 3) - 1) * (TS / 2);
                             t_nan = false; t_have_at = false; t_nin_next = nn;
                             near_prev = (ordw & 4) != 0;
                             did_1b = true;
-                        } else {
-                            nn = tstage1a();
-                            near_prev = timing_near_previous();
+                        } else {                                         // NaN timing sums (fsk.c:878-880): nin stays, the last decisions are emitted again
+                            t_nan = true; nn = nin; t_nin_next = nn; t_rxt = 0.f; did_1b = true;
                         }
                         // do the parked outputs cover this frame's resampling points?  Sure if everything was parked or the timing vector is near
                         // the previous one's; otherwise look (exact rx_timing) and, on a miss, spend the next iteration on mixing the frame again
                         bool miss = false;
                         if (!self && omask != ALLOUT && !near_prev) {
-                            if (!did_1b) { tstage1b(); did_1b = true; }
                             miss = !t_nan && !(((omask >> (t_low >= 0 ? t_low : TS + t_low)) & (omask >> (t_high >= 0 ? t_high : TS + t_high))) & 1);
                         }
                         redo_d = miss;
                         if (miss) {
                             omask = ALLOUT;
-                            if (!ordered) { norm_rx_timing_st = t_nrt_before; ppm = t_ppm_before; }    // (the estimate is formed again after the second pass)
-                            if (lane == 0) CT[OC_FLAGS] = 0;
+                            if (lane == 0) CT[OC_FLAGS] = 2 | 4;          // (all outputs parked; the sums of the second pass are this frame's again)
                             request(0, nin, b_w, b_pv, ckpar, true, kf + 2);
                             prefetch_slot(off, nin);                     // (this frame's samples again)
                         } else {
@@ -1087,16 +1087,16 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
                                     const float appm = (float)(1e6 * (double)d_nrt / (double)cfg.nsym_f);
                                     ppm = (float)(.9 * (double)ppm + .1 * (double)appm);
                                 }
-                            } else if (!did_1b) tstage1b();
+                            }
                             WO_SUB(3);
-                            tstage2_load(0);                             // the frame's resampling points (parked in this iteration's phase A: L2)
+                            tstage2_load();                             // the frame's resampling points (parked in this iteration's phase A: L2)
                             const long long off1 = off + nin;
                             const bool more = self || (off1 + nn <= C.nsamples && frames + 1 < C.cap_frames);
                             if (!more) request(OC_REQ_DEAD, nn, b_w, b_pv, ckpar, false, kf + 2);
                             else {
 #pragma unroll
                                 for (int m = 0; m < M; m++) { b_pv[m] = b_w[m]; b_w[m] = b_n[m]; b_n[m] = b_nn[m]; }
-                                sw = (sw + 1) % 3;
+                                sw = sw == 2 ? 0 : sw + 1;
                                 ckpar ^= 1;
                                 set_work_bins();
                                 if (self) { }                            // (requested already: the words written in phase B)

@@ -77,6 +77,42 @@ struct WrDemodCfg {
     int st_fft_est, st_samp_old, st_sd_last, st_floats;
 };
 
+// LDS carve-up of the batch kernel (demod_oct_impl.h) for a geometry (M tones, Ts samples per symbol, Ndft-point estimator; P == Ts, 48-symbol
+// frames): one block per capture (FB .. CT, `stride` bytes), the shared tables behind the blocks (offsets from the end of the last block, `tab`
+// bytes).  One constexpr function for the host (DemodTables::oct_cfg fills the o_* fields from it) and for the kernel, where these are
+// immediates instead of scalar registers.  The small geometries' exact kernel runs the run-ahead schedule: three spectra, two checkpoint regions,
+// and a layout squeezed so that two workgroups of seven captures share a CU's 160 KB -- the tone-search copy of the spectrum lives in the upper
+// half of the FFT buffer (dead after the last stage), only the twiddles the transform reaches are copied (3 * 63 < 192), and of the per-bin
+// tables only the NCO steps, the digit reversal and the nin = N row of the back-off phasors; the rest is read through the caches.
+struct WoLayout { int FB, FW, TP, FE, CK, CT, stride, ntw, TW, HANN, DPHI, SRC, BACK, tab, nhb; };
+constexpr int wo_align16(int x) { return (x + 15) & ~15; }
+constexpr WoLayout wo_layout(int M, int Ts, int Ndft, bool fast) {
+    WoLayout y{};
+    const bool small = Ndft == 256, ahead = small && !fast;
+    const int NH = Ndft / 2, NI = 49 * Ts, NIq = (NI + 3) & ~3, H = Ts / 2, L = 50 * Ts - 1;
+    y.nhb = (L + H - 1) / H;
+    int t = 0;
+    y.FB = t;  t = wo_align16(t + Ndft * 8);
+    if (ahead) y.FW = y.FB + NH * 8;
+    y.TP = t;  t = wo_align16(t + 2 * NIq * 4);
+    y.FE = t;  t = wo_align16(t + (ahead ? 3 : 2) * NH * 4);
+    if (!ahead) { y.FW = t;  t = wo_align16(t + NH * 4); }
+    y.CK = t;  t = wo_align16(t + (ahead ? 2 : (fast ? 0 : 1)) * M * y.nhb * 8);
+    y.CT = t;  t = wo_align16(t + 32 * 4);
+    y.stride = ahead ? ((t + 31) & ~31) : ((t + 127) & ~127);
+    y.ntw = ahead ? 192 : Ndft;
+    int tab = 0;
+    y.TW = tab;   tab = wo_align16(tab + y.ntw * 8);
+    y.HANN = tab; tab = wo_align16(tab + Ndft * 4);
+    y.DPHI = tab; tab = wo_align16(tab + NH * 8);
+    if (small) {
+        y.SRC = tab;  tab = wo_align16(tab + Ndft * 4);
+        y.BACK = tab; tab = wo_align16(tab + NH * 8);
+    }
+    y.tab = tab;
+    return y;
+}
+
 // state header (first 24 floats/ints of the per-channel state block)
 struct WrChanHdr {
     float2 phi_c[WR_M_MAX];     // fsk.h:61 (un-normalised, as saved at fsk.c:846)

@@ -178,31 +178,14 @@ struct DemodTables {
         if (cfg.big || !(small || large) || cfg.P != cfg.Ts || cfg.Nsym != WR_NSYM ||
             cfg.N < cfg.Ndft + cfg.Ts / 2 || cfg.N + cfg.Ts / 2 >= 2 * cfg.Ndft || getenv("WENET_RX_NO_OCT") != nullptr)
             return c;
-        const int NH = cfg.Ndft / 2, NIq = (cfg.NI + 3) & ~3, H = cfg.Ts / 2;
-        c.o_nhb = (cfg.L + H - 1) / H;
-        int t = 0;
-        // The small geometries' exact kernel runs the run-ahead schedule (demod_oct_impl.h): three spectra, two checkpoint regions, and a
-        // layout squeezed so that two workgroups of seven captures still share a CU's 160 KB: the tone-search copy of the spectrum lives in
-        // the upper half of the FFT buffer (dead after the last stage), only the twiddles the transform reaches are copied (3 * 63 < 192).
-        const bool ahead = small && !fast;
-        c.o_off_FB = t;  t = align16(t + cfg.Ndft * 8);
-        if (ahead) c.o_off_FW = c.o_off_FB + NH * 8;
-        c.o_off_TP = t;  t = align16(t + 2 * NIq * 4);
-        c.o_off_FE = t;  t = align16(t + (ahead ? 3 : 2) * NH * 4);
-        if (!ahead) { c.o_off_FW = t;  t = align16(t + NH * 4); }
-        c.o_off_CK = t;  t = align16(t + (ahead ? 2 : (fast ? 0 : 1)) * cfg.M * c.o_nhb * 8);
-        c.o_off_CT = t;  t = align16(t + 32 * 4);
-        c.o_cap_stride = ahead ? ((t + 31) & ~31) : ((t + 127) & ~127);
-        c.o_ntw = ahead ? 192 : cfg.Ndft;
-        int tab = 0;                                                    // tables behind the capture blocks; the others are read through the caches
-        const int o_tw = tab;   tab = align16(tab + c.o_ntw * 8);
-        const int o_hann = tab; tab = align16(tab + cfg.Ndft * 4);
-        const int o_dphi = tab; tab = align16(tab + NH * 8);
-        int o_src = 0, o_pft = 0, o_back = 0;
-        if (small) {
-            o_src = tab;  tab = align16(tab + cfg.Ndft * 4);
-            o_back = tab; tab = align16(tab + NH * 8);                 // the back-off phasors of the nin = N case (backoff_tab row 1)
-        }
+        const int NH = cfg.Ndft / 2;
+        const WoLayout y = wo_layout(cfg.M, cfg.Ts, cfg.Ndft, fast);     // (wenet_internal.h: the kernel uses the same function at compile time)
+        if (cfg.L != 50 * cfg.Ts - 1 || cfg.NI != 49 * cfg.Ts) return c;
+        c.o_nhb = y.nhb;
+        c.o_off_FB = y.FB; c.o_off_FW = y.FW; c.o_off_TP = y.TP; c.o_off_FE = y.FE; c.o_off_CK = y.CK; c.o_off_CT = y.CT;
+        c.o_cap_stride = y.stride;
+        c.o_ntw = y.ntw;
+        const int tab = y.tab, o_tw = y.TW, o_hann = y.HANN, o_dphi = y.DPHI, o_src = y.SRC, o_pft = 0, o_back = y.BACK;
         const int max_caps = (160 * 1024 - tab) / c.o_cap_stride;
         if (caps < 1) caps = 1;
         if (caps > 15) caps = 15;
@@ -1066,7 +1049,7 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const lon
     if (rx->want_llr && !rx->d_llr.reserve((size_t)nchan * max_pk * WR_NCODE * 4)) return -2;
     rx->profile = getenv("WENET_RX_PROFILE") != nullptr;
     if (rx->profile && !rx->d_prof.reserve((size_t)nchan * 32 * 8)) return -2;
-    const size_t oct_scr = 2 * (size_t)c.M * c.Ts * 64 * 8 + 64;        // demod_oct_impl.h: integrator outputs of one frame, [tone][output][lane] float2, twice (run-ahead schedule)
+    const size_t oct_scr = (size_t)c.M * c.Ts * 64 * 8 + 64;            // demod_oct_impl.h: integrator outputs of one frame, [tone][output][lane] float2
     if (c.big && !rx->d_big.reserve((size_t)nchan * c.big_bytes)) return -2;           // frame scratch, geometries beyond LDS
     if (!c.big && !rx->d_big.reserve((size_t)nchan * oct_scr)) return -2;
     // fresh modem + deframer state per capture
@@ -1127,16 +1110,20 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const lon
     WrDemodCfg launch_cfg = want_tri ? rx->tab.tri_cfg() : (want_raw ? rx->tab.raw_cfg() : rx->tab.cfg);
     if (want_tri && !launch_cfg.p_tri) launch_cfg = want_raw ? rx->tab.raw_cfg() : rx->tab.cfg;     // geometry does not fit three blocks
     // Batches (round 2): one wavefront per capture, `caps` captures per workgroup sharing an NCO-chain and a timing-sum wavefront
-    // (demod_oct_impl.h) -- no speculation, so timing slips cost nothing.  A capture advances one frame per ~23 k cycles there (the
-    // pipelined kernels: 11.5 k), so it takes over once the CUs hold several captures each.  WENET_RX_OCT=<caps> forces it
+    // (demod_oct_impl.h).  A capture advances one frame per ~20 k cycles there (the pipelined kernels: 11.5 k), so it takes over once
+    // the CUs hold several captures each.  WENET_RX_OCT=<caps> forces it
     // (tests), WENET_RX_NO_OCT turns it off.  Traces with Eb/N0 accumulators and profiling stay with the pipelined kernels.
     int oct_caps = 0;
     if (fmt == WENET_FMT_CU8 && (!rx->profile || getenv("WENET_RX_PROFILE")[0] == '4')) {
         const char *force = getenv("WENET_RX_OCT");
-        // measured (tools/gpu_batch_sweep.py, 2 s captures): up to 6 captures per CU the pipelined kernels win (20.8 ms per 3 captures
-        // per CU); 6..12 per CU: three workgroups of four captures per CU (44 ms for 2048); beyond: two of seven (55 ms for 3584)
+        // measured (tools/gpu_batch_sweep.py, 10 s captures, 256 CUs, demod ms): the three-capture pipelined kernel takes 103 per round of 768
+        // captures; workgroups of four captures 179 up to one per CU, 203 up to two per CU; workgroups of seven 195 up to one per CU,
+        // 245..255 up to two per CU.  Hence: up to 3 captures per CU pipelined, then whichever workgroup size needs fewer per CU.
         if (force) oct_caps = atoi(force) > 0 ? atoi(force) : 7;
-        else if (!rx->want_trace && c.M == 2 && nchan >= 6 * wenet_rx_device_info(1)) oct_caps = nchan > 12 * wenet_rx_device_info(1) ? 7 : 4;
+        else if (!rx->want_trace && c.M == 2 && nchan > 3 * wenet_rx_device_info(1)) {
+            const int ncu = wenet_rx_device_info(1);
+            oct_caps = nchan <= 4 * ncu ? 4 : (nchan <= 7 * ncu ? 7 : (nchan <= 8 * ncu ? 4 : 7));
+        }
         // the 4-FSK / Ts 32 geometry (BASELINE config 4): 30 KB of LDS per capture = four captures per CU as two workgroups of two;
         // from two captures per CU on it beats the sequential kernel's one capture per CU (34 vs 11.5 Gsamples/s at 1024 captures)
         else if (!rx->want_trace && c.M == 4 && nchan >= 2 * wenet_rx_device_info(1)) oct_caps = 2;
