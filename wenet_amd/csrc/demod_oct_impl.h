@@ -64,6 +64,13 @@ enum { OC_REQ_SPEC = 1 /* the frame after the one in work, assuming nin = N */, 
        OC_REQ_DEAD = 3 /* capture finished: the last (speculative) chain never happened */ };
 
 typedef __attribute__((address_space(3))) float oct_lds_f32;
+// Pointers read from the channel table are generic as far as the compiler knows -- FLAT instructions, 64-bit address arithmetic per lane.  The
+// hot ones are cast to the global address space and indexed with 32-bit lane offsets from a wave-uniform base (a capture is < 2^31 samples).
+typedef const __attribute__((address_space(1))) unsigned short oct_g_u16;
+typedef const __attribute__((address_space(1))) unsigned oct_g_u32;
+typedef __attribute__((address_space(1))) float oct_g_f32;
+typedef __attribute__((address_space(1))) v2f oct_g_f32x2;              // (the clang vector type: HIP's float2 is a class, bound to the generic address space)
+typedef const __attribute__((address_space(1))) v2f oct_g_cf32x2;
 
 // value of lane + 1 (DPP wave shift; the last lane reads 0)
 __device__ __forceinline__ float lane_up(float v) {
@@ -152,7 +159,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
     const float  *hann_t = (const float *)(smem_all + (G * LY.stride + LY.HANN));
     const float2 *dphi_t = (const float2 *)(smem_all + (G * LY.stride + LY.DPHI));
     const int    *src_t = SMALL ? (const int *)(smem_all + (G * LY.stride + LY.SRC)) : cfg.fft_src;
-    const float2 *pft_t = cfg.phi_ft;                                    // (read through the caches: one coalesced pass per frame)
+    oct_g_cf32x2 *pft_t = (oct_g_cf32x2 *)cfg.phi_ft;                    // (read through the caches: one coalesced pass per frame)
     const float2 *back_t = cfg.backoff_tab;                              // (one entry per chain)
     const int ctw = LY.stride / 4;
     const int *CT0 = (const int *)(smem_all + LY.CT);
@@ -170,7 +177,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
     float *st_fft = C.state + cfg.st_fft_est;
     float2 *st_old = (float2 *)(C.state + cfg.st_samp_old);
     float *st_sd = C.state + cfg.st_sd_last;
-    const unsigned short *raw16 = (const unsigned short *)C.raw;
+    oct_g_u16 *raw16 = (oct_g_u16 *)C.raw;
     const long long last_smp = C.nsamples > 0 ? C.nsamples - 1 : 0;
 
     // ---- shared tables and carried state -> LDS / registers ------------------------------------
@@ -248,9 +255,9 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
         if (!SMALL) { est_off = off_j; return; }                         // (loaded inside estimate_fft)
         const int ln = fresh_lane();
         if (off_j + Ndft <= C.nsamples) {                                // the whole transform window is inside the capture: no index clamping
-            const unsigned short *p = raw16 + off_j;
+            oct_g_u16 *p = raw16 + off_j;
 #pragma unroll
-            for (int j = 0; j < NE; j++) epre[j] = p[src_t[4 * (ln + 64 * (j >> 2)) + (j & 3)]];
+            for (int j = 0; j < NE; j++) epre[j] = p[(unsigned)src_t[4 * (ln + 64 * (j >> 2)) + (j & 3)]];
         } else {                                                         // (a run ahead of the capture's end: its result is never used)
 #pragma unroll
             for (int j = 0; j < NE; j++) { long long a = off_j + src_t[4 * (ln + 64 * (j >> 2)) + (j & 3)]; epre[j] = raw16[a < last_smp ? a : last_smp]; }
@@ -262,9 +269,10 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
         const int ln = fresh_lane(), slot = ln < NBLK ? ln : NBLK - 1;    // (idle lanes repeat the last slot: always inside the frame)
         const long long b0 = off_j - (Nmem - nin_j);                     // buffer position 0 (negative only in a launch's first frame)
         if (b0 >= 0 && b0 + Nmem + 1 <= C.nsamples) {                    // positions 0 .. Nmem (one past the window) are samples of the capture
-            const unsigned *p = (const unsigned *)(raw16 + ((b0 & ~1LL) + TS * slot));
+            oct_g_u32 *p = (oct_g_u32 *)(raw16 + (b0 & ~1LL));              // (wave-uniform; the lane's part is a 32-bit dword offset)
+            const unsigned so = (unsigned)(TS / 2 * slot);
 #pragma unroll
-            for (int u = 0; u < TS / 2 + 1; u++) xr[u] = p[u];
+            for (int u = 0; u < TS / 2 + 1; u++) xr[u] = p[so + u];
         } else {                                                         // first frame (window starts in the carried samp_old[]) / capture's last sample
             // the same dwords sample by sample: position e of the capture, from the carried samples (they came from cu8 input or are the
             // zeros of a reset: exact inverse of the conversion) below 0, the capture's last sample repeated beyond it (never used)
@@ -372,37 +380,42 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
         const float *FEin = FE2 + slot_in * NH;
         float *FEout = FE2 + slot_out * NH;
         const int ln = fresh_lane();
-        for (int i = ln; i < NH; i += 64) {                            // fsk.c:612-628
+        constexpr int NPL = NH / 64;                                     // spectrum points per lane: bins ln, ln + 64, ...
+        float e[NPL];
+#pragma unroll
+        for (int kk = 0; kk < NPL; kk++) {                               // fsk.c:612-628
+            const int i = ln + 64 * kk;
             const float2 v = FB[i];
             float mag = (v.x * v.x) + (v.y * v.y);
             if (i < cfg.f_min) mag = 0.f;
             if (cfg.f_max - 1 >= 0 && i >= cfg.f_max - 1) mag = 0.f;
-            const float e = (FEin[i] * cfg.one_minus_tc) + (sqrtf(mag) * cfg.tc);
-            FEout[i] = e;
-            FW[i] = e;
+            e[kk] = (FEin[i] * cfg.one_minus_tc) + (sqrtf(mag) * cfg.tc);
+            FEout[i] = e[kk];
         }
-        wave_sync();
         int fbin[M];
 #pragma unroll
-        for (int k = 0; k < M; k++) {                                    // fsk.c:633-654
-            BestBin best; best.v = 0.f; best.i = 0;
-            for (int jj = ln; jj < NH; jj += 64) {
-                const float v = FW[jj];
-                if (v > best.v) { best.v = v; best.i = jj; }
-            }
+        for (int k = 0; k < M; k++) {                                    // fsk.c:633-654: the first maximum above zero, then its neighbourhood is cleared
+            // the search copy of the spectrum stays in registers: wave maximum (values only), then the lowest bin that holds it -- bins
+            // ascend with kk first, with the lane second, so it is the first set bit of the first non-empty ballot
+            float bv = e[0];
 #pragma unroll
-            for (int sh = 32; sh >= 1; sh >>= 1) {
-                BestBin o;
-                o.v = __shfl_xor(best.v, sh, 64);
-                o.i = __shfl_xor(best.i, sh, 64);
-                best = better(best, o);
+            for (int kk = 1; kk < NPL; kk++) bv = __builtin_fmaxf(bv, e[kk]);
+#pragma unroll
+            for (int sh = 32; sh >= 1; sh >>= 1) bv = __builtin_fmaxf(bv, __shfl_xor(bv, sh, 64));
+            const float wm = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(bv)));
+            int imax = 0;
+            if (wm > 0.f) {
+                bool found = false;
+#pragma unroll
+                for (int kk = 0; kk < NPL; kk++) {
+                    const unsigned long long bal = __ballot(e[kk] == wm);
+                    if (!found && bal != 0ull) { imax = 64 * kk + (int)__builtin_ctzll(bal); found = true; }
+                }
             }
-            const int imax = __builtin_amdgcn_readfirstlane((best.v > 0.f) ? best.i : 0);
             int lo = imax - cfg.f_zero; lo = lo < 0 ? 0 : lo;
             int hi = imax + cfg.f_zero; hi = hi > NH ? NH : hi;
-            wave_sync();
-            for (int jj = lo + ln; jj < hi; jj += 64) FW[jj] = 0.f;
-            wave_sync();
+#pragma unroll
+            for (int kk = 0; kk < NPL; kk++) { const int i = ln + 64 * kk; if (i >= lo && i < hi) e[kk] = 0.f; }
             fbin[k] = imax;
         }
 #pragma unroll
@@ -446,7 +459,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
     // FOUR of the TS, known beforehand; any other frame (first frame, a timing slip, no signal) parks all of them, and a frame that
     // breaks the prediction is integrated a second time with the full mask before the next frame's chains overwrite the checkpoints.
     // (Keeping the four in registers instead was tried: 16 more live VGPRs spill, +18 % frame time.)
-    float2 *Fscr = (float2 *)C.big;
+    oct_g_f32x2 *Fscr = (oct_g_f32x2 *)C.big;
     int ckpar = 0;                                                       // run-ahead schedule: checkpoint region of the frame in work
     unsigned omask = ALLOUT;                                     // outputs parked by the mix / integrate stage of the frame in work
     float pv_r = 0.f, pv_i = 0.f;                                        // the previous frame's timing vector (0, 0: none)
@@ -465,23 +478,24 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
             for (int u = 0; u < TS; u++) xs[SMALL ? 0 : u] = slot_sample(u);
         }
         float *Trow = TPf + TS * ln;
-        char *fbase[3];
+        unsigned fbase[3];                                               // byte offsets of the lane's values from the scratch block, 4 KB apart
         if (!FT1_LDS) {
-            fbase[0] = (char *)(Fscr + ln);
+            fbase[0] = (unsigned)ln * 8u;
 #pragma unroll
-            for (int k = 1; k < 3; k++) { fbase[k] = fbase[k - 1] + 4096; asm volatile("" : "+v"(fbase[k])); }
+            for (int k = 1; k < 3; k++) { fbase[k] = fbase[k - 1] + 4096u; asm volatile("" : "+v"(fbase[k])); }
         }
         auto put_out = [&](int m, int r, v2f f) __attribute__((always_inline)) {
             if ((omask >> r) & 1) {                                      // (wave-uniform)
                 if (!FT1_LDS) {
-                    // value (m, r) sits 512 (m TS + r) bytes above the lane's first one: reached from three lane pointers 4 KB apart with the
-                    // store's immediate offset (left to itself the compiler materialises -- and spills -- twenty 64-bit addresses)
+                    // value (m, r) sits 512 (m TS + r) bytes above the lane's first one: reached from three lane offsets 4 KB apart with the
+                    // store's immediate offset (left to itself the compiler materialises -- and spills -- twenty addresses)
                     const int byte = (m * TS + r) * 512;
-                    *(float2 *)(fbase[byte >> 12] + (byte & 4095)) = make_float2(f.x, f.y);
+                    typedef __attribute__((address_space(1))) char oct_g_i8;
+                    *(oct_g_f32x2 *)((oct_g_i8 *)Fscr + fbase[byte >> 12] + (byte & 4095)) = f;
                 } else {
                     int l2 = ln;
                     asm volatile("" : "+v"(l2));                         // (address formed here, under the branch: four of them per tone, not 128 hoisted ones)
-                    Fscr[(m * TS + r) * 64 + l2] = make_float2(f.x, f.y);
+                    Fscr[(m * TS + r) * 64 + l2] = f;
                 }
             }
             const v2f sq = f * f;                                        // fsk.c:862-868
@@ -553,7 +567,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
             if (ln < NOUT) {
 #pragma unroll
                 for (int r = 0; r < TS; r += 2) {                        // fsk.c:870-871: the products; the duty wave adds them in order
-                    const float2 pa = pft_t[TS * ln + r], pb = pft_t[TS * ln + r + 1];
+                    const v2f pa = pft_t[TS * ln + r], pb = pft_t[TS * ln + r + 1];
                     const float fa = FT1_LDS ? Trow[r] : ft1[FT1_LDS ? 0 : r], fb = FT1_LDS ? Trow[r + 1] : ft1[FT1_LDS ? 0 : r + 1];
                     const v2f ta = (v2f){fa, fa} * (v2f){pa.x, pa.y}, tb = (v2f){fb, fb} * (v2f){pb.x, pb.y};
                     *(float2 *)(TPf + TS * ln + r) = make_float2(ta.x, tb.x);
@@ -565,7 +579,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
             if (ln < NOUT) {
 #pragma unroll
                 for (int r = 0; r < TS; r++) {
-                    const float2 pf = pft_t[TS * ln + r];
+                    const v2f pf = pft_t[TS * ln + r];
                     const float fa = FT1_LDS ? Trow[r] : ft1[FT1_LDS ? 0 : r];
                     sr += fa * pf.x; si += fa * pf.y;
                 }
@@ -647,7 +661,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
         const float n2 = (t_tcr * t_tcr + t_tci * t_tci) * (pv_r * pv_r + pv_i * pv_i);
         return !t_nan && dot > 0.f && dot * dot > cfg.o_near_cos2 * n2;     // false for a zero or NaN vector
     };
-    float2 t2a[M], t2b[M];                                               // the parked outputs the frame's symbols are resampled from
+    v2f t2a[M], t2b[M];                                                  // the parked outputs the frame's symbols are resampled from
     auto tstage2_load = [&]() __attribute__((always_inline)) {
         if (!t_nan) {
             const int ln = fresh_lane();
@@ -658,8 +672,8 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
             // program order -- and a vmcnt(0) here would wait for every store still on its way to L2)
 #pragma unroll
             for (int m = 0; m < M; m++) {
-                t2a[m] = Fscr[(m * TS + r_lo) * 64 + ln + (t_low >= 0 ? 1 : 0)];     // (lane 63 has no symbol)
-                t2b[m] = Fscr[(m * TS + r_hi) * 64 + ln + (t_high >= 0 ? 1 : 0)];
+                t2a[m] = (Fscr + ((m * TS + r_lo) * 64 + (t_low >= 0 ? 1 : 0)))[(unsigned)ln];     // (lane 63 has no symbol)
+                t2b[m] = (Fscr + ((m * TS + r_hi) * 64 + (t_high >= 0 ? 1 : 0)))[(unsigned)ln];
             }
         }
     };
@@ -669,7 +683,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
             float tmax[M];
 #pragma unroll
             for (int m = 0; m < M; m++) {
-                const float2 a = t2a[m], b = t2b[m];
+                const v2f a = t2a[m], b = t2b[m];
                 float tr = omf * a.x, ti = omf * a.y;
                 tr = tr + fract * b.x;
                 ti = ti + fract * b.y;
@@ -689,8 +703,8 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
             }
         }
         if (C.sd_out && lane < WR_NSYM) {
-            if (NSD == 1) C.sd_out[fr * WR_NSYM + lane] = sdl[0];
-            else *(float2 *)(C.sd_out + (fr * WR_NSYM + lane) * 2) = make_float2(sdl[0], sdl[NSD - 1]);
+            if (NSD == 1) ((oct_g_f32 *)C.sd_out + fr * WR_NSYM)[(unsigned)lane] = sdl[0];
+            else ((oct_g_f32x2 *)C.sd_out + fr * WR_NSYM)[(unsigned)lane] = (v2f){sdl[0], sdl[NSD - 1]};
         }
         if (C.trace && lane == 0) {
             float *tr = C.trace + fr * WR_TRACE_FLOATS;
