@@ -104,6 +104,35 @@ __device__ __forceinline__ v2f nco_steps(v2f phi, v2f d) {           // N steps 
     return phi;
 }
 
+// f(integral_constant<int, B>) ... f(integral_constant<int, E - 1>): a loop whose index is a constant expression in the body
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (B < E) { f(std::integral_constant<int, B>{}); static_for<B + 1, E>(f); }
+}
+
+// acc + d[0] + d[1] + ... + d[K-1], added in that order, as ONE asm statement per (up to) eight terms: left to the compiler every dependent
+// packed add is followed by an s_nop (its dst-forwarding hazard rule, see cmul_pk in demod_common.h) -- an issue slot in two on the
+// slot-ordered window sums
+template <int K>
+__device__ __forceinline__ v2f pk_add_seq(v2f acc, const v2f *d) {
+#define WO_A1(k) "v_pk_add_f32 %0, %0, %" #k "\n\t"
+    if constexpr (K >= 8) {
+        asm(WO_A1(1) WO_A1(2) WO_A1(3) WO_A1(4) WO_A1(5) WO_A1(6) WO_A1(7) WO_A1(8)
+            : "+v"(acc) : "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]), "v"(d[4]), "v"(d[5]), "v"(d[6]), "v"(d[7]));
+        return pk_add_seq<K - 8>(acc, d + 8);
+    } else if constexpr (K >= 4) {
+        asm(WO_A1(1) WO_A1(2) WO_A1(3) WO_A1(4) : "+v"(acc) : "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]));
+        return pk_add_seq<K - 4>(acc, d + 4);
+    } else if constexpr (K >= 2) {
+        asm(WO_A1(1) WO_A1(2) : "+v"(acc) : "v"(d[0]), "v"(d[1]));
+        return pk_add_seq<K - 2>(acc, d + 2);
+    } else if constexpr (K == 1) {
+        asm(WO_A1(1) : "+v"(acc) : "v"(d[0]));
+        return acc;
+    } else return acc;
+#undef WO_A1
+}
+
 // the same N steps with the real and imaginary part of the phasor in neighbouring lanes (nco_step_split, demod_common.h): plain
 // instructions -- half the SIMD time of the packed form, which matters where other wavefronts have work for the SIMD meanwhile
 template <int N>
@@ -523,14 +552,13 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
                 }
                 // slot-ordered window sums (fsk.c:829-840), see the header: `run` is the block's running prefix sum
                 v2f run = (v2f){0.f, 0.f} + d[0];
-#pragma unroll
-                for (int r = 1; r < TS; r++) {
+                static_for<1, TS>([&](auto rc) __attribute__((always_inline)) {
+                    constexpr int r = decltype(rc)::value;
                     v2f acc = lane_up(run) + d[r];
-#pragma unroll
-                    for (int n = r + 1; n < TS; n++) acc = acc + d[n];
+                    acc = pk_add_seq<TS - 1 - r>(acc, &d[r < TS - 1 ? r + 1 : r]);
                     put_out(m, r, acc);
                     run = run + d[r];
-                }
+                });
                 put_out(m, 0, run);
             } else {
 #pragma clang fp contract(fast)

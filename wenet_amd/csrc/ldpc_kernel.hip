@@ -194,7 +194,8 @@ __global__ __launch_bounds__(64) void wenet_llr_stats_kernel(WrDecodeArgs A) {
         for (int g = 0; g < 32; g++) {
             const unsigned long long pb = pbase[2 * g + sub];
             elt v = 0;
-            if (pb != 0ull && i < n) v = ((const elt *)(uintptr_t)pb)[off];
+            // (global address space: a FLAT load would count on lgkmcnt too, and the wait for the LDS writes below would wait for it)
+            if (pb != 0ull && i < n) v = ((const __attribute__((address_space(1))) elt *)pb)[off];
             pre[g] = v;
         }
     };
