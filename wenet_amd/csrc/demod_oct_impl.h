@@ -1,19 +1,19 @@
-// demod_oct_impl.h -- the BATCH demodulator: eight captures per workgroup, ONE wavefront per capture, no speculation.
+// demod_oct_impl.h -- the BATCH demodulator: G captures per workgroup, ONE wavefront per capture, one duty wavefront for everything narrow.
 //
 // Why (round 2).  The pipelined kernels (demod_pipe_impl.h, demod_tri_impl.h) overlap the stages of neighbouring frames of one
 // capture; that is what makes a single stream fast, but for batches it pays twice: the order-dependent recurrences of the
 // reference (NCO chain fsk.c:798,824 -- 4 lanes per capture; timing sum fsk.c:870-874 -- 2 lanes) are issued once per one or
 // three captures, every stage needs rings in LDS (45 KB per capture), and each timing slip costs three re-run steps.  A batch
-// has its parallelism ACROSS captures, so here a capture is processed strictly frame after frame (nin(k+1) is known before
-// frame k+1 starts -- slips are free) by one wavefront that does all the WIDE stages of its capture, and the two NARROW
-// stages are done for all eight captures of the workgroup at once by two extra wavefronts:
+// has its parallelism ACROSS captures, so here a capture is processed by one wavefront that does all the WIDE stages of its
+// capture, and the NARROW stages are done for all captures of the workgroup at once by one extra wavefront:
 //
-//     waves 0..7   capture wave c:  E(k) estimator | mix + slot-ordered integrate + timing products | atan2f, nin, decisions
-//     duty wave    NCO chains of the captures (lane 2c + m = tone m of capture c), a checkpoint every Ts/2 steps;
-//                  later in the frame the ordered timing sums of the captures (lanes 2c, 2c+1 = re, im)
+//     waves 0..G-1  capture wave c:  E(k) estimator | mix + slot-ordered integrate + timing products | resampling, decisions
+//     duty wave     NCO chains of the captures (lanes 2 (M c + m), +1 = re, im of tone m of capture c), a checkpoint every Ts/2
+//                   steps; the ordered timing sums of the captures (lanes 2c, 2c+1 = re, im); their timing estimates (lane 2c)
 //
-// Per frame: [E(k)] barrier [chain(k)] barrier [mix/integrate(k)] barrier [sums(k)] barrier [decide(k), E(k+1)] ...  Two such
-// workgroups share a CU (62 KB of LDS each), so one group's narrow phases run under the other's wide ones.
+// Exact mode runs the run-ahead schedule described at the frame loop: the chain of frame k+1 under the mix stage of frame k, two
+// workgroup barriers per frame.  Two such workgroups share a CU (80 KB of LDS each at G = 7), so one group's narrow phases run
+// under the other's wide ones.
 //
 // Data movement: no sample ring.  A capture wave reads its frame straight from HBM -- lane l owns the Ts samples of symbol
 // slot l (buffer positions Ts*l .. Ts*l+Ts-1 of the reference's Nmem-sample window), loaded one frame ahead -- mixes them with
@@ -21,10 +21,10 @@
 // through LDS: the reference sums the Ts circular-buffer slots in slot order (fsk.c:829-840), which for output i = Ts*l + r is
 //        (prefix of length r of block l+1, summed left to right)  then  + d[Ts*l+r] + ... + d[Ts*l+Ts-1]
 // i.e. the neighbour lane's running prefix sum (one DPP read) continued with the lane's own tail: 55 adds per component and
-// block instead of 100, no index arithmetic, no bank conflicts.  The integrator outputs stay in registers; after the timing
-// estimate the two outputs a symbol is resampled from (fsk.c:913-934) sit in the symbol's own lane or its neighbour.
+// block instead of 100, no index arithmetic, no bank conflicts.  The integrator outputs the resampler may ask for are parked in a
+// per-capture scratch block in global memory (L2) and read back after the timing estimate.
 //
-// FAST = true (parity-ladder rung P3): same skeleton without waves 8 and 9 and without barriers.  The NCO
+// FAST = true (parity-ladder rung P3): the capture waves alone, no duty wave, no barriers.  The NCO
 // phasor of sample s is read from the FFT twiddle table (tone frequencies are bin centres: e^{-j 2 pi bin s / Ndft} exactly
 // periodic), the window sums use block prefix differences, the timing sum is a lane-local sum plus a wave reduction.  Tone bins
 // are computed by the same estimator from the same samples (identical while nin is), nin from the fast timing estimate; a frame
@@ -162,7 +162,11 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
     constexpr int H = TS / 2;                                            // checkpoint spacing = the unit of a timing slip
     constexpr WoLayout LY = wo_layout(M, TS, NDFT, FAST);                // LDS carve-up (wenet_internal.h; the host fills cfg.o_* from the same function)
     constexpr bool SMALL = (NDFT == 256);                                // all tables in LDS, samples fetched a frame ahead
-    constexpr bool AHEAD = SMALL && !FAST;                               // the run-ahead schedule of the frame loop (see there)
+    constexpr bool AHEAD = !FAST;                                        // the run-ahead schedule of the frame loop (see there)
+    // form of the duty wave's NCO chain: lane-split (plain instructions, half the SIMD time of the packed form) in the run-ahead schedule,
+    // where the capture waves on the duty wave's SIMD are busy meanwhile -- measured better for the 4-FSK geometry too (1 568 steps per
+    // frame, two capture waves per workgroup: 466 against 483 ms for 1024 captures)
+    constexpr bool SPLIT = AHEAD;
     constexpr unsigned ALLOUT = TS == 32 ? 0xffffffffu : (1u << TS) - 1u;
     constexpr int NSD = M == 2 ? 1 : 2;                                  // soft decisions per symbol (fsk.c:955-980)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -249,7 +253,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
     // chain costs here -- the capture waves wait for it -- so it runs in the packed form: three dependent instructions per step.)
     v2f own = {1.f, 0.f};
     float own_s = 0.f;                                                   // run-ahead schedule: lane 2 (M c + m) + part carries one component (nco_steps_split)
-    if (is_chain && AHEAD) {
+    if (is_chain && SPLIT) {
         const int q = lane >> 1, cc = q / M, m = q % M;
         const int chc = blockIdx.x * G + cc;
         own_s = (lane & 1) ? 0.f : 1.f;
@@ -803,7 +807,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
         const int nold = Nmem - nin_j;
         const int bc = CTc[OC_CBC + m], bp = CTc[OC_CBP + m];
         const int ncase = (nin_j < N) ? 0 : ((nin_j > N) ? 2 : 1);
-        const float2 bo = (ncase == 1) ? ((const float2 *)(smem_all + (G * LY.stride + LY.BACK)))[bp] : back_t[ncase * NH + bp];
+        const float2 bo = (SMALL && ncase == 1) ? ((const float2 *)(smem_all + (G * LY.stride + LY.BACK)))[bp] : back_t[ncase * NH + bp];
         own_s = nco_step_split(own_s, bo.x, part ? bo.y : -bo.y);       // fsk.c:758-759: the products and sums of cmul_pk(bo, own)
         const float2 d0 = dphi_t[bp], d1 = dphi_t[bc];
         float k1 = d0.x, k2 = part ? d0.y : -d0.y;
@@ -877,26 +881,9 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
     };
 
     // ================================ frame loop ===============================================
-    // Exact mode, per frame k (four workgroup barriers):
-    //   A  duty wave: NCO chains of frame k, started as soon as every capture has published nin(k) and its tone bins (an LDS
-    //      sequence word per capture: no barrier)    | capture waves: decisions and outputs of frame k-1, then the FFT of E(k+1)
-    //      AHEAD, assuming nin(k+1) = N (they would idle otherwise)
-    //   B  capture waves: mix / integrate / timing products of frame k
-    //   C  duty wave: ordered timing sums of frame k  | capture waves: smoothing and tone search of E(k+1)
-    //   D  capture waves: timing estimate and nin(k+1); if nin(k+1) != N the estimator run of frame k+1 is repeated with the true
-    //      nin (it reads the untouched spectrum of frame k); frame k+1 becomes the frame in work and is published
+    // (exact mode: the run-ahead schedule, described where it starts below; fast mode: every capture wave on its own, no barriers)
     int ran = 0;                                                         // duty wave: captures that demodulated at least one frame
-    auto publish = [&](int nn, bool more, long long seq) __attribute__((always_inline)) {               // inputs of the next frame are final: its chain may start
-        if (lane == 0) {
-            CT[OC_NIN] = nn; CT[OC_ALIVE] = more ? 1 : 0;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __hip_atomic_store(&CT[OC_SEQ], (int)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-    };
-    if (is_cap && !AHEAD) {
-        if (alive) { prefetch_est(0); if (SMALL) prefetch_slot(0, nin); estimate(nin); commit_estimate(); if (!FAST && SMALL) prefetch_est(nin); }
-        if (!FAST) publish(nin, alive, 1);
-    }
+    if (is_cap && FAST && alive) { prefetch_est(0); if (SMALL) prefetch_slot(0, nin); estimate(nin); commit_estimate(); }
     int sw = 0;                                                          // run-ahead schedule: ring slot (FE2) of the spectrum after the frame in work's estimator run
     if (FAST) {
         // no shared stages: every capture wave runs on its own
@@ -919,8 +906,8 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
             alive = more;
             if (alive) { if (SMALL) prefetch_slot(off, nin); else prefetch_est(off); estimate(nin); commit_estimate(); }
         }
-    } else if (AHEAD) {
-        // ---- the run-ahead schedule (small geometries, exact mode) ---------------------------------------------------------------
+    } else {
+        // ---- the run-ahead schedule (exact mode) ---------------------------------------------------------------
         // A capture's frames form one dependency chain: NCO chain(k) -> mix / integrate(k) -> ordered timing sum(k) -> nin(k+1) ->
         // chain(k+1).  Run in that order (the loop below this one) the duty wave idles through the wide stage and the capture waves
         // through the chain.  Here the duty wave runs chain(k+1) DURING mix / integrate(k), assuming nin(k+1) = N -- true for all but the
@@ -974,12 +961,13 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
         };
         if (is_cap) {
             if (lane == 0) { CT[OC_FLAGS] = 0; CT[OC_ORD] = 0; ((float *)CT)[OC_PV] = 0.f; ((float *)CT)[OC_PV + 1] = 0.f; }
-            if (alive) { prefetch_est(0); prefetch_slot(0, nin); }       // frame 0 starts like a frame after a slip, without a guess
+            if (alive) { prefetch_est(0); if (SMALL) prefetch_slot(0, nin); }       // frame 0 starts like a frame after a slip, without a guess
             request(0, nin, b_w, b_pv, ckpar, alive, 1);
         }
         // One copy of the loop per role: a wave never changes its role, so inside its copy only that role's values are live.
         if (is_chain) {
             float own_m1 = own_s;                                        // the phasors before the last chain that was run
+            v2f own_m1p = own;                                           // (packed form)
             int mask = (1 << G) - 1;
             int selfmask = 0;                                            // captures whose next chain is the speculative one they wrote down beforehand
             for (long long kf = 0;; kf++) {
@@ -988,15 +976,16 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
                         while (__hip_atomic_load((int *)&CT0[c * ctw + OC_SEQ], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (int)(kf + 1)) __builtin_amdgcn_s_sleep(1);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 WO_STAMP(0);
-                const int cc = lane / (2 * M);
+                constexpr int LPC = SPLIT ? 2 * M : M;                   // chain lanes per capture
+                const int cc = lane / LPC;
                 int req = 0;
                 if (cc < G && ((mask >> cc) & 1)) req = CT0[cc * ctw + OC_REQ];
-                if (req == OC_REQ_SPEC) own_m1 = own_s;
-                else if (req == OC_REQ_TRUE || req == OC_REQ_DEAD) own_s = own_m1;
+                if (req == OC_REQ_SPEC) { own_m1 = own_s; own_m1p = own; }
+                else if (req == OC_REQ_TRUE || req == OC_REQ_DEAD) { own_s = own_m1; own = own_m1p; }
                 const unsigned long long bal = __ballot(req == OC_REQ_SPEC || req == OC_REQ_TRUE);
                 int m2 = 0;
-                for (int c = 0; c < G; c++) m2 |= (int)((bal >> (c * 2 * M)) & 1ull) << c;
-                if (m2) { chain_split(m2); ran |= m2; }
+                for (int c = 0; c < G; c++) m2 |= (int)((bal >> (c * LPC)) & 1ull) << c;
+                if (m2) { if (SPLIT) chain_split(m2); else chain(m2); ran |= m2; }
                 WO_STAMP(1);
                 lds_barrier();                                           // timing products of the frames in work; checkpoints of the requested chains
                 WO_STAMP(2);
@@ -1046,7 +1035,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
                 if (alive) {
                     if (ready) {
                         dstage(off, nin, omask, true);
-                        prefetch_slot(off + nin, N);                     // the next frame's samples, assuming nin = N (fetched again after a slip)
+                        if (SMALL) prefetch_slot(off + nin, N);          // the next frame's samples, assuming nin = N (fetched again after a slip)
                     }
                     // estimator runs of this phase: after a slip E(k) with the true nin (tone search included), then -- always, unless it is done
                     // already -- the FFT of the newest frame the schedule looks at, assuming it (and the frames before it) have nin = N
@@ -1120,7 +1109,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
                             omask = ALLOUT;
                             if (lane == 0) CT[OC_FLAGS] = 2 | 4;          // (all outputs parked; the sums of the second pass are this frame's again)
                             request(0, nin, b_w, b_pv, ckpar, true, kf + 2);
-                            prefetch_slot(off, nin);                     // (this frame's samples again)
+                            if (SMALL) prefetch_slot(off, nin);          // (this frame's samples again)
                         } else {
                             if (ordered) {                               // the rest of tstage1b(): fsk.c:887-896
                                 const float d_nrt = o_nrt - norm_rx_timing_st;
@@ -1158,7 +1147,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
                                 CT[OC_FLAGS] = (fastok ? 1 : 0) | (omask == ALLOUT ? 2 : 0) | (more && ready ? 4 : 0);
                                 ((float *)CT)[OC_PV] = pv_r; ((float *)CT)[OC_PV + 1] = pv_i;
                             }
-                            if (more && nn != N) { prefetch_slot(off1, nn); prefetch_est(off1); }
+                            if (more && nn != N) { if (SMALL) prefetch_slot(off1, nn); prefetch_est(off1); }
                             WO_SUB(4);
                             tstage2_finish(frames);
                             WO_SUB(5);
@@ -1198,83 +1187,6 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
 #endif
 #undef WO_STAMP
 #undef WO_SUB
-    } else {
-        if (is_chain) __builtin_amdgcn_s_setprio(2);                     // the serial wave wins VALU arbitration against the wide ones
-        // development (WENET_RX_PROFILE=4): cycles of wave 0 and of the duty wave per section, summed over the frames:
-        //   wave 0: [0] decide + E ahead + wait for the chains  [1] mix / integrate (to its barrier)  [2] wait for the sums  [4] decide + E ahead busy
-        //   duty wave (+8): [0] wait for nin  [1] chains  [2] barrier wait  [3] sums   [6] frames
-        const bool pp = C.prof != nullptr && lane == 0 && (wave == 0 || is_chain);
-        long long *pr = C.prof + (is_chain ? 8 : 0);
-        long long pt[6] = {0, 0, 0, 0, 0, 0}, t0 = pp ? (long long)__builtin_readcyclecounter() : 0;
-#define WO_STAMP(k) do { if (pp) { const long long t1 = (long long)__builtin_readcyclecounter(); pt[k] += t1 - t0; t0 = t1; } } while (0)
-        int mask = (1 << G) - 1;                                         // captures whose next frame is awaited
-        long long kf = 0;                                                // frame index within this launch (lock-step over the group)
-        for (;;) {
-            if (is_chain) {
-                // frame kf of every capture that was alive: wait until its nin / bins / alive flag are published, then run the chains
-                for (int c = 0; c < G; c++)
-                    if ((mask >> c) & 1)
-                        while (__hip_atomic_load((int *)&CT0[c * ctw + OC_SEQ], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (int)(kf + 1)) __builtin_amdgcn_s_sleep(2);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                WO_STAMP(0);
-                const int m2 = alive_mask() & mask;
-                if (m2) { chain(m2); ran |= m2; }
-                WO_STAMP(1);
-            } else if (alive) {
-                if (!SMALL) prefetch_est(off + nin);                     // (large geometry: the samples are loaded where they are used)
-                estimate_fft(N);                                         // E(k+1) ahead, first half ...
-                if (SMALL) prefetch_est(off + nin + N);                  // ... then the samples of E(k+2), one frame ahead again
-                if (pp) { pt[4] += (long long)__builtin_readcyclecounter() - t0; }
-            }
-            lds_barrier();                                               // checkpoints of frame k; every capture's flags are final
-            WO_STAMP(is_chain ? 2 : 0);
-            mask &= alive_mask();
-            if (!mask) break;
-            const long long off1 = off + nin;
-            if (is_cap && alive) dstage(off, nin, omask, true);
-            lds_barrier();                                               // timing products
-            WO_STAMP(is_chain ? 2 : 1);
-            if (is_sum) tsum(mask);
-            else if (alive) estimate_pick();                             // E(k+1) ahead, second half (under the sums)
-            lds_barrier();                                               // timing sums
-            WO_STAMP(is_chain ? 3 : 2);
-            if (is_cap && alive) {
-#pragma unroll
-            for (int m = 0; m < M; m++) t_bins[m] = CT[OC_FBIN + m];
-                __builtin_amdgcn_s_setprio(1);
-                const int nn = tstage1a();
-                // do the parked outputs cover this frame's resampling points?  Sure if everything was parked or the timing vector is
-                // near the previous one's; otherwise look (exact rx_timing) and, on a miss, integrate the frame again -- before the
-                // next frame's chains may overwrite the checkpoints
-                bool did_1b = false;
-                const bool near_prev = timing_near_previous();
-                if (omask != ALLOUT && !near_prev) {
-                    tstage1b(); did_1b = true;
-                    if (!t_nan && !(((omask >> (t_low >= 0 ? t_low : TS + t_low)) & (omask >> (t_high >= 0 ? t_high : TS + t_high))) & 1))
-                        dstage(off, nin, ALLOUT, false);
-                }
-                const bool more = off1 + nn <= C.nsamples && frames + 1 < C.cap_frames;
-                if (more) {
-                    if (nn != N) { prefetch_est(off1); estimate(nn); }                               // (a timing slip: E(k+1) again)
-                    commit_estimate();
-                }
-                publish(nn, more, kf + 2);                               // -> the duty wave starts the chains of frame k+1 ...
-                __builtin_amdgcn_s_setprio(0);
-                if (!did_1b) tstage1b();
-                omask = (!t_nan && near_prev) ? window_mask(t_low) : ALLOUT;
-                pv_r = t_nan ? 0.f : t_tcr; pv_i = t_nan ? 0.f : t_tci;
-                if (pp) { const long long t1 = (long long)__builtin_readcyclecounter(); pt[3] += t1 - t0; }
-                tstage2(frames);                                         // ... while this wave resamples, decides and writes frame k
-                if (more && SMALL) { prefetch_slot(off1, nn); if (nn != N) prefetch_est(off1 + nn); }
-                if (pp) { const long long t1 = (long long)__builtin_readcyclecounter(); pt[5] += t1 - t0; }
-                nslip += (nn != N) ? 1 : 0;
-                off = off1; nin = nn; frames++;
-                alive = more;
-            }
-            kf++;
-        }
-        if (pp) { for (int k = 0; k < 6; k++) pr[k] = pt[k]; if (!is_chain) pr[6] = frames; }
-#undef WO_STAMP
     }
 
     // ================================ save carried state =======================================
@@ -1299,7 +1211,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
             hdr->consumed_call = off;
         }
     }
-    if (is_chain && AHEAD) {
+    if (is_chain && SPLIT) {
         const int q = lane >> 1, cc = q / M, m = q % M;
         const int chc = blockIdx.x * G + cc;
         if (cc < G && chc < nchan && ((ran >> cc) & 1)) {

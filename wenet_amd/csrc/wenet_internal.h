@@ -88,7 +88,7 @@ struct WoLayout { int FB, FW, TP, FE, CK, CT, stride, ntw, TW, HANN, DPHI, SRC, 
 constexpr int wo_align16(int x) { return (x + 15) & ~15; }
 constexpr WoLayout wo_layout(int M, int Ts, int Ndft, bool fast) {
     WoLayout y{};
-    const bool small = Ndft == 256, ahead = small && !fast;
+    const bool small = Ndft == 256, ahead = !fast;
     const int NH = Ndft / 2, NI = 49 * Ts, NIq = (NI + 3) & ~3, H = Ts / 2, L = 50 * Ts - 1;
     y.nhb = (L + H - 1) / H;
     int t = 0;
@@ -100,7 +100,7 @@ constexpr WoLayout wo_layout(int M, int Ts, int Ndft, bool fast) {
     y.CK = t;  t = wo_align16(t + (ahead ? 2 : (fast ? 0 : 1)) * M * y.nhb * 8);
     y.CT = t;  t = wo_align16(t + 32 * 4);
     y.stride = ahead ? ((t + 31) & ~31) : ((t + 127) & ~127);
-    y.ntw = ahead ? 192 : Ndft;
+    y.ntw = ahead ? 3 * Ndft / 4 : Ndft;                             // (the transform's largest twiddle index is 3 (Ndft/4 - 1))
     int tab = 0;
     y.TW = tab;   tab = wo_align16(tab + y.ntw * 8);
     y.HANN = tab; tab = wo_align16(tab + Ndft * 4);
