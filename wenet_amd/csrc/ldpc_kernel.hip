@@ -108,13 +108,15 @@ namespace {
 // reference truncates y to an integer and walks thresholds; "trunc(y) >= T" equals "y >= T" for integer T, and
 // within one table cell phi0 steps at most once, so one ordered compare of the raw bits finishes the job.  The
 // clamped key also covers y < 1, negatives and NaN/Inf/overflow (x86 cvttss2si -> INT_MIN -> 10.0).  No branches.
+// Two 4-byte LDS reads instead of one 12-byte read: the threshold of the cell, then the value below or above it (val[2 cell + above]).
+// The decode kernel is bound by LDS bandwidth, most of it the random 96-bit table reads (6 clocks per wavefront before bank conflicts).
 __device__ __forceinline__ float phi0_dev(float xf, const uint4 *lut) {
-    const int b = __float_as_int(xf);                           // (thresholds and keys carry the 2^16 of x = (int)(xf*65536), phi0.c:10,14)
-    // clamp the raw key (one v_med3_i32) and fold the bias into the table base: four instructions to the LDS read instead of six
-    const int key = min(max(b >> 18, WR_PHI0_KEY_BIAS), WR_PHI0_KEY_BIAS + WR_PHI0_LUT_ENTRIES - 1);
-    typedef unsigned v3u __attribute__((ext_vector_type(3)));          // 12 of the entry's 16 bytes: a 96-bit LDS read (6 clocks per wavefront instead of 8)
-    const v3u e = *(const v3u *)((const char *)lut + (key - WR_PHI0_KEY_BIAS) * 16);
-    return __uint_as_float((b >= (int)e.x) ? e.z : e.y);
+    const int b = __float_as_int(xf);
+    const int key = min(max(b >> 18, WR_PHI0_KEY_BIAS), WR_PHI0_KEY_BIAS + WR_PHI0_LUT_ENTRIES - 1) - WR_PHI0_KEY_BIAS;
+    const int *thr = (const int *)lut;
+    const float *val = (const float *)(thr + WR_PHI0_LUT_ENTRIES + 2);
+    const int t = thr[key];
+    return val[2 * key + (b >= t ? 1 : 0)];
 }
 
 __device__ __forceinline__ float with_sign(float mag, int neg) {
@@ -288,7 +290,13 @@ __global__ __launch_bounds__(WR_DEC_THREADS, 8) void wenet_decode_kernel(WrDecod
     // ---- once per workgroup: phi0 LUT into LDS; this thread's variables (LdpcTables::place_variables: the data variables are dealt
     //      to the positions tid + 512 t so that the variable pass loads the LDS banks evenly) and their edge addresses into registers.
     //      Positions t = 0..3 hold data bits (degree 3) for every thread; t = 4 straddles the data/parity boundary, t = 5 is parity or nothing.
-    for (int i = tid; i < WR_PHI0_LUT_ENTRIES; i += WR_DEC_THREADS) lut[i] = A.phi0_lut[i];
+    for (int i = tid; i < WR_PHI0_LUT_ENTRIES; i += WR_DEC_THREADS) {
+        const uint4 e = A.phi0_lut[i];
+        int *thr = (int *)lut;
+        unsigned *val = (unsigned *)(thr + WR_PHI0_LUT_ENTRIES + 2);
+        thr[i] = (int)e.x; val[2 * i] = e.y; val[2 * i + 1] = e.z;
+    }
+
     int ea[WR_VARS_PER_THREAD][3], deg[WR_VARS_PER_THREAD];
     // (the variable numbers themselves are needed twice per packet only -- LLR in, bit out -- and are re-read there: six registers
     //  held across the iterations would cost the fourth workgroup per CU)
