@@ -58,6 +58,42 @@ def test_exact_mode_equals_oracle(name, group, monkeypatch):
     rx.close()
 
 
+@pytest.mark.parametrize("group", [7, 2])
+def test_rare_paths_of_the_run_ahead_schedule(group, monkeypatch):
+    """Inputs that leave the common path of the run-ahead schedule on most frames: pure noise (the timing vector turns at random: the
+    speculative chain is void on every second frame, the parked integrator outputs miss the resampling points), a signal that stops
+    and starts again, a signal whose symbol timing jumps by a few samples, a burst after silence.  Every capture equals the oracle."""
+    monkeypatch.setenv("WENET_RX_OCT", str(group))
+    cfg = siggen.CONFIGS["v2"]()
+    rng = np.random.default_rng(77)
+    a = siggen.make_capture(cfg, 3, 9.0, seed=901)[0]
+    b = siggen.make_capture(cfg, 3, 9.0, seed=902)[0]
+    fr = 2 * cfg.Ts * 48                                          # bytes per nominal frame
+    noise = lambda n: rng.integers(96, 160, n, dtype=np.uint8)    # noqa: E731
+    caps = [noise(fr * 60),                                       # noise only
+            np.concatenate([a[:fr * 30], noise(fr * 25), b[:fr * 30]]),                         # signal, noise, signal
+            np.concatenate([a[:fr * 25 + 2 * 3], b[fr * 7:fr * 40]]),                           # timing (and phase) jump in mid-stream
+            np.concatenate([np.full(fr * 12, 127, np.uint8), a[:fr * 35]]),                     # burst after silence
+            np.concatenate([a[:fr * 20], np.full(fr * 10 + 14, 127, np.uint8), a[fr * 20:]]),   # a hole of silence, odd length
+            rng.integers(0, 256, fr * 40, dtype=np.uint8),                                      # full-scale noise
+            a, b]
+    rx = RxBatch(cfg.Fs, cfg.Rs, cfg.M, framing=cfg.mode)
+    rx.enable_trace()
+    rx.process(caps, "cu8")
+    assert rx.last_kernel() == "wenet_demod_oct_kernel"
+    slips = 0
+    for i, c in enumerate(caps):
+        sd, tr = ol.oracle_demod(c, "cu8", cfg.Fs, cfg.Rs, cfg.M, want_trace=True)
+        assert bits_equal(rx.soft(i), sd), i
+        assert bits_equal(np.ascontiguousarray(rx.trace(i)[:, :7]), np.ascontiguousarray(tr[:, :7])), i
+        ref = ol.oracle_deframe(sd, cfg.mode)
+        p = rx.packets(i)
+        assert p["n"] == ref["n"] and (p["bytes"] == ref["bytes"]).all()
+        slips += int((tr[:, 4] != cfg.Ts * 48).sum())
+    assert slips > 60                                              # (noise: |norm_rx_timing| > 0.25 on about every second frame)
+    rx.close()
+
+
 def test_large_batch_picks_the_kernel_by_itself():
     """From six captures per CU on the library takes the one-wavefront-per-capture kernel without being told; spot-check captures
     of such a batch against the oracle."""
