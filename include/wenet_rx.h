@@ -213,6 +213,10 @@ float wenet_rx_last_ms(wenet_rx *rx, int what);
 int wenet_rx_device_info(int what);
 const char *wenet_rx_version(void);
 
+/* self-test: phi0 (src/phi0.c:13-218) exactly as the decode kernel evaluates it on the device (keyed LDS tables), y[i] = phi0(x[i]) for n
+ * host floats.  0 on success.  (The library also checks the tables on the host against the reference form when it builds them.) */
+int wenet_phi0_eval(const float *x, float *y, long n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -494,6 +494,25 @@ __global__ __launch_bounds__(WR_DEC_THREADS, 8) void wenet_decode_kernel(WrDecod
 
 
 
+// self-test entry (wenet_phi0_eval, include/wenet_rx.h): the device phi0 of the decoder on n arguments, through the same LDS tables
+__global__ __launch_bounds__(256) void wenet_phi0_kernel(const uint4 *lut_g, const float *x, float *y, long long n) {
+    __shared__ __attribute__((aligned(16))) uint4 lut[WR_PHI0_LUT_ENTRIES];
+    for (int i = threadIdx.x; i < WR_PHI0_LUT_ENTRIES; i += 256) {
+        const uint4 e = lut_g[i];
+        int *thr = (int *)lut;
+        unsigned *val = (unsigned *)(thr + WR_PHI0_LUT_ENTRIES + 2);
+        thr[i] = (int)e.x; val[2 * i] = e.y; val[2 * i + 1] = e.z;
+    }
+    __syncthreads();
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] = phi0_dev(x[i], lut);
+}
+extern "C" hipError_t wr_launch_phi0(const uint4 *d_lut, const float *d_x, float *d_y, long long n, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    const unsigned grid = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(wenet_phi0_kernel, dim3(grid), dim3(256), 0, stream, d_lut, d_x, d_y, n);
+    return hipGetLastError();
+}
+
 extern "C" hipError_t wr_launch_deframe(const WrDeframeChan *d_chans, int nchan, int mode, hipStream_t stream) {
     if (nchan <= 0) return hipSuccess;
     hipLaunchKernelGGL(wenet_deframe_kernel, dim3(nchan), dim3(64), 0, stream, d_chans, nchan, mode);

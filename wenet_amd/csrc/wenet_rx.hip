@@ -28,6 +28,7 @@ extern "C" hipError_t wr_launch_demod_ex(const WrDemodCfg *cfg, const WrChan *d_
 extern "C" hipError_t wr_launch_demod_oct(const WrDemodCfg *cfg, const WrChan *d_chans, int nchan, hipStream_t stream, int fast);
 extern "C" hipError_t wr_launch_deframe(const WrDeframeChan *d_chans, int nchan, int mode, hipStream_t stream);
 extern "C" hipError_t wr_launch_decode(const WrDecodeArgs *args, hipStream_t stream);
+extern "C" hipError_t wr_launch_phi0(const uint4 *d_lut, const float *d_x, float *d_y, long long n, hipStream_t stream);
 
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
@@ -1399,5 +1400,18 @@ extern "C" int wenet_rx_device_info(int what) {
     if (hipGetDeviceProperties(&p, dev) != hipSuccess) return -1;
     if (what == 1) return p.multiProcessorCount;
     return -1;
+}
+// self-test: phi0 (phi0.c) as the decode kernel evaluates it on the device, for n host arguments
+extern "C" int wenet_phi0_eval(const float *x, float *y, long n) {
+    if (!x || !y || n < 0) return -1;
+    LdpcTables *t = ldpc_tables();
+    if (!t) return -2;
+    if (n == 0) return 0;
+    DevBuf dx, dy;
+    if (!dx.reserve((size_t)n * 4) || !dy.reserve((size_t)n * 4)) return -2;
+    WR_CHECK(hipMemcpy(dx.p, x, (size_t)n * 4, hipMemcpyHostToDevice), -3);
+    WR_CHECK(wr_launch_phi0(t->d_lut, dx.as<float>(), dy.as<float>(), n, 0), -4);
+    WR_CHECK(hipMemcpy(y, dy.p, (size_t)n * 4, hipMemcpyDeviceToHost), -3);
+    return 0;
 }
 extern "C" const char *wenet_rx_version(void) { return "wenet_rx 0.1 (gfx950)"; }
