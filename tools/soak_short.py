@@ -1,0 +1,29 @@
+import os, sys
+import numpy as np
+ROOT = "/root/repo"
+sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/tests")
+import torch  # noqa
+import oracle_lib as ol
+from wenet_amd import siggen
+from wenet_amd.rx import RxBatch
+bad = 0
+for name, grp in (("v2", "7"), ("v1", "4"), ("4fsk", "2")):
+    os.environ["WENET_RX_OCT"] = grp
+    cfg = siggen.CONFIGS[name]()
+    rng = np.random.default_rng(3)
+    base = siggen.make_capture(cfg, 2, 9.0, seed=5, ppm=300.0)[0]
+    N = cfg.Ts * 48
+    lens = [0, 1, N - 6, N - 5, N - 1, N, N + 1, N + cfg.Ts // 2 - 1, N + cfg.Ts // 2, N + cfg.Ts // 2 + 1, 2 * N - 5, 2 * N, 2 * N + 7, 3 * N + 3] + \
+           [int(x) for x in rng.integers(0, 6 * N, 40)]
+    caps = [base[2 * int(rng.integers(0, 50)):][:2 * L].copy() for L in lens]
+    rx = RxBatch(cfg.Fs, cfg.Rs, cfg.M, framing=cfg.mode)
+    rx.process(caps, "cu8")
+    assert "oct" in rx.last_kernel(), rx.last_kernel()
+    for i, c in enumerate(caps):
+        sd, _ = ol.oracle_demod(c, "cu8", cfg.Fs, cfg.Rs, cfg.M) if c.size else (np.zeros(0, np.float32), None)
+        g = rx.soft(i)
+        if g.size != sd.size or not (g.view(np.uint32) == sd.view(np.uint32)).all():
+            bad += 1; print("MISMATCH", name, lens[i], g.size, sd.size)
+    rx.close()
+print("short soak mismatches", bad)
+sys.exit(1 if bad else 0)
