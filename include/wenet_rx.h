@@ -197,7 +197,8 @@ long long wenet_rx_get_llrs(wenet_rx *rx, int ch, float *llr, long long cap_pack
  * decision, LLR and packet byte is bit-identical to the reference pipe.  1 = fast mode, rung P3: table phasors instead of the
  * NCO recurrence (src/fsk.c:798,824), tree sums instead of the ordered ones (fsk.c:833-840,870-874); tone bins and nin are
  * computed as in exact mode, a capture with a frame whose timing estimate fell within the guard band of a nin threshold
- * (fsk.c:900-907) is re-run through the exact kernel by the same call.  Soft decisions then agree to ~1e-6 relative. */
+ * (fsk.c:900-907) is re-run through the exact kernel by the same call.  Soft decisions then agree to 1e-4 of the frame maximum, LLRs to 2e-5 relative
+ * (the rounding noise of the reference's own float32 timing sum; tests/test_gpu_oct.py).  Measured slower than the exact mode: an option, not the default. */
 void wenet_rx_set_fast(wenet_rx *rx, int on);
 /* captures of the last fast-mode batch that were demodulated a second time by the exact kernel */
 long long wenet_rx_fast_reruns(wenet_rx *rx);

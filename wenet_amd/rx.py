@@ -36,7 +36,7 @@ class RxBatch:
         self._L.wenet_rx_enable_llr_dump(self._h, 1 if on else 0)
 
     def set_fast(self, on=True):
-        """fast mode (parity-ladder rung P3, include/wenet_rx.h): soft decisions within ~1e-6 of the reference's instead of bit-identical."""
+        """fast mode (parity-ladder rung P3, include/wenet_rx.h): LLRs within 2e-5 relative of the reference's instead of bit-identical (slower than exact mode: DESIGN.md 7)."""
         self._L.wenet_rx_set_fast(self._h, 1 if on else 0)
 
     def fast_reruns(self):
