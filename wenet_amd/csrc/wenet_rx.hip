@@ -968,7 +968,17 @@ struct wenet_rx {
     std::vector<ChunkEv> cev;
     int nchunks = 0;
     hipStream_t stream = nullptr;
-    hipStream_t copy_stream = nullptr;      // host-fed batches: H2D of sub-batch k+1 runs under the kernels of sub-batch k
+    hipStream_t copy_stream = nullptr;      // host-fed batches: H2D of sub-batch k+1 runs under the kernels of sub-batch k; results: D2H behind each decode launch
+    hipEvent_t copied_all = nullptr;        // the last result copy of the batch in flight
+    std::vector<hipEvent_t> part_ev;        // one per decode launch
+    hipEvent_t part_event(int i) {
+        while ((int)part_ev.size() <= i) {
+            hipEvent_t ev = nullptr;
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return nullptr;
+            part_ev.push_back(ev);
+        }
+        return part_ev[i];
+    }
     bool pending = false;
     bool chunk_events(int n) {
         while ((int)cev.size() < n) {
@@ -982,6 +992,8 @@ struct wenet_rx {
     ~wenet_rx() {
         for (auto &c : cev) { for (auto &e : c.ev) if (e) (void)hipEventDestroy(e); if (c.copied) (void)hipEventDestroy(c.copied); }
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
+        if (copied_all) (void)hipEventDestroy(copied_all);
+        for (hipEvent_t ev : part_ev) (void)hipEventDestroy(ev);
         if (h_pin) (void)hipHostFree(h_pin);
     }
 };
@@ -1152,7 +1164,14 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const lon
     bounds.push_back(nchan);
     rx->nchunks = (int)bounds.size() - 1;
     if (!rx->chunk_events(rx->nchunks)) return -4;
-    if (host_src && !rx->copy_stream) WR_CHECK(hipStreamCreateWithFlags(&rx->copy_stream, hipStreamNonBlocking), -4);
+    if (!rx->copy_stream) WR_CHECK(hipStreamCreateWithFlags(&rx->copy_stream, hipStreamNonBlocking), -4);
+    {   // the results' pinned host buffer: packet slots, then their start offsets (filled part by part behind the decode launches)
+        const size_t n_slots = (size_t)nchan * max_pk;
+        const size_t out_bytes = n_slots * sizeof(WrPacketOut), st_bytes = n_slots * 8;
+        if (!rx->pin_reserve(out_bytes + st_bytes + 64)) return -2;
+        rx->h_out = (WrPacketOut *)rx->h_pin;
+        rx->h_starts = (long long *)((char *)rx->h_pin + ((out_bytes + 63) & ~(size_t)63));
+    }
     for (int k = 0; k < rx->nchunks; k++) {
         const int lo = bounds[k], hi = bounds[k + 1], n = hi - lo;
         wenet_rx::ChunkEv &e = rx->cev[k];
@@ -1167,7 +1186,6 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const lon
         ak.dchans = a.dchans + lo;
         ak.out = a.out + (size_t)lo * max_pk;
         ak.esn0 = a.esn0 + (size_t)lo * max_pk;
-        ak.work = (unsigned *)(a.esn0 + (size_t)nchan * max_pk) + k;    // one counter per sub-batch, behind the array
         ak.census = a.census + (size_t)lo * WR_CENSUS_CLASSES;
         if (a.llr_out) ak.llr_out = a.llr_out + (size_t)lo * max_pk * WR_NCODE;
         WR_CHECK(hipEventRecord(e.ev[0], stream), -4);
@@ -1207,9 +1225,33 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const lon
         WR_CHECK(hipEventRecord(e.ev[1], stream), -4);
         WR_CHECK(wr_launch_deframe(rx->d_dchans.as<WrDeframeChan>() + lo, n, rx->mode, stream), -4);
         WR_CHECK(hipEventRecord(e.ev[2], stream), -4);
-        WR_CHECK(wr_launch_decode(&ak, stream), -4);
+        // Decode in up to four parts of the sub-batch's captures, each part's packet slots and start offsets copied to pinned host
+        // memory on the copy stream while the next part decodes: the copy-back (280 B per slot, 7 ms for 3584 captures) leaves the
+        // critical path except for the last part's.
+        const int nparts = n >= 1024 ? 4 : 1;
+        for (int p = 0; p < nparts; p++) {
+            const int plo = (int)((long long)n * p / nparts), phi = (int)((long long)n * (p + 1) / nparts);
+            WrDecodeArgs ap = ak;
+            ap.nchan = phi - plo;
+            ap.dchans = ak.dchans + plo;
+            ap.out = ak.out + (size_t)plo * max_pk;
+            ap.esn0 = ak.esn0 + (size_t)plo * max_pk;
+            ap.work = (unsigned *)(a.esn0 + (size_t)nchan * max_pk) + (k * 4 + p);      // one counter per launch, behind the array
+            ap.census = ak.census + (size_t)plo * WR_CENSUS_CLASSES;
+            if (ak.llr_out) ap.llr_out = ak.llr_out + (size_t)plo * max_pk * WR_NCODE;
+            WR_CHECK(wr_launch_decode(&ap, stream), -4);
+            hipEvent_t done = rx->part_event(k * 4 + p);
+            if (!done) return -4;
+            WR_CHECK(hipEventRecord(done, stream), -4);
+            WR_CHECK(hipStreamWaitEvent(rx->copy_stream, done, 0), -4);
+            const size_t s0 = (size_t)(lo + plo) * max_pk, ns = (size_t)(phi - plo) * max_pk;
+            WR_CHECK(hipMemcpyAsync(rx->h_out + s0, rx->d_out.as<WrPacketOut>() + s0, ns * sizeof(WrPacketOut), hipMemcpyDeviceToHost, rx->copy_stream), -3);
+            WR_CHECK(hipMemcpyAsync(rx->h_starts + s0, rx->d_starts.as<long long>() + s0, ns * 8, hipMemcpyDeviceToHost, rx->copy_stream), -3);
+        }
         WR_CHECK(hipEventRecord(e.ev[3], stream), -4);
     }
+    if (!rx->copied_all) WR_CHECK(hipEventCreateWithFlags(&rx->copied_all, hipEventDisableTiming), -4);
+    WR_CHECK(hipEventRecord(rx->copied_all, rx->copy_stream), -4);
     rx->pending = true;
     return 0;
 }
@@ -1236,16 +1278,8 @@ extern "C" int wenet_rx_collect(wenet_rx *rx) {
     }
     rx->h_census.resize((size_t)nchan * WR_CENSUS_CLASSES);
     WR_CHECK(hipMemcpy(rx->h_census.data(), rx->d_census.p, rx->h_census.size() * 4, hipMemcpyDeviceToHost), -3);
-    // packet slots + start offsets: one contiguous device->pinned-host copy each (per-capture copies of only the
-    // filled slots cost ~1000 small transfers for 512 captures)
-    const size_t n_slots = (size_t)nchan * rx->max_pk;
-    const size_t out_bytes = n_slots * sizeof(WrPacketOut), st_bytes = n_slots * 8;
-    if (!rx->pin_reserve(out_bytes + st_bytes + 64)) return -2;
-    rx->h_out = (WrPacketOut *)rx->h_pin;
-    rx->h_starts = (long long *)((char *)rx->h_pin + ((out_bytes + 63) & ~(size_t)63));
-    WR_CHECK(hipMemcpyAsync(rx->h_out, rx->d_out.p, out_bytes, hipMemcpyDeviceToHost, rx->stream), -3);
-    WR_CHECK(hipMemcpyAsync(rx->h_starts, rx->d_starts.p, st_bytes, hipMemcpyDeviceToHost, rx->stream), -3);
-    WR_CHECK(hipStreamSynchronize(rx->stream), -3);
+    // packet slots + start offsets were copied to the pinned host buffer behind each decode launch (rx_enqueue)
+    WR_CHECK(hipEventSynchronize(rx->copied_all), -4);
     rx->pending = false;
     return 0;
 }
