@@ -968,7 +968,8 @@ struct wenet_rx {
     std::vector<ChunkEv> cev;
     int nchunks = 0;
     hipStream_t stream = nullptr;
-    hipStream_t copy_stream = nullptr;      // host-fed batches: H2D of sub-batch k+1 runs under the kernels of sub-batch k; results: D2H behind each decode launch
+    hipStream_t copy_stream = nullptr;      // host-fed batches: H2D of sub-batch k+1 runs under the kernels of sub-batch k
+    hipStream_t res_stream = nullptr;       // results: D2H behind each decode launch (its own stream: uploads and result copies must not queue behind each other)
     hipEvent_t copied_all = nullptr;        // the last result copy of the batch in flight
     std::vector<hipEvent_t> part_ev;        // one per decode launch
     hipEvent_t part_event(int i) {
@@ -992,6 +993,7 @@ struct wenet_rx {
     ~wenet_rx() {
         for (auto &c : cev) { for (auto &e : c.ev) if (e) (void)hipEventDestroy(e); if (c.copied) (void)hipEventDestroy(c.copied); }
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
+        if (res_stream) (void)hipStreamDestroy(res_stream);
         if (copied_all) (void)hipEventDestroy(copied_all);
         for (hipEvent_t ev : part_ev) (void)hipEventDestroy(ev);
         if (h_pin) (void)hipHostFree(h_pin);
@@ -1164,7 +1166,8 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const lon
     bounds.push_back(nchan);
     rx->nchunks = (int)bounds.size() - 1;
     if (!rx->chunk_events(rx->nchunks)) return -4;
-    if (!rx->copy_stream) WR_CHECK(hipStreamCreateWithFlags(&rx->copy_stream, hipStreamNonBlocking), -4);
+    if (host_src && !rx->copy_stream) WR_CHECK(hipStreamCreateWithFlags(&rx->copy_stream, hipStreamNonBlocking), -4);
+    if (!rx->res_stream) WR_CHECK(hipStreamCreateWithFlags(&rx->res_stream, hipStreamNonBlocking), -4);
     {   // the results' pinned host buffer: packet slots, then their start offsets (filled part by part behind the decode launches)
         const size_t n_slots = (size_t)nchan * max_pk;
         const size_t out_bytes = n_slots * sizeof(WrPacketOut), st_bytes = n_slots * 8;
@@ -1243,15 +1246,15 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const lon
             hipEvent_t done = rx->part_event(k * 4 + p);
             if (!done) return -4;
             WR_CHECK(hipEventRecord(done, stream), -4);
-            WR_CHECK(hipStreamWaitEvent(rx->copy_stream, done, 0), -4);
+            WR_CHECK(hipStreamWaitEvent(rx->res_stream, done, 0), -4);
             const size_t s0 = (size_t)(lo + plo) * max_pk, ns = (size_t)(phi - plo) * max_pk;
-            WR_CHECK(hipMemcpyAsync(rx->h_out + s0, rx->d_out.as<WrPacketOut>() + s0, ns * sizeof(WrPacketOut), hipMemcpyDeviceToHost, rx->copy_stream), -3);
-            WR_CHECK(hipMemcpyAsync(rx->h_starts + s0, rx->d_starts.as<long long>() + s0, ns * 8, hipMemcpyDeviceToHost, rx->copy_stream), -3);
+            WR_CHECK(hipMemcpyAsync(rx->h_out + s0, rx->d_out.as<WrPacketOut>() + s0, ns * sizeof(WrPacketOut), hipMemcpyDeviceToHost, rx->res_stream), -3);
+            WR_CHECK(hipMemcpyAsync(rx->h_starts + s0, rx->d_starts.as<long long>() + s0, ns * 8, hipMemcpyDeviceToHost, rx->res_stream), -3);
         }
         WR_CHECK(hipEventRecord(e.ev[3], stream), -4);
     }
     if (!rx->copied_all) WR_CHECK(hipEventCreateWithFlags(&rx->copied_all, hipEventDisableTiming), -4);
-    WR_CHECK(hipEventRecord(rx->copied_all, rx->copy_stream), -4);
+    WR_CHECK(hipEventRecord(rx->copied_all, rx->res_stream), -4);
     rx->pending = true;
     return 0;
 }
