@@ -523,12 +523,13 @@ extern "C" hipError_t wr_launch_decode(const WrDecodeArgs *args, hipStream_t str
     if (args->nchan <= 0 || args->max_pk <= 0) return hipSuccess;
     const long long slots = (long long)args->nchan * args->max_pk;
     const unsigned blocks = (unsigned)((slots + 255) / 256);
-    if (args->input_kind != WR_DEC_IN_LLR)
+    if (args->input_kind != WR_DEC_IN_LLR && args->phase != 2)
     {
         const dim3 sgrid((unsigned)((slots + 63) / 64));
         if (args->input_kind == WR_DEC_IN_SD64) hipLaunchKernelGGL(wenet_llr_stats_kernel<true>, sgrid, dim3(64), 0, stream, *args);
         else hipLaunchKernelGGL(wenet_llr_stats_kernel<false>, sgrid, dim3(64), 0, stream, *args);
     }
+    if (args->phase == 1) return hipGetLastError();
     const int lds = WR_DEC_LDS_BYTES;
     wr_attr_ok(hipFuncSetAttribute((const void *)wenet_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     static int ncu = 0;

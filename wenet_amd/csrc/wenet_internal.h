@@ -213,6 +213,7 @@ struct WrDecodeArgs {
     const uint16_t *vpos;               // [2580] variable handled at position tid + 512 t of the variable pass (LdpcTables::place_variables)
     unsigned       *work;               // persistent decode workgroups: next packet slot to take (zeroed before the launch)
     const uint4    *phi0_lut;           // [90]
+    int             phase;              // wr_launch_decode: 0 = everything, 1 = LLR statistics only, 2 = decode + CRC only (statistics done by an earlier call)
     const uint8_t  *scramble;           // [125]
 };
 

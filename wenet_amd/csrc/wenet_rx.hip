@@ -1232,9 +1232,11 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const lon
         // memory on the copy stream while the next part decodes: the copy-back (280 B per slot, 7 ms for 3584 captures) leaves the
         // critical path except for the last part's.
         const int nparts = n >= 1024 ? 4 : 1;
+        if (nparts > 1) { WrDecodeArgs as = ak; as.phase = 1; WR_CHECK(wr_launch_decode(&as, stream), -4); }      // LLR statistics of the whole sub-batch in one launch
         for (int p = 0; p < nparts; p++) {
             const int plo = (int)((long long)n * p / nparts), phi = (int)((long long)n * (p + 1) / nparts);
             WrDecodeArgs ap = ak;
+            ap.phase = nparts > 1 ? 2 : 0;
             ap.nchan = phi - plo;
             ap.dchans = ak.dchans + plo;
             ap.out = ak.out + (size_t)plo * max_pk;
