@@ -14,6 +14,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--config", default="v1"); ap.add_argument("--seconds", type=float, default=10.0)
 ap.add_argument("--lo", type=float, default=4.0); ap.add_argument("--hi", type=float, default=12.0); ap.add_argument("--n", type=int, default=64)
 ap.add_argument("--check-cpu", type=int, default=3, help="captures to cross-check against the reference CPU pipe")
+ap.add_argument("--bins", type=int, default=0, help="print this many Eb/N0 bins (sums over the captures of a bin) instead of one row per capture")
 a = ap.parse_args()
 cfg = siggen.CONFIGS[a.config]()
 nsym = int(a.seconds * cfg.Rs); nsamp = nsym * cfg.Ts
@@ -38,10 +39,9 @@ rx.enqueue_device(ptrs, ns, "cu8"); rx.collect()
 t0 = time.perf_counter(); rx.enqueue_device(ptrs, ns, "cu8"); rx.collect(); dt = time.perf_counter() - t0
 sent = nsym // cfg.symbols_per_frame
 print(f"# {a.config}: {a.n} captures x {a.seconds:g} s, Eb/N0 {a.lo}..{a.hi} dB, {sent} packets sent per capture")
-print(f"# batch: {a.n * nsamp / dt / 1e6:.0f} Msamples/s ({dt * 1e3:.1f} ms; demod {rx.last_ms(0):.1f} ms, decode {rx.last_ms(2):.1f} ms)")
+print(f"# batch: {a.n * nsamp / dt / 1e6:.0f} Msamples/s ({dt * 1e3:.1f} ms; demod {rx.last_ms(0):.1f} ms, decode {rx.last_ms(2):.1f} ms; kernel {rx.last_kernel()})")
 sym_h = sym.cpu().numpy().reshape(a.n, nfr * spp)[:, :nsym]
-print("| Eb/N0 dB | packets found | CRC-valid | bytes decoded | PER | mean iter | BER before FEC | BER after FEC (found packets) | all valid payloads were sent |")
-print("|---|---|---|---|---|---|---|---|---|")
+rows = []
 spf = cfg.symbols_per_frame
 body0 = (16 + 4) * (10 if cfg.mode == 1 else 8)                  # symbols of preamble + unique word ahead of the packet body
 for c, eb in enumerate(ebs):
@@ -60,9 +60,23 @@ for c, eb in enumerate(ebs):
             continue
         epre += int((hard[st:st + nsymb] != sym_h[c][k * spf + body0:k * spf + body0 + nsymb]).sum()); npre += nsymb
         nerr += int(np.unpackbits(np.frombuffer(pls[c][k], np.uint8) ^ p["bytes"][i][:256]).sum()); nbit += 2048
-    ber_pre = epre / npre if npre else float("nan")
-    print(f"| {eb:5.2f} | {p['n']} | {len(ok)} | {256 * len(ok)} | {1 - len(ok) / max(sent, 1):.3f} | {p['iter'].mean() if p['n'] else 0:.2f} | "
-          f"{ber_pre:.2e} | {nerr / nbit if nbit else float('nan'):.2e} | {all(x in sset for x in ok)} |")
+    rows.append(dict(eb=eb, found=p["n"], valid=len(ok), iters=float(p["iter"].sum()) if p["n"] else 0.0, epre=epre, npre=npre, nerr=nerr, nbit=nbit,
+                     sent_ok=all(x in sset for x in ok)))
+if a.bins > 0:
+    print("| Eb/N0 dB (bin) | captures | packets found | CRC-valid | PER | mean iter | BER before FEC | BER after FEC (found packets) | all valid payloads were sent |")
+    print("|---|---|---|---|---|---|---|---|---|")
+    for b in range(a.bins):
+        rr = rows[len(rows) * b // a.bins: len(rows) * (b + 1) // a.bins]
+        if not rr: continue
+        f = sum(r["found"] for r in rr); v = sum(r["valid"] for r in rr); npre = sum(r["npre"] for r in rr); nbit = sum(r["nbit"] for r in rr)
+        print(f"| {rr[0]['eb']:5.2f}..{rr[-1]['eb']:5.2f} | {len(rr)} | {f} | {v} | {1 - v / max(sent * len(rr), 1):.4f} | {sum(r['iters'] for r in rr) / max(f, 1):.2f} | "
+              f"{(sum(r['epre'] for r in rr) / npre) if npre else float('nan'):.2e} | {(sum(r['nerr'] for r in rr) / nbit) if nbit else float('nan'):.2e} | {all(r['sent_ok'] for r in rr)} |")
+else:
+    print("| Eb/N0 dB | packets found | CRC-valid | bytes decoded | PER | mean iter | BER before FEC | BER after FEC (found packets) | all valid payloads were sent |")
+    print("|---|---|---|---|---|---|---|---|---|")
+    for r in rows:
+        print(f"| {r['eb']:5.2f} | {r['found']} | {r['valid']} | {256 * r['valid']} | {1 - r['valid'] / max(sent, 1):.3f} | {r['iters'] / max(r['found'], 1):.2f} | "
+              f"{(r['epre'] / r['npre']) if r['npre'] else float('nan'):.2e} | {(r['nerr'] / r['nbit']) if r['nbit'] else float('nan'):.2e} | {r['sent_ok']} |")
 refdir = os.path.join(ROOT, "oracle", "_ref")
 if a.check_cpu and os.path.exists(os.path.join(refdir, "fsk_demod")):
     l2 = os.path.join(refdir, "drs232_ldpc" if cfg.mode == 1 else "wenet_ldpc")
