@@ -59,64 +59,7 @@ __device__ __forceinline__ void dsp_barrier(int *cnt, int target, int lane) {
 enum { CT_NIN_NEXT = 0, CT_CNT = 1, CT_CONT = 2 /* this capture has another frame */, CT_FBIN = 4 /* [4 frames][4 tones] */, CT_INTS = 24 };
 
 
-// NCO chain of one frame with the real / imaginary part of tone m in lanes 2m / 2m+1 (nco_step_split): the batch form of
-// C(j) below -- same statements, half the SIMD time per step, a longer dependent path.  Out of line so that the kernel's
-// register allocation (80 VGPRs in the three-captures-per-CU variant) is not disturbed by it.
-typedef __attribute__((address_space(3))) float lds_f32;
-typedef __attribute__((address_space(3))) int lds_i32;
-__device__ __forceinline__ void nco_chain_split(int j, int nin_j, int lane, int M, int N, int NH, int Nmem, int L, lds_i32 *CT, lds_f32 *PHE,
-                                             lds_f32 *CKb, lds_f32 *CKD, const lds_f32 *dphi_t, const float *bin_freq, const float2 *backoff_tab,
-                                             int capmask, int cap_stride_words) {
-    // lanes [2M*c, 2M*(c+1)) carry capture c: tone m = pair index, part = re / im; pointers move to that capture's LDS block
-    const int cap = lane / (2 * M);
-    if (cap >= WT_CAPS || !((capmask >> cap) & 1)) return;
-    const int m = (lane - cap * 2 * M) >> 1, part = lane & 1;
-    CT += cap * cap_stride_words; PHE += cap * cap_stride_words; CKb += cap * cap_stride_words; CKD += cap * cap_stride_words;
-    const int nold = Nmem - nin_j;
-    int bc = CT[CT_FBIN + (j & 3) * 4 + m];
-    int bp = CT[CT_FBIN + ((j + 3) & 3) * 4 + m];
-    const int bp0 = CT[CT_FBIN + ((j + 3) & 3) * 4 + 0];
-    if (bin_freq[bp0] < 1.0f) bp = bc;                                   // first run (fsk.c:750-753)
-    const int ncase = (nin_j < N) ? 0 : ((nin_j > N) ? 2 : 1);
-    const float2 bo = backoff_tab[ncase * NH + bp];
-    const lds_f32 *pc = PHE + (((j + 2) % 3) * 4 + m) * 2;
-    const v2f phi0 = cmul_pk((v2f){bo.x, bo.y}, (v2f){pc[0], pc[1]});    // fsk.c:758-759 (both lanes of the pair)
-    float own = part ? phi0.y : phi0.x;
-    float dx = dphi_t[2 * bp], dy = dphi_t[2 * bp + 1];
-    float k1 = dx, k2 = part ? dy : -dy;
-    lds_f32 *ckA = CKb + ((((j & 1) * 2 + 0) * M + m) * WP_CKROW) * 2 + part;
-    lds_f32 *ckB = CKb + ((((j & 1) * 2 + 1) * M + m) * WP_CKROW) * 2 + part;
-    CKD[(((j & 1) * 2 + 0) * M + m) * 2 + part] = part ? dy : dx;
-    int s = 0, c = 0;
-    for (; s + WP_CK <= nold; s += WP_CK, c++) {
-        ckA[2 * c] = own;
-        static_assert(WP_CK == 8, "nco_step_split8"); own = nco_step_split8(own, k1, k2);
-    }
-    if (s < nold) { ckA[2 * c] = own; for (; s < nold; s++) own = nco_step_split(own, k1, k2); }
-    {
-        const float oth = __shfl_xor(own, 1, 64);
-        const float re = part ? oth : own, im = part ? own : oth;
-        const float av = sqrtf(re * re + im * im);                       // comp_normalize (fsk.c:787)
-        own = own / av;
-        dx = dphi_t[2 * bc]; dy = dphi_t[2 * bc + 1];
-        k1 = dx; k2 = part ? dy : -dy;
-    }
-    CKD[(((j & 1) * 2 + 1) * M + m) * 2 + part] = part ? dy : dx;
-    c = 0;
-    for (; s + 4 * WP_CK <= L; s += 4 * WP_CK, c += 4) {                     // four checkpoints per trip: a taken branch costs ~16 cycles
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            ckB[2 * (c + k)] = own;
-            own = nco_step_split8(own, k1, k2);
-        }
-    }
-    for (; s + WP_CK <= L; s += WP_CK, c++) {
-        ckB[2 * c] = own;
-        static_assert(WP_CK == 8, "nco_step_split8"); own = nco_step_split8(own, k1, k2);
-    }
-    if (s < L) { ckB[2 * c] = own; for (; s < L; s++) own = nco_step_split(own, k1, k2); }
-    PHE[((j % 3) * 4 + m) * 2 + part] = own;                             // un-normalised (fsk.c:846)
-}
+#include "demod_chain_split.h"
 
 }  // namespace
 
@@ -210,310 +153,20 @@ __global__ __launch_bounds__(WP_THREADS, 4) void wenet_demod_tri_kernel(WrDemodC
         // first 4*Nmax samples into the ring
         const long long last = C.nsamples - 1;
         for (long long i = ctid; i < 4LL * Nmax; i += WT_CTHREADS)
-            if (C.nsamples > 0) ring_put_raw(RIDX(i), load_raw(C.raw, fmt_k, i < last ? i : last), fmt_k);
-            else ring_put_f(RIDX(i), make_float2(0.f, 0.f));
-    }
-    long long filled = 4LL * Nmax;                    // ring holds absolute samples [off - nstash, filled)
-    lds_barrier();
-
-    // ================================ stage bodies ============================================
-    // E(j): tone estimator of frame j.  One wavefront.  slot_in/out index the spectrum ring.
-    auto estimate = [&](int j, long long off_j, int nin_j) {
-        const float *FEin = FEr + ((j + 3) & 3) * NH;          // after frame j-1
-        float *FEout = FEr + (j & 3) * NH;
-        const int fft_loops = nin_j / Ndft;
-        for (int jl = 0; jl < fft_loops; jl++) {
-            const int samps = nin_j - (jl + 1) * Ndft;                  // fsk.c:583
-            const int fft_samps = samps >= Ndft ? Ndft : samps;         // fsk.c:584
-            for (int n = lane; n < Ndft; n += 64) {
-                const int idx = src_t[n];
-                float2 v = make_float2(0.f, 0.f);
-                if (idx < fft_samps) {
-                    const float h = hann_t[idx];
-                    const float2 x = ring_get(RIDX(off_j + idx + Ndft * jl));
-                    v = make_float2(h * x.x, h * x.y);
-                }
-                FB[n] = v;
-            }
-            wave_sync();
-            for (int s = cfg.nstages - 1; s >= 0; s--) {
-                const int m = cfg.mstage[s], p = cfg.radix[s], fs = cfg.fstride[s];
-                const int lgm = 31 - __clz(m);
-                const int nb = Ndft / p;
-                for (int b = lane; b < nb; b += 64) {
-                    const int blk = b >> lgm, k = b & (m - 1);           // m is a power of two (Ndft is)
-                    float2 *F = FB + blk * m * p + k;
-                    if (p == 4) {                                       // kf_bfly4 (kiss_fft.c:44-90)
-                        const float2 s0 = cmul(F[m], tw_t[k * fs]);
-                        const float2 s1 = cmul(F[2 * m], tw_t[k * fs * 2]);
-                        const float2 s2 = cmul(F[3 * m], tw_t[k * fs * 3]);
-                        float2 f0 = F[0];
-                        const float2 s5 = make_float2(f0.x - s1.x, f0.y - s1.y);
-                        f0 = make_float2(f0.x + s1.x, f0.y + s1.y);
-                        const float2 s3 = make_float2(s0.x + s2.x, s0.y + s2.y);
-                        const float2 s4 = make_float2(s0.x - s2.x, s0.y - s2.y);
-                        F[2 * m] = make_float2(f0.x - s3.x, f0.y - s3.y);
-                        F[0] = make_float2(f0.x + s3.x, f0.y + s3.y);
-                        F[m] = make_float2(s5.x + s4.y, s5.y - s4.x);
-                        F[3 * m] = make_float2(s5.x - s4.y, s5.y + s4.x);
-                    } else {                                            // kf_bfly2 (kiss_fft.c:21-42)
-                        const float2 t = cmul(F[m], tw_t[k * fs]);
-                        const float2 f0 = F[0];
-                        F[m] = make_float2(f0.x - t.x, f0.y - t.y);
-                        F[0] = make_float2(f0.x + t.x, f0.y + t.y);
-                    }
-                }
-                wave_sync();
-            }
-            const float *FEcur = (jl == 0) ? FEin : FEout;
-            for (int i = lane; i < NH; i += 64) {                       // fsk.c:612-628
-                const float2 v = FB[i];
-                float mag = (v.x * v.x) + (v.y * v.y);
-                if (i < cfg.f_min) mag = 0.f;
-                if (cfg.f_max - 1 >= 0 && i >= cfg.f_max - 1) mag = 0.f;
-                const float e = (FEcur[i] * cfg.one_minus_tc) + (sqrtf(mag) * cfg.tc);
-                FEout[i] = e;
-                FW[i] = e;
-            }
-            wave_sync();
-        }
-        if (fft_loops == 0) {
-            for (int i = lane; i < NH; i += 64) { FEout[i] = FEin[i]; FW[i] = 0.f; }
-            wave_sync();
-        }
-        int fbin[M];
-#pragma unroll
-        for (int k = 0; k < M; k++) {                                   // fsk.c:633-654
-            BestBin best; best.v = 0.f; best.i = 0;
-            for (int jj = lane; jj < NH; jj += 64) {
-                const float v = FW[jj];
-                if (v > best.v) { best.v = v; best.i = jj; }
-            }
-#pragma unroll
-            for (int sh = 32; sh >= 1; sh >>= 1) {
-                BestBin o;
-                o.v = __shfl_xor(best.v, sh, 64);
-                o.i = __shfl_xor(best.i, sh, 64);
-                best = better(best, o);
-            }
-            const int imax = __builtin_amdgcn_readfirstlane((best.v > 0.f) ? best.i : 0);
-            int lo = imax - cfg.f_zero; lo = lo < 0 ? 0 : lo;
-            int hi = imax + cfg.f_zero; hi = hi > NH ? NH : hi;
-            wave_sync();
-            for (int jj = lo + lane; jj < hi; jj += 64) FW[jj] = 0.f;
-            wave_sync();
-            fbin[k] = imax;
-        }
-#pragma unroll
-        for (int a = 1; a < M; a++) {
-#pragma unroll
-            for (int b = a; b > 0; b--)
-                if (fbin[b - 1] > fbin[b]) { const int t = fbin[b]; fbin[b] = fbin[b - 1]; fbin[b - 1] = t; }
-        }
-        if (lane == 0) {
-#pragma unroll
-            for (int m = 0; m < M; m++) CT[CT_FBIN + (j & 3) * 4 + m] = fbin[m];
-        }
-        wave_sync();
-    };
-
-    // C(j): NCO phasor chain of frame j (one wavefront, lanes 0..M-1 carry one tone each)
+#include "demod_pipe_shared_1.inc"
     auto chain = [&](int j, int nin_j, int capmask) {                   // C(j) of the captures in capmask (lanes 4c..4c+3 carry capture c)
         // (the packed form of the one-capture kernel -- one lane per capture and tone, shorter dependent path -- measured 9 % slower
         //  here: with 16 wavefronts on the CU SIMD time still counts for more than the chain's latency)
-        nco_chain_split(j, nin_j, lane, M, N, NH, Nmem, L, (lds_i32 *)CT, (lds_f32 *)PHE, (lds_f32 *)CKb, (lds_f32 *)CKD,
+        nco_chain_split<WT_CAPS>(j, nin_j, lane, M, N, NH, Nmem, L, (lds_i32 *)CT, (lds_f32 *)PHE, (lds_f32 *)CKb, (lds_f32 *)CKD,
                         (const lds_f32 *)dphi_t, cfg.bin_freq, cfg.backoff_tab, capmask, cfg.p_cap_stride / 4);
         wave_sync();
     };
 
     // D(j): mix + integrate + timing products of frame j.  Waves 3..7 (t = D thread index).
     const int t = dwave * 64 + lane;                                     // D thread index within the capture (0..191)
-    int dsp_phase = 0;
-    auto dstage = [&](int j, long long off_j, int nin_j) {
-        const int nold = Nmem - nin_j;
-        float2 *PH = DCb;
-        float2 *FI = FIb + (j & 1) * M * NI;
-        float2 *TP = TPb + (j & 1) * NIq;
-        float *TPs = (float *)TP;                                        // split layout: TPs[i] = re, TPs[NIq + i] = im
-        const long long src0 = off_j - nold;                             // chain step s <-> absolute sample src0 + s
-        const bool fastI = (q == 1 && (Ts == 10 || Ts == 8) && NI % Ts == 0);                // fast integrator path
-        const int padTs = fastI ? Ts : 0;                                          // ... with padded rows: one element after every Ts samples, so that the
-                                                                                   // integrator's lane stride is Ts+1 elements (odd: all LDS banks) instead of Ts
-        auto mix = [&](auto PADC) {
-            constexpr int PADTS = decltype(PADC)::value;             // 0: rows unpadded; 8: one pad element after every 8 samples
-            // one D thread per (tone, checkpoint): replay the <= WP_CK chain steps that follow the checkpoint
-            // (the same cmul_pk sequence the chain wave ran) and mix each sample with its conjugate phasor
-            const int nA = (nold + WP_CK - 1) / WP_CK, nB = (L - nold + WP_CK - 1) / WP_CK;
-            const int per_tone = nA + nB;
-            if (RAW && M == 2) {
-                // batch variant: one D thread per checkpoint does ALL tones of its samples -- each raw sample is read from the ring
-                // and converted once instead of once per tone (fewer instructions; one stream prefers the finer split below)
-                for (int c = t; c < per_tone; c += WP_DSP_THREADS) {
-                    const bool segB = c >= nA;
-                    const int cc = segB ? c - nA : c;
-                    const int s0 = segB ? nold + cc * WP_CK : cc * WP_CK;
-                    const int send = segB ? L : nold;
-                    const int cnt = (send - s0) < WP_CK ? (send - s0) : WP_CK;
-                    v2f d[M], phi[M];
-#pragma unroll
-                    for (int m = 0; m < M; m++) {
-                        const float2 dd = CKD[((j & 1) * 2 + (segB ? 1 : 0)) * M + m];
-                        d[m] = (v2f){dd.x, dd.y};
-                        phi[m] = ((const v2f *)(CKb + (((j & 1) * 2 + (segB ? 1 : 0)) * M + m) * WP_CKROW))[cc];
-                    }
-                    const int pq0 = PADTS ? s0 / (PADTS ? PADTS : 1) : 0, pr0 = s0 - pq0 * PADTS;
-                    float2 *row = PH + s0 + pq0;
-                    float2 *dump = PH + M * Lpad;                        // steps past the end of a segment land here (no branches)
-                    const int rbase = RIDX(src0 + s0);
-                    float2 x[WP_CK];
-#pragma unroll
-                    for (int u = 0; u < WP_CK; u++) x[u] = ring_get((rbase + (u < cnt ? u : 0)) & rmask);
-#pragma unroll
-                    for (int u = 0; u < WP_CK; u++) {
-                        float2 *dst = (u < cnt) ? row + u + ((PADTS && pr0 + u >= PADTS) ? 1 : 0) : dump;  // (WP_CK <= Ts: at most one pad crossed)
-#pragma unroll
-                        for (int m = 0; m < M; m++) {
-                            dst[(u < cnt) ? m * Lpad : 0] = cmul(x[u], make_float2(phi[m].x, -phi[m].y));
-                            phi[m] = cmul_pk(phi[m], d[m]);
-                        }
-                    }
-                }
-                return;
-            }
-            for (int w = t; w < M * per_tone; w += WP_DSP_THREADS) {
-                const int m = w / per_tone, c = w - m * per_tone;
-                const bool segB = c >= nA;
-                const int cc = segB ? c - nA : c;
-                const int s0 = segB ? nold + cc * WP_CK : cc * WP_CK;
-                const int send = segB ? L : nold;
-                const int cnt = (send - s0) < WP_CK ? (send - s0) : WP_CK;
-                const float2 dd = CKD[((j & 1) * 2 + (segB ? 1 : 0)) * M + m];
-                const v2f d = {dd.x, dd.y};
-                v2f phi = ((const v2f *)(CKb + (((j & 1) * 2 + (segB ? 1 : 0)) * M + m) * WP_CKROW))[cc];
-                // In the fast integrator layout one element of padding follows every Ts samples (sample s sits at s + s/Ts):
-                // lane strides of 8 and Ts elements would hit only 2..16 of the 32 LDS banks, 9 and Ts+1 hit all of them.
-                const int pq0 = PADTS ? s0 / (PADTS ? PADTS : 1) : 0, pr0 = s0 - pq0 * PADTS;
-                float2 *row = PH + m * Lpad + s0 + pq0;
-                float2 *dump = PH + M * Lpad;                            // steps past the end of a segment land here (no branches)
-                const int rbase = RIDX(src0 + s0);
-                float2 x[WP_CK];
-#pragma unroll
-                for (int u = 0; u < WP_CK; u++) x[u] = ring_get((rbase + (u < cnt ? u : 0)) & rmask);
-#pragma unroll
-                for (int u = 0; u < WP_CK; u++) {
-                    float2 *dst = (u < cnt) ? row + u + ((PADTS && pr0 + u >= PADTS) ? 1 : 0) : dump;      // (WP_CK <= Ts: at most one pad crossed)
-                    *dst = cmul(x[u], make_float2(phi.x, -phi.y));
-                    phi = cmul_pk(phi, d);
-                }
-            }
-                };
-#ifdef WR_DBG_SKIP
-        if (!(cfg.dbg_skip & 16)) {
-#endif
-        if (padTs == 8) mix(std::integral_constant<int, 8>()); else if (padTs == 10) mix(std::integral_constant<int, 10>()); else mix(std::integral_constant<int, 0>());
-#ifdef WR_DBG_SKIP
-        }
-#endif
-        dsp_barrier(&CT[CT_CNT], WP_DSP_WAVES * (++dsp_phase), lane);
-        if (fastI) {
-            // Fast path (one sample per integrator step).  The Ts circular-buffer slots are summed in SLOT order
-            // (fsk.c:829-840), i.e. the window row[i .. i+Ts) rotated by o = (-i) mod Ts.  Each D wave takes whole
-            // residue classes i mod Ts, so o is wave-uniform and the rotation is resolved at compile time (no index
-            // arithmetic per element); one lane does both tones of its output and the timing product right away,
-            // which also saves the barrier between the two steps.
-            auto residue = [&](int r, auto TSC, auto OC) {
-                constexpr int TS = decltype(TSC)::value, O = decltype(OC)::value;
-                for (int j = lane; j < NI / TS; j += 64) {
-                    const int i = j * TS + r;
-                    float ft1 = 0.f;
-#pragma unroll 1
-                    for (int m = 0; m < M; m++) {
-                        constexpr int R = (TS - O) % TS;                    // this residue class (wave-uniform, == r)
-                        constexpr bool PAD = true;                          // rows padded by one element per TS samples (see the mix stage)
-                        const v2f *row = (const v2f *)PH + m * Lpad + (PAD ? j * (TS + 1) + R : i);
-                        v2f v[TS];
-#pragma unroll
-                        for (int u = 0; u < TS; u++) v[u] = row[u + ((PAD && R + u >= TS) ? 1 : 0)];
-                        v2f acc = {0.f, 0.f};
-#pragma unroll
-                        for (int u = 0; u < TS; u++) acc = acc + v[(O + u) % TS];
-                        FI[m * NI + i] = make_float2(acc.x, acc.y);
-                        ft1 += (acc.x * acc.x) + (acc.y * acc.y);           // fsk.c:862-868
-                    }
-                    const float2 pf = RAW ? cfg.phi_ft[i] : pft_t[i];
-                    if (cfg.p_tsum_split) { TPs[i] = ft1 * pf.x; TPs[NIq + i] = ft1 * pf.y; }
-                    else TP[i] = make_float2(ft1 * pf.x, ft1 * pf.y);
-                }
-            };
-            auto classes = [&](auto TSC) {
-                constexpr int TS = decltype(TSC)::value;
+#include "demod_pipe_shared_2.inc"
                 for (int r = dwave; r < TS; r += WP_DSP_WAVES) {
-                    switch ((r == 0) ? 0 : TS - r) {
-#define WP_ROT(K) case K: residue(r, TSC, std::integral_constant<int, (K) % TS>()); break;
-                        WP_ROT(0) WP_ROT(1) WP_ROT(2) WP_ROT(3) WP_ROT(4) WP_ROT(5) WP_ROT(6) WP_ROT(7) WP_ROT(8) WP_ROT(9)
-#undef WP_ROT
-                    }
-                }
-            };
-#ifdef WR_DBG_SKIP
-            if (!(cfg.dbg_skip & 32))
-#endif
-            if (Ts == 10) classes(std::integral_constant<int, 10>()); else classes(std::integral_constant<int, 8>());
-            wave_sync();
-            return;
-        }
-        {
-            // one row per (tone, output): sum the Ts circular-buffer slots in slot order (fsk.c:829-840), loads first
-            auto integrate_row = [&](int m, int i, auto TSC) {
-                constexpr int TS = decltype(TSC)::value;                 // 0 = runtime Ts
-                const int ts = TS ? TS : Ts;
-                const int base = i * q;
-                const int r = base % ts;
-                int o = (r == 0) ? 0 : ts - r;
-                const v2f *row = (const v2f *)PH + m * Lpad + base;
-                v2f acc = {0.f, 0.f};
-                if (TS) {
-                    v2f v[TS ? TS : 1];
-#pragma unroll
-                    for (int u = 0; u < TS; u++) { v[u] = row[o]; o++; if (o == ts) o = 0; }
-#pragma unroll
-                    for (int u = 0; u < TS; u++) acc = acc + v[u];
-                } else {
-                    for (int j0 = 0; j0 < ts; j0 += 8) {
-                        v2f v[8];
-#pragma unroll
-                        for (int u = 0; u < 8; u++) { v[u] = row[(j0 + u < ts) ? o : 0]; if (j0 + u < ts) { o++; if (o == ts) o = 0; } }
-#pragma unroll
-                        for (int u = 0; u < 8; u++) if (j0 + u < ts) acc = acc + v[u];
-                    }
-                }
-                FI[m * NI + i] = make_float2(acc.x, acc.y);
-            };
-            for (int w = t; w < M * NI; w += WP_DSP_THREADS) {
-                const int m = w / NI, i = w - m * NI;
-                if (Ts == 10) integrate_row(m, i, std::integral_constant<int, 10>());
-                else if (Ts == 8) integrate_row(m, i, std::integral_constant<int, 8>());
-                else integrate_row(m, i, std::integral_constant<int, 0>());
-            }
-        }
-        dsp_barrier(&CT[CT_CNT], WP_DSP_WAVES * (++dsp_phase), lane);
-        for (int i = t; i < NI; i += WP_DSP_THREADS) {                   // timing products (fsk.c:862-870)
-            float ft1 = 0.f;
-#pragma unroll
-            for (int m = 0; m < M; m++) {
-                const float2 v = FI[m * NI + i];
-                ft1 += (v.x * v.x) + (v.y * v.y);
-            }
-            const float2 pf = RAW ? cfg.phi_ft[i] : pft_t[i];
-            if (cfg.p_tsum_split) { TPs[i] = ft1 * pf.x; TPs[NIq + i] = ft1 * pf.y; }
-            else TP[i] = make_float2(ft1 * pf.x, ft1 * pf.y);
-        }
-        wave_sync();
-    };
-
-    // T(k): ordered sum, timing, nin, decisions (fsk.c:870-993).  Wave 2.  kf = frame index in this launch.
-    float norm_rx_timing_st = hdr->norm_rx_timing;                       // T-wave private carried scalars
-    float ppm = hdr->ppm;
+#include "demod_pipe_shared_3.inc"
     auto tstage = [&](int kf, long long frames, int nin_cur, int act_caps) {
         if (C.prof && lane == 0) C.prof[12] = (long long)__builtin_readcyclecounter();
         const float2 *FI = FIb + (kf & 1) * M * NI;
@@ -588,96 +241,7 @@ __global__ __launch_bounds__(WP_THREADS, 4) void wenet_demod_tri_kernel(WrDemodC
             nin_next = __builtin_amdgcn_readfirstlane(nin_next);
             if (lane == 0) CT[CT_NIN_NEXT] = nin_next;                   // published early; read after the frame barrier
             if (C.prof && lane == 0) C.prof[9] += (long long)__builtin_readcyclecounter() - C.prof[12];   // development: ... + atan2f, nin
-            const int low_sample = (int)floorf(rx_timing);
-            const float fract = rx_timing - (float)low_sample;
-            const int high_sample = (int)ceilf(rx_timing);
-            const float omf = 1 - fract;
-            tr_rxt = rx_timing;
-            float mymax = 0.f;
-            if (lane < WR_NSYM) {
-                const int st = (lane + 1) * P;
-                float tmax[M];
-#pragma unroll
-                for (int m = 0; m < M; m++) {
-                    const float2 a = FI[m * NI + st + low_sample];
-                    const float2 b = FI[m * NI + st + high_sample];
-                    float tr = omf * a.x, ti = omf * a.y;
-                    tr = tr + fract * b.x;
-                    ti = ti + fract * b.y;
-                    tmax[m] = (tr * tr) + (ti * ti);
-                }
-                float mx = tmax[0];
-                int sym = 0;
-#pragma unroll
-                for (int m = 0; m < M; m++) if (tmax[m] > mx) { mx = tmax[m]; sym = m; }
-                mymax = mx;
-                if (C.bits_out) {
-                    uint8_t *bo = C.bits_out + frames * Nbits;
-                    if (M == 2) bo[lane] = (uint8_t)(sym == 1);
-                    else { bo[lane * 2 + 1] = (uint8_t)(sym & 1); bo[lane * 2] = (uint8_t)((sym & 2) >> 1); }
-                }
-#pragma unroll
-                for (int m = 0; m < M; m++) tmax[m] = sqrtf(tmax[m]);
-                if (M == 2) {
-                    SDL[lane] = tmax[0] - tmax[1];
-                } else {
-                    float s1 = -tmax[0], s0 = -tmax[0];
-                    s1 += tmax[1 % M];  s0 += -tmax[1 % M];
-                    s1 += -tmax[2 % M]; s0 += tmax[2 % M];
-                    s1 += tmax[3 % M];  s0 += tmax[3 % M];
-                    SDL[lane * 2 + 1] = s1;
-                    SDL[lane * 2] = s0;
-                }
-            }
-            if (cfg.stats) {
-                if (lane < WR_NSYM) ((float2 *)SC)[lane] = make_float2(mymax, sqrtf(mymax));
-                wave_sync();
-                if (lane == 0) {
-                    // the two running sums of fsk.c:998-1004 are independent chains: one packed add per symbol, loads up front
-                    v2f acc = {0.f, 0.f};
-                    const v2f *sc2 = (const v2f *)SC;
-#pragma unroll
-                    for (int i0 = 0; i0 < WR_NSYM; i0 += 16) {
-                        v2f w[16];
-#pragma unroll
-                        for (int u = 0; u < 16; u++) w[u] = sc2[i0 + u];
-#pragma unroll
-                        for (int u = 0; u < 16; u++) acc = acc + w[u];
-                    }
-                    float stdebno = acc.x, meanebno = acc.y;
-                    meanebno = meanebno / cfg.nsym_f;
-                    stdebno = (stdebno / cfg.nsym_f) - (meanebno * meanebno);
-                    if ((double)stdebno > 0.0) stdebno = (float)sqrt((double)stdebno); else stdebno = 0.0f;
-                    SC[2 * WR_NSYM] = meanebno;
-                    SC[2 * WR_NSYM + 1] = stdebno;
-                }
-                wave_sync();
-                tr_mean = SC[2 * WR_NSYM];
-                tr_std = SC[2 * WR_NSYM + 1];
-            }
-            if (C.dump && frames >= C.dump_first && ((frames - C.dump_first) % C.dump_period) == 0) {
-                const long long slot = (frames - C.dump_first) / C.dump_period;
-                if (slot < C.dump_cap) {
-                    float *d = C.dump + slot * cfg.dump_floats;
-                    const float *FEk = FEr + (kf & 3) * NH;
-                    const int neye = cfg.eye_traces * M * cfg.neyesamp;
-                    for (int e = lane; e < neye; e += 64) {
-                        const int j = e % cfg.neyesamp;
-                        const int tm = e / cfg.neyesamp;
-                        const int i = tm / M, m = tm - i * M;
-                        const int ind = 2 * P * i + (high_sample + 1) + j * cfg.eye_dec;
-                        float v = 0.f;
-                        if (ind >= 0 && ind < NI) { const float2 f = FI[m * NI + ind]; v = sqrtf(f.x * f.x + f.y * f.y); }
-                        d[e] = v;
-                    }
-                    for (int i = lane; i < NH; i += 64) d[neye + i] = FEk[i];
-                    if (lane == 0) { d[neye + NH] = (float)high_sample; d[neye + NH + 1] = (float)frames; }
-                }
-            }
-        } else if (lane == 0) {
-            CT[CT_NIN_NEXT] = nin_next;
-        }
-        wave_sync();
+#include "demod_pipe_shared_4.inc"
         if (C.prof && lane == 0) C.prof[10] += (long long)__builtin_readcyclecounter() - C.prof[12];      // development: ... + resample/decide
         if (C.sd_out) {
             float *so = C.sd_out + frames * Nbits;
