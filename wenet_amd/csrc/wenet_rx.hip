@@ -15,6 +15,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/wenet_rx.h"
@@ -1150,6 +1151,22 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const lon
         use_oct = oct_cfg.o_ok != 0 && fmt == WENET_FMT_CU8;
     }
     const int oct_fast = use_oct && rx->fast ? 1 : 0;
+    if (use_oct && !host_src) {
+        // The captures of a workgroup advance in lock-step and a workgroup lasts as long as its longest capture: deal the captures to the
+        // workgroups by length (longest first; the table's order decides nothing else -- every entry carries its own buffers), so that the
+        // captures of a group end together and the long groups start first.
+        std::vector<int> order(nchan);
+        for (int i = 0; i < nchan; i++) order[i] = i;
+        bool ragged = false;
+        for (int i = 1; i < nchan && !ragged; i++) ragged = chans[i].nsamples != chans[0].nsamples;
+        if (ragged && getenv("WENET_RX_NO_SORT") == nullptr) {
+            std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return chans[x].nsamples > chans[y].nsamples; });
+            std::vector<WrChan> sorted(nchan);
+            for (int i = 0; i < nchan; i++) sorted[i] = chans[order[i]];
+            WR_CHECK(hipMemcpyAsync(rx->d_chans.p, sorted.data(), sizeof(WrChan) * nchan, hipMemcpyHostToDevice, stream), -3);
+            WR_CHECK(hipStreamSynchronize(stream), -3);
+        }
+    }
     rx->last_kernel = use_oct ? (oct_fast ? "wenet_demod_oct_kernel<fast>" : "wenet_demod_oct_kernel")
                               : (launch_cfg.p_tri ? "wenet_demod_tri_kernel" : (launch_cfg.pipe_ok && !launch_cfg.big ? "wenet_demod_pipe_kernel" : "wenet_demod_kernel"));
     // more captures than CUs: SIMD time matters more than the latency of one frame (see tstage in demod_pipe_kernel.hip)
