@@ -1111,45 +1111,58 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const lon
     a.census = rx->d_census.as<unsigned>();
     a.llr_out = rx->want_llr ? rx->d_llr.as<float>() : nullptr;
     fill_decode_tables(a, t);
-    // every capture starts from reset state; with cu8 input the three-per-CU raw-ring variant applies
-    // ... when a third capture per CU is worth having; up to two per CU the float-ring variant (96 registers, no spills)
-    // is 7 % faster per frame.  WENET_RX_FORCE_RAW=1 selects the raw ring regardless (tests).
-    const bool want_raw = (fmt == WENET_FMT_CU8) && (nchan > 2 * wenet_rx_device_info(1) || getenv("WENET_RX_FORCE_RAW") != nullptr);
-    // three captures per workgroup (one shared NCO-chain wave, demod_tri_impl.h) for big cu8 batches; WENET_RX_TRI=1 forces it on
-    // any cu8 batch (tests), WENET_RX_NO_TRI turns it off
-    // ... unless the previous batch of this handle slipped on more than 5 % of its frames (symbol-clock error: the timing estimate
-    // ping-pongs at its thresholds): a slip stalls all three captures of a workgroup, and the one-capture kernel wins
-    // (tools/gpu_slip_batch.py: 100 ppm = 11 % slips: 34.5 vs 30.5 ms)
-    const bool slippy = rx->slip_rate > 0.05 && getenv("WENET_RX_TRI") == nullptr;
-    const bool want_tri = (fmt == WENET_FMT_CU8) && (!rx->profile || getenv("WENET_RX_PROFILE")[0] == '3') &&
-                          (getenv("WENET_RX_TRI") != nullptr || (2 * nchan >= 3 * wenet_rx_device_info(1) && !slippy));   // from 1.5 captures per CU on it wins (measured 384..3072)
-    WrDemodCfg launch_cfg = want_tri ? rx->tab.tri_cfg() : (want_raw ? rx->tab.raw_cfg() : rx->tab.cfg);
-    if (want_tri && !launch_cfg.p_tri) launch_cfg = want_raw ? rx->tab.raw_cfg() : rx->tab.cfg;     // geometry does not fit three blocks
-    // Batches (round 2): one wavefront per capture, `caps` captures per workgroup sharing an NCO-chain and a timing-sum wavefront
-    // (demod_oct_impl.h).  A capture advances one frame per ~20 k cycles there (the pipelined kernels: 11.5 k), so it takes over once
-    // the CUs hold several captures each.  WENET_RX_OCT=<caps> forces it
-    // (tests), WENET_RX_NO_OCT turns it off.  Traces with Eb/N0 accumulators and profiling stay with the pipelined kernels.
-    int oct_caps = 0;
-    if (fmt == WENET_FMT_CU8 && (!rx->profile || getenv("WENET_RX_PROFILE")[0] == '4')) {
-        const char *force = getenv("WENET_RX_OCT");
-        // measured (tools/gpu_batch_sweep.py, 10 s captures, 256 CUs, demod ms): the three-capture pipelined kernel takes 103 per round of 768
-        // captures; workgroups of four captures 179 up to one per CU, 203 up to two per CU; workgroups of seven 195 up to one per CU,
-        // 245..255 up to two per CU.  Hence: up to 3 captures per CU pipelined, then whichever workgroup size needs fewer per CU.
-        if (force) oct_caps = atoi(force) > 0 ? atoi(force) : 7;
-        else if (!rx->want_trace && c.M == 2 && nchan > 3 * wenet_rx_device_info(1)) {
-            const int ncu = wenet_rx_device_info(1);
-            oct_caps = nchan <= 4 * ncu ? 4 : (nchan <= 7 * ncu ? 7 : (nchan <= 8 * ncu ? 4 : 7));
+    // Which demodulator kernel for n_sel captures launched together (the whole batch; or, below, the full rounds and the remainder of a
+    // device-resident batch separately):
+    struct DemodChoice { bool use_oct; WrDemodCfg oct_cfg, launch_cfg; };
+    auto choose_demod = [&](int n_sel) -> DemodChoice {
+        // every capture starts from reset state; with cu8 input the three-per-CU raw-ring variant applies
+        // ... when a third capture per CU is worth having; up to two per CU the float-ring variant (96 registers, no spills)
+        // is 7 % faster per frame.  WENET_RX_FORCE_RAW=1 selects the raw ring regardless (tests).
+        const bool want_raw = (fmt == WENET_FMT_CU8) && (n_sel > 2 * wenet_rx_device_info(1) || getenv("WENET_RX_FORCE_RAW") != nullptr);
+        // three captures per workgroup (one shared NCO-chain wave, demod_tri_impl.h) for big cu8 batches; WENET_RX_TRI=1 forces it on
+        // any cu8 batch (tests), WENET_RX_NO_TRI turns it off
+        // ... unless the previous batch of this handle slipped on more than 5 % of its frames (symbol-clock error: the timing estimate
+        // ping-pongs at its thresholds): a slip stalls all three captures of a workgroup, and the one-capture kernel wins
+        // (tools/gpu_slip_batch.py: 100 ppm = 11 % slips: 34.5 vs 30.5 ms)
+        const bool slippy = rx->slip_rate > 0.05 && getenv("WENET_RX_TRI") == nullptr;
+        const bool want_tri = (fmt == WENET_FMT_CU8) && (!rx->profile || getenv("WENET_RX_PROFILE")[0] == '3') &&
+                              (getenv("WENET_RX_TRI") != nullptr || (2 * n_sel >= 3 * wenet_rx_device_info(1) && !slippy));   // from 1.5 captures per CU on it wins (measured 384..3072)
+        WrDemodCfg launch_cfg = want_tri ? rx->tab.tri_cfg() : (want_raw ? rx->tab.raw_cfg() : rx->tab.cfg);
+        if (want_tri && !launch_cfg.p_tri) launch_cfg = want_raw ? rx->tab.raw_cfg() : rx->tab.cfg;     // geometry does not fit three blocks
+        // Batches (round 2): one wavefront per capture, `caps` captures per workgroup sharing an NCO-chain and a timing-sum wavefront
+        // (demod_oct_impl.h).  A capture advances one frame per ~20 k cycles there (the pipelined kernels: 11.5 k), so it takes over once
+        // the CUs hold several captures each.  WENET_RX_OCT=<caps> forces it
+        // (tests), WENET_RX_NO_OCT turns it off.  Traces with Eb/N0 accumulators and profiling stay with the pipelined kernels.
+        int oct_caps = 0;
+        if (fmt == WENET_FMT_CU8 && (!rx->profile || getenv("WENET_RX_PROFILE")[0] == '4')) {
+            const char *force = getenv("WENET_RX_OCT");
+            // measured (tools/gpu_batch_sweep.py, 10 s captures, 256 CUs, demod ms): the three-capture pipelined kernel takes 103 per round of 768
+            // captures; workgroups of four captures 179 up to one per CU, 203 up to two per CU; workgroups of seven 195 up to one per CU,
+            // 245..255 up to two per CU.  Hence: up to 3 captures per CU pipelined, then whichever workgroup size needs fewer per CU.
+            if (force) oct_caps = atoi(force) > 0 ? atoi(force) : 7;
+            else if (!rx->want_trace && c.M == 2 && n_sel > 3 * wenet_rx_device_info(1)) {
+                const int ncu = wenet_rx_device_info(1);
+                oct_caps = n_sel <= 4 * ncu ? 4 : (n_sel <= 7 * ncu ? 7 : (n_sel <= 8 * ncu ? 4 : 7));
+            }
+            // the 4-FSK / Ts 32 geometry (BASELINE config 4): 30 KB of LDS per capture = four captures per CU as two workgroups of two;
+            // from two captures per CU on it beats the sequential kernel's one capture per CU (34 vs 11.5 Gsamples/s at 1024 captures)
+            else if (!rx->want_trace && c.M == 4 && n_sel >= 2 * wenet_rx_device_info(1)) oct_caps = 2;
         }
-        // the 4-FSK / Ts 32 geometry (BASELINE config 4): 30 KB of LDS per capture = four captures per CU as two workgroups of two;
-        // from two captures per CU on it beats the sequential kernel's one capture per CU (34 vs 11.5 Gsamples/s at 1024 captures)
-        else if (!rx->want_trace && c.M == 4 && nchan >= 2 * wenet_rx_device_info(1)) oct_caps = 2;
-    }
-    WrDemodCfg oct_cfg;
-    bool use_oct = false;
-    if (oct_caps > 0 || rx->fast) {
-        oct_cfg = rx->tab.oct_cfg(oct_caps > 0 ? oct_caps : 7, rx->fast != 0);
-        use_oct = oct_cfg.o_ok != 0 && fmt == WENET_FMT_CU8;
-    }
+        WrDemodCfg oct_cfg;
+        bool use_oct = false;
+        if (oct_caps > 0 || rx->fast) {
+            oct_cfg = rx->tab.oct_cfg(oct_caps > 0 ? oct_caps : 7, rx->fast != 0);
+            use_oct = oct_cfg.o_ok != 0 && fmt == WENET_FMT_CU8;
+        }
+        launch_cfg.p_tsum_split = getenv("WENET_RX_TSUM_SPLIT") ? atoi(getenv("WENET_RX_TSUM_SPLIT")) : ((n_sel > wenet_rx_device_info(1)) ? 1 : 0);
+        if (launch_cfg.p_tri) launch_cfg.p_tsum_split = 1;              // (the batch form throughout)
+        DemodChoice dc; dc.use_oct = use_oct; dc.oct_cfg = oct_cfg; dc.launch_cfg = launch_cfg;
+        return dc;
+    };
+    DemodChoice whole = choose_demod(nchan);
+    const bool use_oct = whole.use_oct;
+    WrDemodCfg &oct_cfg = whole.oct_cfg;
+    WrDemodCfg &launch_cfg = whole.launch_cfg;
     const int oct_fast = use_oct && rx->fast ? 1 : 0;
     if (use_oct && !host_src) {
         // The captures of a workgroup advance in lock-step and a workgroup lasts as long as its longest capture: deal the captures to the
@@ -1169,9 +1182,6 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const lon
     }
     rx->last_kernel = use_oct ? (oct_fast ? "wenet_demod_oct_kernel<fast>" : "wenet_demod_oct_kernel")
                               : (launch_cfg.p_tri ? "wenet_demod_tri_kernel" : (launch_cfg.pipe_ok && !launch_cfg.big ? "wenet_demod_pipe_kernel" : "wenet_demod_kernel"));
-    // more captures than CUs: SIMD time matters more than the latency of one frame (see tstage in demod_pipe_kernel.hip)
-    launch_cfg.p_tsum_split = getenv("WENET_RX_TSUM_SPLIT") ? atoi(getenv("WENET_RX_TSUM_SPLIT")) : ((nchan > wenet_rx_device_info(1)) ? 1 : 0);
-    if (launch_cfg.p_tri) launch_cfg.p_tsum_split = 1;                  // (the batch form throughout)
     // WENET_RX_PROFILE: 1 = instrumented pipelined kernel, 2 = instrumented one-wave sequential kernel, 3 = production
     // kernels with the per-channel stamp buffer attached (streamed sequential kernel: cycle stamps of one frame)
     const int prof = rx->profile ? (getenv("WENET_RX_PROFILE")[0] == '2' ? 2 : (getenv("WENET_RX_PROFILE")[0] == '3' ? 0 : 1)) : 0;
@@ -1209,8 +1219,18 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const lon
         ak.census = a.census + (size_t)lo * WR_CENSUS_CLASSES;
         if (a.llr_out) ak.llr_out = a.llr_out + (size_t)lo * max_pk * WR_NCODE;
         WR_CHECK(hipEventRecord(e.ev[0], stream), -4);
-        if (use_oct) WR_CHECK(wr_launch_demod_oct(&oct_cfg, rx->d_chans.as<WrChan>() + lo, n, stream, oct_fast), -4);
+        // A capture is a serial job, so the batch demodulator works in rounds of the captures a device holds (two workgroups per CU); what is
+        // left over after the full rounds of a device-resident batch is launched as a batch of its own size -- sixteen captures through the
+        // pipelined kernel take 96 ms, a nearly empty round of the batch demodulator 177.
+        const int round_caps = use_oct ? 2 * oct_cfg.o_caps * ncu : 0;
+        const int full = (use_oct && !host_src && !oct_fast && getenv("WENET_RX_OCT") == nullptr && round_caps > 0 && n > round_caps) ? (n / round_caps) * round_caps : n;
+        if (use_oct) WR_CHECK(wr_launch_demod_oct(&oct_cfg, rx->d_chans.as<WrChan>() + lo, full, stream, oct_fast), -4);
         else WR_CHECK(wr_launch_demod_ex(&launch_cfg, rx->d_chans.as<WrChan>() + lo, n, stream, prof), -4);
+        if (full < n) {
+            DemodChoice rest = choose_demod(n - full);
+            if (rest.use_oct) WR_CHECK(wr_launch_demod_oct(&rest.oct_cfg, rx->d_chans.as<WrChan>() + lo + full, n - full, stream, 0), -4);
+            else WR_CHECK(wr_launch_demod_ex(&rest.launch_cfg, rx->d_chans.as<WrChan>() + lo + full, n - full, stream, 0), -4);
+        }
         if (oct_fast) {
             // Fast mode: a capture with a frame whose timing estimate fell within the guard band of a nin threshold (fsk.c:900-907)
             // may have taken the other branch than the reference; it is demodulated again, from reset state, by an exact kernel
