@@ -48,7 +48,7 @@ def _pipe_cmd(ref_dir, cfg, framing, path, stats):
     return f"{demod} --cu8 -s {st}{cfg.M} {cfg.Fs} {cfg.Rs} {path} - 2>{err} | {l2} - - 2>/dev/null"
 
 
-def cpu_baseline(cfg, caps_host, framing, gpu_payloads, reps=3):
+def cpu_baseline(cfg, caps_host, framing, gpu_payloads, reps=3, comparable=True):
     """Reference pipeline `fsk_demod --cu8 -s M Fs Rs - - | {drs232,wenet}_ldpc - -` on host cores:
     (a) with --stats=100 and the stats stream kept (the shape of benchmarking/test_demod.py:26-43), one capture = 2 busy cores;
     (b) stats off; (c) every sample capture at once through xargs -P $(nproc).  Medians of `reps` repetitions."""
@@ -111,12 +111,14 @@ def cpu_baseline(cfg, caps_host, framing, gpu_payloads, reps=3):
     return {"value": legs["b_stats_off"]["msamples_per_s"], "unit": "Msamples/s", "cores": 2, "kind": "reference",
             "sample": f"one 10 s capture of the batch through the literal 2-process pipe, stats off, median of {reps} repetitions (leg b); "
                       f"legs a (--stats=100, the harness shape) and c ({len(paths)} captures, xargs -P {ncpu}) beside it",
-            "legs": legs, "packets_match_gpu": bool(same)}
+            "legs": legs, "packets_match_gpu": bool(same) if comparable else None,
+            **({} if comparable else {"packets_note": "not compared: the reference executables have MAX_ITER 10 compiled in (drs232_ldpc.c / wenet_ldpc.c), this run decodes with another iteration limit"})}
 
 
-def load_pmc_profile(kernel_name):
-    """Committed rocprofv3 PMC profile of the demod kernel that ran (profiles/r02_pmc_*.json): HBM bytes per IQ sample from separate
-    FETCH_SIZE / WRITE_SIZE passes and the SQ counters behind the VALU figures.  None if no profile of this kernel is committed."""
+def load_pmc_profile(kernel_name, inst, captures):
+    """Committed rocprofv3 PMC profile of the demod kernel that ran (profiles/r*_pmc_*.json): HBM bytes per IQ sample from separate
+    FETCH_SIZE / WRITE_SIZE passes and the SQ counters behind the VALU figures.  None unless a profile of THIS kernel instantiation
+    (`inst` = its template arguments, e.g. "<2, 10, 256") at THIS batch size is committed."""
     best = None
     for pj in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_*.json"))):
         try:
@@ -124,7 +126,8 @@ def load_pmc_profile(kernel_name):
         except Exception:
             continue
         for k, v in d.get("kernels", {}).items():
-            if kernel_name.split("<")[0] in k and ("<fast>" in kernel_name) == bool(v.get("fast", False)):
+            if kernel_name.split("<")[0] in k and ("<fast>" in kernel_name) == bool(v.get("fast", False)) and \
+                    (inst is None or inst in k) and d.get("captures") == captures:
                 best = dict(v, file=os.path.relpath(pj, ROOT), captures=d.get("captures"), samples_in_launch=d.get("samples_in_launch"))
     return best
 
@@ -248,7 +251,8 @@ def main():
     if rank == 0:
         demod_s = k_ms[0] / 1e3
         achieved = ALGO_BYTES_PER_SAMPLE * B * nsamp / demod_s / 1e9
-        prof = load_pmc_profile(kernel_name)
+        inst = f"<{cfg.M}, {cfg.Ts}, {256 if cfg.Ts <= 10 else 1024}" if "oct" in kernel_name else None
+        prof = load_pmc_profile(kernel_name, inst, B)
         roof = {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
                 "algorithmic_bytes_per_launch": round(ALGO_BYTES_PER_SAMPLE * B * nsamp), "avg_launch_ms": round(k_ms[0], 3),
@@ -285,7 +289,7 @@ def main():
             ncpu = max(2, min(B, 32, os.cpu_count() or 2))
             caps_host = [caps[i].cpu().numpy() for i in range(ncpu)]
             gpu_payloads = [rx.valid_payloads(i) for i in range(ncpu)]
-            line["cpu_baseline"] = cpu_baseline(cfg, caps_host, cfg.mode, gpu_payloads)
+            line["cpu_baseline"] = cpu_baseline(cfg, caps_host, cfg.mode, gpu_payloads, comparable=(args.max_iter == 10))
         else:
             line["cpu_baseline"] = None
         if world == 1 and not args.no_extras:

@@ -678,15 +678,16 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
             t_rxt = rx_timing;
         }
     };
-    // the four outputs frame k+1 parks if frame k's rx_timing is rt (low = floor(rt)): offsets low-1 .. low+2 cover every
-    // rx_timing within 0.94 samples of rt
+    // the 2 W + 2 outputs frame k+1 parks if frame k's rx_timing is rt (low = floor(rt), W = wo_park_halfwidth): offsets low-W .. low+W+1 cover every
+    // rx_timing within W - 0.06 samples of rt
     auto window_mask = [&](int low) __attribute__((always_inline)) -> unsigned {
+        constexpr int W = wo_park_halfwidth(TS);
         unsigned mk = 0;
 #pragma unroll
-        for (int j = -1; j <= 2; j++) { const int x = low + j + TS; mk |= 1u << ((x >= TS ? x - TS : x) % TS); }   // (low >= -TS/2: x >= 0; the % folds away for x < 2 TS)
+        for (int j = -W; j <= W + 1; j++) { const int x = low + j + TS; mk |= 1u << ((x >= TS ? x - TS : x) % TS); }   // (low >= -TS/2: x >= 0; the % folds away for x < 2 TS)
         return mk;
     };
-    // is this frame's timing vector within 0.94 samples of rx_timing (0.94 * 360 / P degrees: 34 at P = 10) of the previous frame's?
+    // is this frame's timing vector within W - 0.06 samples of rx_timing ((W - 0.06) * 360 / P degrees: 34 at P = 10, 33 at P = 32) of the previous frame's?
     // (o_near_cos2 = cos^2 of that angle; all of this is wave-uniform arithmetic with 6 % of a sample to spare for its rounding)
     auto timing_near_previous = [&]() __attribute__((always_inline)) -> bool {
         const float dot = t_tcr * pv_r + t_tci * pv_i;

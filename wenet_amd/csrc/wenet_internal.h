@@ -84,6 +84,11 @@ struct WrDemodCfg {
 // and a layout squeezed so that two workgroups of seven captures share a CU's 160 KB -- the tone-search copy of the spectrum lives in the upper
 // half of the FFT buffer (dead after the last stage), only the twiddles the transform reaches are copied (3 * 63 < 192), and of the per-bin
 // tables only the NCO steps, the digit reversal and the nin = N row of the back-off phasors; the rest is read through the caches.
+// The mix stage of the batch kernel parks, of the Ts integrator outputs per symbol and tone, only those the resampler can ask for while the
+// timing estimate stays near the previous frame's: offsets low - W .. low + W + 1 around the previous low_sample cover every rx_timing within
+// W - 0.06 samples of the previous one (W = 1: four outputs; the 32-sample symbols of the 4-FSK geometry move by more than a sample per frame
+// at 8 dB: W = 3, eight of 32).
+constexpr int wo_park_halfwidth(int Ts) { return Ts >= 32 ? 3 : 1; }
 struct WoLayout { int FB, FW, TP, FE, CK, CT, stride, ntw, TW, HANN, DPHI, SRC, BACK, tab, nhb; };
 constexpr int wo_align16(int x) { return (x + 15) & ~15; }
 constexpr WoLayout wo_layout(int M, int Ts, int Ndft, bool fast) {

@@ -212,8 +212,8 @@ struct DemodTables {
             while (nrt(a) < -0.25f) a = nextafterf(a, INFINITY);
             c.o_at_lo = a;
         }
-        {   // a timing vector within 0.94 samples of rx_timing (0.94 * 2 pi / P) of the previous one: cos^2 of that angle
-            const double ang = 0.94 * 2 * M_PI / cfg.P;
+        {   // a timing vector within W - 0.06 samples of rx_timing of the previous one (wo_park_halfwidth): cos^2 of that angle
+            const double ang = (wo_park_halfwidth(cfg.Ts) - 0.06) * 2 * M_PI / cfg.P;
             c.o_near_cos2 = (float)(cos(ang) * cos(ang));
         }
         c.o_ok = 1;
