@@ -193,15 +193,9 @@ long long wenet_rx_get_trace(wenet_rx *rx, int ch, float *trace, long long cap_f
 /* per-packet LLRs (2580 floats per packet); enable before process */
 void wenet_rx_enable_llr_dump(wenet_rx *rx, int on);
 long long wenet_rx_get_llrs(wenet_rx *rx, int ch, float *llr, long long cap_packets);
-/* Demodulator arithmetic of the batch chain (SURVEY.md 8c parity ladder).  0 (default) = exact mode, rung P2: every soft
- * decision, LLR and packet byte is bit-identical to the reference pipe.  1 = fast mode, rung P3: table phasors instead of the
- * NCO recurrence (src/fsk.c:798,824), tree sums instead of the ordered ones (fsk.c:833-840,870-874); tone bins and nin are
- * computed as in exact mode, a capture with a frame whose timing estimate fell within the guard band of a nin threshold
- * (fsk.c:900-907) is re-run through the exact kernel by the same call.  Soft decisions then agree to 1e-4 of the frame maximum, LLRs to 2e-5 relative
- * (the rounding noise of the reference's own float32 timing sum; tests/test_gpu_oct.py).  Measured slower than the exact mode: an option, not the default. */
-void wenet_rx_set_fast(wenet_rx *rx, int on);
-/* captures of the last fast-mode batch that were demodulated a second time by the exact kernel */
-long long wenet_rx_fast_reruns(wenet_rx *rx);
+/* (Round 2's wenet_rx_set_fast / wenet_rx_fast_reruns -- parity-ladder rung P3, SURVEY.md 8c -- are gone: the relaxed arithmetic was slower than
+ * the exact kernels and missed the 1e-4 absolute LLR bound; DESIGN.md section 7 keeps the measurements.  Every mode of this library is rung P2:
+ * bit-identical to the reference pipe.) */
 /* name of the demodulator kernel the last enqueue launched (the library picks it by batch size, format and geometry) */
 const char *wenet_rx_last_kernel(wenet_rx *rx);
 /* timing of the last enqueue in milliseconds (HIP events on the launch stream):

@@ -1,6 +1,6 @@
 """GPU: the batch demodulator with one wavefront per capture (wenet_amd/csrc/demod_oct_impl.h; the library picks it by itself from
-six captures per CU on, forced here through WENET_RX_OCT=<captures per workgroup>) against the oracle -- exact mode bit for bit,
-fast mode (parity-ladder rung P3) with identical control decisions and soft decisions / LLRs within tolerance."""
+six captures per CU on, forced here through WENET_RX_OCT=<captures per workgroup>) against the oracle, bit for bit.
+(Round 2's relaxed "fast mode", parity-ladder rung P3, was removed in round 3: DESIGN.md section 7.)"""
 import numpy as np
 import pytest
 
@@ -110,51 +110,6 @@ def test_large_batch_picks_the_kernel_by_itself():
         assert bits_equal(rx.soft(i), sd), i
         ref = ol.oracle_deframe(sd, cfg.mode)
         assert rx.npackets(i) == ref["n"] and (rx.packets(i)["bytes"] == ref["bytes"]).all()
-    rx.close()
-
-
-@pytest.mark.parametrize("name", ["v2", "v1"])
-def test_fast_mode_within_tolerance(name):
-    """Rung P3: tone bins and nin identical to the oracle's on every frame (or the capture was re-run exactly), packet bytes
-    identical, soft decisions and LLRs within 1e-4 RELATIVE (of the frame's / packet's largest).  What limits the agreement is not
-    the fast arithmetic but the reference's own rounding: its ordered float sum of 490 timing products carries ~1e-6..6e-6 of noise
-    in norm_rx_timing, which moves the resampling instant of every symbol of the frame (fsk.c:913-934); an ABSOLUTE 1e-4 on LLRs of
-    magnitude > 10 is therefore out of reach for anything but the exact mode (measured here: 4e-4)."""
-    cfg = siggen.CONFIGS[name]()
-    caps = _captures(cfg, 700)
-    rx = RxBatch(cfg.Fs, cfg.Rs, cfg.M, framing=cfg.mode)
-    rx.set_fast()
-    rx.enable_trace()
-    rx.enable_llr_dump()
-    rx.process(caps, "cu8")
-    assert "oct" in rx.last_kernel()
-    worst_sd = worst_llr_rel = worst_llr_abs = worst_nrt = 0.0
-    for i, c in enumerate(caps):
-        if not c.size:
-            assert rx.frames(i) == 0
-            continue
-        sd, tr = ol.oracle_demod(c, "cu8", cfg.Fs, cfg.Rs, cfg.M, want_trace=True)
-        g, gt = rx.soft(i), rx.trace(i)
-        assert g.size == sd.size
-        assert bits_equal(np.ascontiguousarray(gt[:, :5]), np.ascontiguousarray(tr[:, :5])), i                 # f_est and nin: identical
-        worst_nrt = max(worst_nrt, float(np.abs(gt[:, 5] - tr[:, 5]).max()))                                   # norm_rx_timing
-        fr_max = np.abs(sd.reshape(-1, 48)).max(axis=1, keepdims=True)
-        err = (np.abs(g - sd).reshape(-1, 48) / np.maximum(fr_max, 1e-9)).max() if sd.size else 0.0
-        worst_sd = max(worst_sd, float(err))
-        ref = ol.oracle_deframe(sd, cfg.mode, want_llr=True)
-        p = rx.packets(i)
-        assert p["n"] == ref["n"] and (p["start"] == ref["start"]).all()
-        if ref["n"]:
-            # what the reference pipe writes -- the CRC-valid packets -- is identical; a packet the decoder gives up on after
-            # max_iter iterations ends in a state that depends chaotically on the last bit of every LLR, in any arithmetic
-            assert (p["crc_ok"] == ref["crc_ok"]).all() and (p["bytes"][ref["crc_ok"]] == ref["bytes"][ref["crc_ok"]]).all(), i
-            assert (p["iter"][ref["crc_ok"]] == ref["iter"][ref["crc_ok"]]).all(), i
-            d = np.abs(rx.llrs(i) - ref["llr"])
-            worst_llr_abs = max(worst_llr_abs, float(d.max()))
-            worst_llr_rel = max(worst_llr_rel, float((d.max(axis=1) / np.abs(ref["llr"]).max(axis=1)).max()))
-    print(f"fast mode {name}: {rx.fast_reruns()} captures re-run exactly; max |d norm_rx_timing| {worst_nrt:.3g} (guard band 2e-5), "
-          f"max |d sd| / frame max {worst_sd:.3g}, max |d LLR| {worst_llr_abs:.3g} abs, {worst_llr_rel:.3g} of the packet's largest")
-    assert worst_nrt < 2e-5 and worst_sd < 1e-4 and worst_llr_rel < 1e-4
     rx.close()
 
 

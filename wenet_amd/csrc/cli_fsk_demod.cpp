@@ -138,6 +138,8 @@ int main(int argc, char *argv[]) {
     if ((argc - dx) < 5) { fprintf(stderr, "Too few arguments\n"); usage(argv[0]); }
     if ((argc - dx) > 5) { fprintf(stderr, "Too many arguments\n"); usage(argv[0]); }
     M = atoi(argv[dx]); Fs = atoi(argv[dx + 1]); Rs = atoi(argv[dx + 2]);
+    /* (the reference divides by Rs here and dies with SIGFPE on a zero or non-numeric rate; a crash is no contract: say what is wrong) */
+    if (Fs <= 0 || Rs <= 0) { fprintf(stderr, "SampleRate and SymbolRate must be positive integers (got %s, %s)\n", argv[dx + 1], argv[dx + 2]); usage(argv[0]); }
     if (P == 0) P = Fs / Rs;                                                 /* fsk_demod.c:186-188 */
     if ((M != 2) && (M != 4)) { fprintf(stderr, "Mode %d is not valid. Mode must be 2 or 4.\n", M); usage(argv[0]); }
 

@@ -24,12 +24,8 @@
 // block instead of 100, no index arithmetic, no bank conflicts.  The integrator outputs the resampler may ask for are parked in a
 // per-capture scratch block in global memory (L2) and read back after the timing estimate.
 //
-// FAST = true (parity-ladder rung P3): the capture waves alone, no duty wave, no barriers.  The NCO
-// phasor of sample s is read from the FFT twiddle table (tone frequencies are bin centres: e^{-j 2 pi bin s / Ndft} exactly
-// periodic), the window sums use block prefix differences, the timing sum is a lane-local sum plus a wave reduction.  Tone bins
-// are computed by the same estimator from the same samples (identical while nin is), nin from the fast timing estimate; a frame
-// whose estimate lands within WO_GUARD of a decision threshold is counted in the state header (uncertain_call) so that the host
-// can re-run that capture through the exact kernel.
+// (Round 2 also carried a FAST = true variant of this kernel -- table phasors, prefix-difference window sums, wave-reduced timing sum;
+// DESIGN.md section 7 keeps the measurements.  It was slower than this exact form and is gone.)
 #pragma once
 #include <type_traits>
 
@@ -44,7 +40,6 @@
 #ifndef WO_EXTRA_OUT
 #define WO_EXTRA_OUT 0            // 1: a fifth parked output, on the side of the window rx_timing is nearer to (measured: 12 dB 215 against 208 ms, 8 dB equal, 6 dB 227 against 231)
 #endif
-#define WO_GUARD 2e-5f              // |norm_rx_timing -+ 0.25| below this: the fast estimate does not decide nin(k+1) safely
 
 namespace {
 
@@ -157,25 +152,20 @@ __device__ __forceinline__ float nco_steps_split(float own, float k1, float k2) 
 // Geometries: (M 2, TS 8 | 10, NDFT 256) = Wenet v1 / v2; (M 4, TS 32, NDFT 1024) = BASELINE config 4 (4-FSK, Fs 1 843 200).  The small ones keep every
 // table in LDS and fetch their samples a frame ahead; the large one reads three of the tables through the caches and loads its samples
 // where it uses them (the registers they would sit in are worth more than the microsecond in a 35 us frame).
-template <int M, int TS, int NDFT, bool FAST>
+template <int M, int TS, int NDFT>
 // (launch bounds: the LDS of the large geometry allows <= 10 wavefronts per CU anyway, so it may have 256 VGPRs)
 __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WAVES_PER_EU) void wenet_demod_oct_kernel(WrDemodCfg cfg, const WrChan *chans, int nchan) {
     static_assert(M == 2 || M == 4, "two or four tones");
     static_assert(NDFT == 256 || NDFT == 1024, "a power of four: radix-4 stages only");
     constexpr int H = TS / 2;                                            // checkpoint spacing = the unit of a timing slip
-    constexpr WoLayout LY = wo_layout(M, TS, NDFT, FAST);                // LDS carve-up (wenet_internal.h; the host fills cfg.o_* from the same function)
+    constexpr WoLayout LY = wo_layout(M, TS, NDFT);                // LDS carve-up (wenet_internal.h; the host fills cfg.o_* from the same function)
     constexpr bool SMALL = (NDFT == 256);                                // all tables in LDS, samples fetched a frame ahead
-    constexpr bool AHEAD = !FAST;                                        // the run-ahead schedule of the frame loop (see there)
-    // form of the duty wave's NCO chain: lane-split (plain instructions, half the SIMD time of the packed form) in the run-ahead schedule,
-    // where the capture waves on the duty wave's SIMD are busy meanwhile -- measured better for the 4-FSK geometry too (1 568 steps per
-    // frame, two capture waves per workgroup: 466 against 483 ms for 1024 captures)
-    constexpr bool SPLIT = AHEAD;
     constexpr unsigned ALLOUT = TS == 32 ? 0xffffffffu : (1u << TS) - 1u;
     constexpr int NSD = M == 2 ? 1 : 2;                                  // soft decisions per symbol (fsk.c:955-980)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int G = cfg.o_caps;                                            // captures (= capture waves) of this workgroup
-    const bool is_cap = wave < G, is_chain = !FAST && wave == G, is_sum = is_chain;      // one duty wave: the chain, later the sums
+    const bool is_cap = wave < G, is_chain = wave == G;      // one duty wave: the chain, later the sums
     const int cap = is_cap ? wave : 0;
     const int ch = blockIdx.x * G + cap;
     const bool present = is_cap && ch < nchan;
@@ -236,10 +226,10 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
     for (int b = 0; b < NSD; b++) sdl[b] = 0.f;
     float norm_rx_timing_st = 0.f, ppm = 0.f;
     long long off = 0, frames = 0;
-    int nslip = 0, nuncertain = 0;
+    int nslip = 0;
     bool alive = false;
     if (is_cap) {
-        for (int i = lane; i < NH; i += 64) FE2[(AHEAD ? 2 * NH : 0) + i] = present ? st_fft[i] : 0.f;   // (run-ahead: the frame before the launch's first = slot -1 % 3)
+        for (int i = lane; i < NH; i += 64) FE2[2 * NH + i] = present ? st_fft[i] : 0.f;   // (run-ahead: the frame before the launch's first = slot -1 % 3)
         if (present) {
             if (lane < WR_NSYM) {
 #pragma unroll
@@ -252,24 +242,15 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
         if (lane < M) CT[OC_FBIN + lane] = present ? hdr->f_bin[lane] : 0;           // bins of the frame before this launch
         if (lane == 0) { CT[OC_NIN] = nin; CT[OC_ALIVE] = alive ? 1 : 0; CT[OC_SEQ] = 0; }
     }
-    // duty wave: lane M c + m carries phi_c[m] of capture c, in registers, across the frames.  (Latency, not SIMD time, is what the
-    // chain costs here -- the capture waves wait for it -- so it runs in the packed form: three dependent instructions per step.)
-    v2f own = {1.f, 0.f};
-    float own_s = 0.f;                                                   // run-ahead schedule: lane 2 (M c + m) + part carries one component (nco_steps_split)
-    if (is_chain && SPLIT) {
+    // duty wave: lane 2 (M c + m) + part carries one component of phi_c[m] of capture c, in a register, across the frames (nco_steps_split)
+    float own_s = 0.f;
+    if (is_chain) {
         const int q = lane >> 1, cc = q / M, m = q % M;
         const int chc = blockIdx.x * G + cc;
         own_s = (lane & 1) ? 0.f : 1.f;
         if (cc < G && chc < nchan) {
             const WrChanHdr *h = (const WrChanHdr *)chans[chc].state;
             own_s = (lane & 1) ? h->phi_c[m].y : h->phi_c[m].x;
-        }
-    } else if (is_chain) {
-        const int cc = lane / M, m = lane % M;
-        const int chc = blockIdx.x * G + cc;
-        if (cc < G && chc < nchan) {
-            const WrChanHdr *h = (const WrChanHdr *)chans[chc].state;
-            own = (v2f){h->phi_c[m].x, h->phi_c[m].y};
         }
     }
     lds_barrier();
@@ -337,9 +318,8 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
     };
 
     // E(j): tone estimator (fsk.c:540-677) on the prefetched samples; one FFT (Ndft <= nin < 2 Ndft)
-    int fecur = 0;                                                       // FE2[fecur]: spectrum after the estimator run of the frame in work
-    // E(j) in two parts: estimate_fft (window + FFT, leaves the spectrum in FB) and estimate_pick (magnitude, smoothing, tone
-    // search: reads FE2[fecur], leaves FE2[fecur ^ 1] and the bins in OC_FBINN)
+    // E(j) in two parts: estimate_fft (window + FFT, leaves the spectrum in FB) and estimate_pick_to (magnitude, smoothing, tone
+    // search: reads one slot of the spectrum ring FE2, leaves the next)
     // Ndft = 4^k points = k radix-4 stages of kiss_fft's decimation-in-time recursion (kiss_fft.c:237-302, kf_bfly4 :44-90), innermost
     // butterflies first.  Lane b loads the four digit-reversed inputs of ITS first butterfly (elements 4b .. 4b+3), so the window
     // goes straight into stage one; that stage's twiddles are all tw[0] = (1, -0), a multiplication that changes nothing but the
@@ -463,28 +443,6 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
 #pragma unroll
         for (int m = 0; m < M; m++) bins_out[m] = fbin[m];
     };
-    auto estimate_pick = [&]() __attribute__((always_inline)) {
-        int fb[M];
-        estimate_pick_to(fecur, fecur ^ 1, fb);
-        if (lane == 0) {
-#pragma unroll
-            for (int m = 0; m < M; m++) CT[OC_FBINN + m] = fb[m];
-        }
-        wave_sync();
-    };
-    auto estimate = [&](int nin_j) __attribute__((always_inline)) { estimate_fft(nin_j); estimate_pick(); };
-    // the frame whose estimator run is in OC_FBINN / FE2[fecur ^ 1] becomes the frame in work.  First-run rule (fsk.c:750-753): while
-    // the stored estimate of tone 0 is below 1 Hz the old part of the frame is mixed with the NEW estimates
-    auto commit_estimate = [&]() __attribute__((always_inline)) {
-        if (lane == 0) {
-            const bool first = CT[OC_FBIN] < cfg.o_first_bins;                // bin_freq[stored bin of tone 0] < 1.0f
-#pragma unroll
-            for (int m = 0; m < M; m++) { const int nb = CT[OC_FBINN + m]; CT[OC_FBINP + m] = first ? nb : CT[OC_FBIN + m]; CT[OC_FBIN + m] = nb; }
-        }
-        fecur ^= 1;
-        wave_sync();
-    };
-
     // The integrator outputs of this lane's symbol slot (fsk.c:803-841: M x TS complex values per lane) are needed twice: at once
     // for the timing products, and after the timing estimate for the two of them the symbol is resampled from.  Holding them in
     // registers across the timing sum would cost 40 VGPRs per wave (and a CU another workgroup); they are parked in the capture's
@@ -542,52 +500,30 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
 #pragma unroll(FT1_LDS ? 1 : M)                                         // (large slots: one tone's code, run M times -- d[] alone is 2 TS registers)
         for (int m = 0; m < M; m++) {
             v2f d[TS];
-            if (!FAST) {
-                const float2 dA2 = dphi_t[CT[OC_FBINP + m]], dB2 = dphi_t[CT[OC_FBIN + m]];
+            const float2 dA2 = dphi_t[CT[OC_FBINP + m]], dB2 = dphi_t[CT[OC_FBIN + m]];
 #pragma unroll
-                for (int hh = 0; hh < 2; hh++) {
-                    const int hb = 2 * slot + hh;
-                    const float2 p2 = CK[(AHEAD ? ckpar * M * NHB : 0) + m * NHB + (hb < NHB ? hb : NHB - 1)];
-                    v2f phi = {p2.x, p2.y};
-                    const bool segA = hb * H < nold;
-                    const v2f dd = {segA ? dA2.x : dB2.x, segA ? dA2.y : dB2.y};
+            for (int hh = 0; hh < 2; hh++) {
+                const int hb = 2 * slot + hh;
+                const float2 p2 = CK[ckpar * M * NHB + m * NHB + (hb < NHB ? hb : NHB - 1)];
+                v2f phi = {p2.x, p2.y};
+                const bool segA = hb * H < nold;
+                const v2f dd = {segA ? dA2.x : dB2.x, segA ? dA2.y : dB2.y};
 #pragma unroll
-                    for (int u = 0; u < H; u++) {
-                        d[hh * H + u] = cmul_conj_pk(SMALL ? slot_sample(hh * H + u) : xs[SMALL ? 0 : hh * H + u], phi);   // fsk.c:796 / :822
-                        if (u < H - 1) phi = cmul_pk(phi, dd);                                     // fsk.c:798 / :824 (replayed from the checkpoint)
-                    }
+                for (int u = 0; u < H; u++) {
+                    d[hh * H + u] = cmul_conj_pk(SMALL ? slot_sample(hh * H + u) : xs[SMALL ? 0 : hh * H + u], phi);   // fsk.c:796 / :822
+                    if (u < H - 1) phi = cmul_pk(phi, dd);                                     // fsk.c:798 / :824 (replayed from the checkpoint)
                 }
-                // slot-ordered window sums (fsk.c:829-840), see the header: `run` is the block's running prefix sum
-                v2f run = (v2f){0.f, 0.f} + d[0];
-                static_for<1, TS>([&](auto rc) __attribute__((always_inline)) {
-                    constexpr int r = decltype(rc)::value;
-                    v2f acc = lane_up(run) + d[r];
-                    acc = pk_add_seq<TS - 1 - r>(acc, &d[r < TS - 1 ? r + 1 : r]);
-                    put_out(m, r, acc);
-                    run = run + d[r];
-                });
-                put_out(m, 0, run);
-            } else {
-#pragma clang fp contract(fast)
-                // phasor of buffer position s: the old part of the frame turns with the previous bin, the new part with this frame's,
-                // phase-continuous at s = nold (fsk.c:756-764,785-788); angles are multiples of 2 pi / Ndft
-                const int bp = CT[OC_FBINP + m], bc = CT[OC_FBIN + m];
-                const int s0 = TS * ln;
-                v2f tot = {0.f, 0.f};
-#pragma unroll
-                for (int u = 0; u < TS; u++) {
-                    const int s = s0 + u;
-                    const int k = (s < nold) ? bp * s : bp * nold + bc * (s - nold);
-                    const float2 w = tw_t[k & (Ndft - 1)];                // e^{-j 2 pi k / Ndft} = conj(phasor)
-                    const v2f x = SMALL ? slot_sample(u) : xs[SMALL ? 0 : u];
-                    d[u] = (v2f){x.x * w.x - x.y * w.y, x.x * w.y + x.y * w.x};
-                    tot = tot + d[u];
-                }
-                put_out(m, 0, tot);
-                v2f run = d[0];                                          // window r = (this block without its first r samples) + (the next block's first r)
-#pragma unroll
-                for (int r = 1; r < TS; r++) { put_out(m, r, (tot - run) + lane_up(run)); run = run + d[r]; }
             }
+            // slot-ordered window sums (fsk.c:829-840), see the header: `run` is the block's running prefix sum
+            v2f run = (v2f){0.f, 0.f} + d[0];
+            static_for<1, TS>([&](auto rc) __attribute__((always_inline)) {
+                constexpr int r = decltype(rc)::value;
+                v2f acc = lane_up(run) + d[r];
+                acc = pk_add_seq<TS - 1 - r>(acc, &d[r < TS - 1 ? r + 1 : r]);
+                put_out(m, r, acc);
+                run = run + d[r];
+            });
+            put_out(m, 0, run);
             if (FT1_LDS && ln < NOUT) {                                  // ft1 += this tone's powers (fsk.c:866), four outputs per LDS access
                 typedef float v4f __attribute__((ext_vector_type(4)));
                 v4f *T4 = (v4f *)Trow;
@@ -598,89 +534,27 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
                 }
             }
         }
-        if (!FAST) {
-            if (ln < NOUT) {
+        if (ln < NOUT) {
 #pragma unroll
-                for (int r = 0; r < TS; r += 2) {                        // fsk.c:870-871: the products; the duty wave adds them in order
-                    const v2f pa = pft_t[TS * ln + r], pb = pft_t[TS * ln + r + 1];
-                    const float fa = FT1_LDS ? Trow[r] : ft1[FT1_LDS ? 0 : r], fb = FT1_LDS ? Trow[r + 1] : ft1[FT1_LDS ? 0 : r + 1];
-                    const v2f ta = (v2f){fa, fa} * (v2f){pa.x, pa.y}, tb = (v2f){fb, fb} * (v2f){pb.x, pb.y};
-                    *(float2 *)(TPf + TS * ln + r) = make_float2(ta.x, tb.x);
-                    *(float2 *)(TPf + NIq + TS * ln + r) = make_float2(ta.y, tb.y);
-                }
+            for (int r = 0; r < TS; r += 2) {                        // fsk.c:870-871: the products; the duty wave adds them in order
+                const v2f pa = pft_t[TS * ln + r], pb = pft_t[TS * ln + r + 1];
+                const float fa = FT1_LDS ? Trow[r] : ft1[FT1_LDS ? 0 : r], fb = FT1_LDS ? Trow[r + 1] : ft1[FT1_LDS ? 0 : r + 1];
+                const v2f ta = (v2f){fa, fa} * (v2f){pa.x, pa.y}, tb = (v2f){fb, fb} * (v2f){pb.x, pb.y};
+                *(float2 *)(TPf + TS * ln + r) = make_float2(ta.x, tb.x);
+                *(float2 *)(TPf + NIq + TS * ln + r) = make_float2(ta.y, tb.y);
             }
-        } else {
-            float sr = 0.f, si = 0.f;
-            if (ln < NOUT) {
-#pragma unroll
-                for (int r = 0; r < TS; r++) {
-                    const v2f pf = pft_t[TS * ln + r];
-                    const float fa = FT1_LDS ? Trow[r] : ft1[FT1_LDS ? 0 : r];
-                    sr += fa * pf.x; si += fa * pf.y;
-                }
-            }
-#pragma unroll
-            for (int sh = 32; sh >= 1; sh >>= 1) { sr += __shfl_xor(sr, sh, 64); si += __shfl_xor(si, sh, 64); }
-            if (lane == 0) { ((float *)CT)[OC_TC] = sr; ((float *)CT)[OC_TC + 1] = si; }
         }
         wave_sync();
     };
 
-    // T(j): timing estimate, nin of the next frame, resampling and decisions (fsk.c:876-993); returns nin(j+1)
-    // T(j) in two parts.  tstage1: timing estimate and nin of the next frame (fsk.c:876-907) -- everything the next frame's NCO
-    // chain waits for; tstage2: resampling, decisions, outputs (fsk.c:913-993).
+    // T(j) in two parts.  The timing estimate and nin of the next frame (fsk.c:876-907) -- everything the next frame's NCO chain waits
+    // for -- are formed by the duty wave (frame loop); tstage2_load / _finish: resampling, decisions, outputs (fsk.c:913-993).
     float t_rxt = 0.f, t_fract = 0.f;
     int t_low = 0, t_high = 0, t_nin_next = 0, t_bins[M];               // (t_bins: tone bins of the frame, for the trace)
 #pragma unroll
     for (int m = 0; m < M; m++) t_bins[m] = 0;
     bool t_nan = false;
-    // nin(k+1) first: norm_rx_timing = (float)((double)atan2f / 2 pi) is monotone in the atan2f value, so "norm_rx_timing > 0.25f"
-    // is the same predicate as "atan2f > o_at_hi" (the host finds the float where it flips, DemodTables::oct_cfg): the double
-    // division leaves the path the next frame's NCO chain waits on
-    float t_at = 0.f, t_tcr = 0.f, t_tci = 0.f;
-    float t_nrt_before = 0.f, t_ppm_before = 0.f;                        // (run-ahead schedule: what tstage1b() changed, for a frame that is mixed twice)
-    bool t_have_at = false;
-    auto tstage1a = [&]() __attribute__((always_inline)) -> int {
-        const float tcr = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(((const float *)CT)[OC_TC])));
-        const float tci = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(((const float *)CT)[OC_TC + 1])));
-        t_nan = (tcr != tcr) || (tci != tci);                            // fsk.c:878-880
-        int nin_next = nin;
-        t_have_at = false;
-        if (!t_nan) {
-            // an angle well inside (-pi/2, pi/2) -- |angle| < atan(16) = 86.4 degrees, all but a few per cent of the frames of a locked
-            // signal -- leaves nin at N whatever the last bits of atan2f are: the value itself is then computed after the publication
-            if (16.0f * tcr > fabsf(tci)) nin_next = N;
-            else {
-                t_at = wg_atan2f(tci, tcr); t_have_at = true;
-                nin_next = t_at > cfg.o_at_hi ? N + TS / 2 : (t_at < cfg.o_at_lo ? N - TS / 2 : N);  // fsk.c:900-907
-            }
-        }
-        t_tcr = tcr; t_tci = tci;
-        t_nin_next = __builtin_amdgcn_readfirstlane(nin_next);
-        return t_nin_next;
-    };
-    auto tstage1b = [&]() __attribute__((always_inline)) {
-        t_rxt = 0.f;
-        t_nrt_before = norm_rx_timing_st; t_ppm_before = ppm;
-        if (!t_nan) {
-            if (!t_have_at) t_at = wg_atan2f(t_tci, t_tcr);
-            const float at = t_at;
-            const float norm_rx_timing = (float)((double)at / (2 * 3.14159265358979323846));
-            const float rx_timing = norm_rx_timing * cfg.P_f;
-            const float d_nrt = norm_rx_timing - norm_rx_timing_st;
-            norm_rx_timing_st = norm_rx_timing;
-            // ppm (fsk.c:890-896) feeds nothing but the statistics: it is kept up only when a trace is asked for
-            if (C.trace && (double)fabsf(d_nrt) < .2) {
-                const float appm = (float)(1e6 * (double)d_nrt / (double)cfg.nsym_f);
-                ppm = (float)(.9 * (double)ppm + .1 * (double)appm);
-            }
-            if (FAST && (fabsf(norm_rx_timing - 0.25f) < WO_GUARD || fabsf(norm_rx_timing + 0.25f) < WO_GUARD)) nuncertain++;
-            t_low = __builtin_amdgcn_readfirstlane((int)floorf(rx_timing));
-            t_fract = rx_timing - (float)t_low;
-            t_high = __builtin_amdgcn_readfirstlane((int)ceilf(rx_timing));
-            t_rxt = rx_timing;
-        }
-    };
+    float t_tcr = 0.f, t_tci = 0.f;                                      // the frame's timing sum (read from the duty wave's order words)
     // the 2 W + 2 outputs frame k+1 parks if frame k's rx_timing is rt (low = floor(rt), W = wo_park_halfwidth): offsets low-W .. low+W+1 cover every
     // rx_timing within W - 0.06 samples of rt
     auto window_mask = [&](int low, int extra = 0) __attribute__((always_inline)) -> unsigned {
@@ -690,13 +564,6 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
         for (int j = -W; j <= W + 1; j++) { const int x = low + j + TS; mk |= 1u << ((x >= TS ? x - TS : x) % TS); }   // (low >= -TS/2: x >= 0; the % folds away for x < 2 TS)
         if (extra) { const int x = low + (extra < 0 ? -W - 1 : W + 2) + TS; mk |= 1u << ((x >= TS ? x - TS : x) % TS); }   // one more on the side the estimate sits nearer to
         return mk;
-    };
-    // is this frame's timing vector within W - 0.06 samples of rx_timing ((W - 0.06) * 360 / P degrees: 34 at P = 10, 33 at P = 32) of the previous frame's?
-    // (o_near_cos2 = cos^2 of that angle; all of this is wave-uniform arithmetic with 6 % of a sample to spare for its rounding)
-    auto timing_near_previous = [&]() __attribute__((always_inline)) -> bool {
-        const float dot = t_tcr * pv_r + t_tci * pv_i;
-        const float n2 = (t_tcr * t_tcr + t_tci * t_tci) * (pv_r * pv_r + pv_i * pv_i);
-        return !t_nan && dot > 0.f && dot * dot > cfg.o_near_cos2 * n2;     // false for a zero or NaN vector
     };
     v2f t2a[M], t2b[M];                                                  // the parked outputs the frame's symbols are resampled from
     auto tstage2_load = [&]() __attribute__((always_inline)) {
@@ -755,52 +622,10 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
             tr[WR_TR_RXT] = t_rxt;
         }
     };
-    auto tstage2 = [&](long long fr) __attribute__((always_inline)) { tstage2_load(); tstage2_finish(fr); };
 
     // ================================ narrow stages (exact mode) ===============================
-    // C(j) of the captures in `mask`: lanes 2M c .. 2M c + 2M - 1
-    auto chain = [&](int mask) __attribute__((always_inline)) {
-        const int cc = lane / M;
-        if (cc >= G || !((mask >> cc) & 1)) return;
-        const int m = lane % M;
-        const int *CTc = CT0 + cc * ctw;
-        v2f *ck = (v2f *)(smem_all + cc * LY.stride + LY.CK) + (AHEAD ? CTc[OC_CREG] * M * NHB : 0) + m * NHB;
-        const int nin_j = CTc[AHEAD ? OC_CNIN : OC_NIN];
-        const int nold = Nmem - nin_j;
-        const int bc = CTc[(AHEAD ? OC_CBC : OC_FBIN) + m], bp = CTc[(AHEAD ? OC_CBP : OC_FBINP) + m];
-        const int ncase = (nin_j < N) ? 0 : ((nin_j > N) ? 2 : 1);
-        const float2 bo = (SMALL && ncase == 1) ? ((const float2 *)(smem_all + (G * LY.stride + LY.BACK)))[bp] : back_t[ncase * NH + bp];
-        own = cmul_pk((v2f){bo.x, bo.y}, own);                           // fsk.c:758-759
-        const float2 d0 = dphi_t[bp], d1 = dphi_t[bc];
-        v2f d = {d0.x, d0.y};
-        const int hsw = nold / H;                                        // 3, 4 or 5: the half symbol that starts with the new samples
-        int hb = 0;
-        auto blocks = [&](int upto) __attribute__((always_inline)) {
-#pragma unroll 1
-            for (; hb < upto; hb++) { ck[hb] = own; own = nco_steps<H>(own, d); }
-        };
-        auto swtch = [&]() __attribute__((always_inline)) {                                             // fsk.c:785-788: normalise, continue with this frame's estimate
-            if (hb == hsw) {
-                const float av = sqrtf(own.x * own.x + own.y * own.y);
-                own = (v2f){own.x / av, own.y / av};
-                d = (v2f){d1.x, d1.y};
-            }
-        };
-        blocks(3); swtch(); blocks(4); swtch(); blocks(5); swtch();
-        const int full = L / H;
-#pragma unroll 1
-        for (; hb + 8 <= full; hb += 8) {                                // eight checkpoints per trip: a taken branch costs ~16 cycles
-#pragma unroll
-            for (int k = 0; k < 8; k++) { ck[hb + k] = own; own = nco_steps<H>(own, d); }
-        }
-        blocks(full);
-        if (full * H < L) {
-            ck[hb] = own;
-            for (int s = full * H; s < L; s++) own = cmul_pk(own, d);
-        }
-    };
-
-    // the same chain in the lane-split form (run-ahead schedule: the capture waves of the duty wave's SIMD mix their frames meanwhile)
+    // C(j) of the captures in `mask`, lane-split form: lanes 2 (M c + m), + 1 carry re, im of tone m of capture c (plain instructions, half the
+    // SIMD time of a packed chain: the capture waves of the duty wave's SIMD mix their frames meanwhile)
     auto chain_split = [&](int mask) __attribute__((always_inline)) {
         const int q = lane >> 1, part = lane & 1;
         const int cc = q / M;
@@ -886,32 +711,10 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
     };
 
     // ================================ frame loop ===============================================
-    // (exact mode: the run-ahead schedule, described where it starts below; fast mode: every capture wave on its own, no barriers)
+    // (the run-ahead schedule, described where it starts below)
     int ran = 0;                                                         // duty wave: captures that demodulated at least one frame
-    if (is_cap && FAST && alive) { prefetch_est(0); if (SMALL) prefetch_slot(0, nin); estimate(nin); commit_estimate(); }
     int sw = 0;                                                          // run-ahead schedule: ring slot (FE2) of the spectrum after the frame in work's estimator run
-    if (FAST) {
-        // no shared stages: every capture wave runs on its own
-        while (alive) {
-            const long long off1 = off + nin;
-            if (SMALL) prefetch_est(off1);
-            dstage(off, nin, omask, true);
-#pragma unroll
-            for (int m = 0; m < M; m++) t_bins[m] = CT[OC_FBIN + m];
-            const int nn = tstage1a();
-            tstage1b();
-            if (!t_nan && !(((omask >> (t_low >= 0 ? t_low : TS + t_low)) & (omask >> (t_high >= 0 ? t_high : TS + t_high))) & 1))
-                dstage(off, nin, ALLOUT, false);                 // prediction missed: integrate again, park everything
-            omask = (!t_nan && timing_near_previous()) ? window_mask(t_low) : ALLOUT;
-            pv_r = t_nan ? 0.f : t_tcr; pv_i = t_nan ? 0.f : t_tci;
-            tstage2(frames);
-            const bool more = off1 + nn <= C.nsamples && frames + 1 < C.cap_frames;
-            nslip += (nn != N) ? 1 : 0;
-            off = off1; nin = nn; frames++;
-            alive = more;
-            if (alive) { if (SMALL) prefetch_slot(off, nin); else prefetch_est(off); estimate(nin); commit_estimate(); }
-        }
-    } else {
+    {
         // ---- the run-ahead schedule (exact mode) ---------------------------------------------------------------
         // A capture's frames form one dependency chain: NCO chain(k) -> mix / integrate(k) -> ordered timing sum(k) -> nin(k+1) ->
         // chain(k+1).  Run in that order (the loop below this one) the duty wave idles through the wide stage and the capture waves
@@ -972,7 +775,6 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
         // One copy of the loop per role: a wave never changes its role, so inside its copy only that role's values are live.
         if (is_chain) {
             float own_m1 = own_s;                                        // the phasors before the last chain that was run
-            v2f own_m1p = own;                                           // (packed form)
             int mask = (1 << G) - 1;
             int selfmask = 0;                                            // captures whose next chain is the speculative one they wrote down beforehand
             for (long long kf = 0;; kf++) {
@@ -981,16 +783,16 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
                         while (__hip_atomic_load((int *)&CT0[c * ctw + OC_SEQ], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (int)(kf + 1)) __builtin_amdgcn_s_sleep(1);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 WO_STAMP(0);
-                constexpr int LPC = SPLIT ? 2 * M : M;                   // chain lanes per capture
+                constexpr int LPC = 2 * M;                               // chain lanes per capture
                 const int cc = lane / LPC;
                 int req = 0;
                 if (cc < G && ((mask >> cc) & 1)) req = CT0[cc * ctw + OC_REQ];
-                if (req == OC_REQ_SPEC) { own_m1 = own_s; own_m1p = own; }
-                else if (req == OC_REQ_TRUE || req == OC_REQ_DEAD) { own_s = own_m1; own = own_m1p; }
+                if (req == OC_REQ_SPEC) own_m1 = own_s;
+                else if (req == OC_REQ_TRUE || req == OC_REQ_DEAD) own_s = own_m1;
                 const unsigned long long bal = __ballot(req == OC_REQ_SPEC || req == OC_REQ_TRUE);
                 int m2 = 0;
                 for (int c = 0; c < G; c++) m2 |= (int)((bal >> (c * LPC)) & 1ull) << c;
-                if (m2) { if (SPLIT) chain_split(m2); else chain(m2); ran |= m2; }
+                if (m2) { chain_split(m2); ran |= m2; }
                 WO_STAMP(1);
                 lds_barrier();                                           // timing products of the frames in work; checkpoints of the requested chains
                 WO_STAMP(2);
@@ -1020,7 +822,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
                             const float nrt = (float)((double)at / (2 * 3.14159265358979323846));
                             const float rxt = nrt * cfg.P_f;
                             const int low = (int)floorf(rxt), high = (int)ceilf(rxt);
-                            const int nnc = at > cfg.o_at_hi ? 2 : (at < cfg.o_at_lo ? 0 : 1);               // fsk.c:900-907 (see tstage1a)
+                            const int nnc = at > cfg.o_at_hi ? 2 : (at < cfg.o_at_lo ? 0 : 1);               // fsk.c:900-907
                             self = (fl & 1) && nnc == 1 && ((fl & 2) || near);
                             ord = 1 | (self ? 2 : 0) | (near ? 4 : 0) | (nnc << 4) | ((low + 64) << 8) | ((high + 64) << 16);
                             ((float *)CTc)[OC_O_NRT] = nrt; ((float *)CTc)[OC_O_FRACT] = rxt - (float)low; ((float *)CTc)[OC_O_RXT] = rxt;
@@ -1097,7 +899,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
                             t_rxt = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(o4.z)));
                             t_low = ((ordw >> 8) & 0xff) - 64; t_high = ((ordw >> 16) & 0xff) - 64;
                             nn = N + (((ordw >> 4) & 3) - 1) * (TS / 2);
-                            t_nan = false; t_have_at = false; t_nin_next = nn;
+                            t_nan = false; t_nin_next = nn;
                             near_prev = (ordw & 4) != 0;
                             did_1b = true;
                         } else {                                         // NaN timing sums (fsk.c:878-880): nin stays, the last decisions are emitted again
@@ -1116,7 +918,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
                             request(0, nin, b_w, b_pv, ckpar, true, kf + 2);
                             if (SMALL) prefetch_slot(off, nin);          // (this frame's samples again)
                         } else {
-                            if (ordered) {                               // the rest of tstage1b(): fsk.c:887-896
+                            if (ordered) {                               // fsk.c:887-896
                                 const float d_nrt = o_nrt - norm_rx_timing_st;
                                 norm_rx_timing_st = o_nrt;
                                 if (C.trace && (double)fabsf(d_nrt) < .2) {
@@ -1197,7 +999,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
     // ================================ save carried state =======================================
     if (is_cap && present) {
         if (frames > 0) {
-            for (int i = lane; i < NH; i += 64) st_fft[i] = FE2[(AHEAD ? sw : fecur) * NH + i];
+            for (int i = lane; i < NH; i += 64) st_fft[i] = FE2[sw * NH + i];
             for (int i = lane; i < nstash; i += 64) st_old[i] = cvt(raw16[off - nstash + i]);     // fsk.c:851 (off >= nin > nstash)
             if (lane < WR_NSYM) {
 #pragma unroll
@@ -1212,23 +1014,16 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
             hdr->frames_total += frames;
             hdr->frames_call = frames;
             hdr->slips_call = nslip;
-            hdr->uncertain_call = nuncertain;
+            hdr->uncertain_call = 0;
             hdr->consumed_call = off;
         }
     }
-    if (is_chain && SPLIT) {
+    if (is_chain) {                                                      // un-normalised, as saved at fsk.c:846
         const int q = lane >> 1, cc = q / M, m = q % M;
         const int chc = blockIdx.x * G + cc;
         if (cc < G && chc < nchan && ((ran >> cc) & 1)) {
             WrChanHdr *h = (WrChanHdr *)chans[chc].state;
             ((float *)&h->phi_c[m])[lane & 1] = own_s;
-        }
-    } else if (is_chain) {                                               // un-normalised, as saved at fsk.c:846
-        const int cc = lane / M, m = lane % M;
-        const int chc = blockIdx.x * G + cc;
-        if (cc < G && chc < nchan && ((ran >> cc) & 1)) {
-            WrChanHdr *h = (WrChanHdr *)chans[chc].state;
-            h->phi_c[m] = make_float2(own.x, own.y);
         }
     }
 }

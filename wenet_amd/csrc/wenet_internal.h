@@ -91,21 +91,20 @@ struct WrDemodCfg {
 constexpr int wo_park_halfwidth(int Ts) { return Ts >= 32 ? 3 : 1; }
 struct WoLayout { int FB, FW, TP, FE, CK, CT, stride, ntw, TW, HANN, DPHI, SRC, BACK, tab, nhb; };
 constexpr int wo_align16(int x) { return (x + 15) & ~15; }
-constexpr WoLayout wo_layout(int M, int Ts, int Ndft, bool fast) {
+constexpr WoLayout wo_layout(int M, int Ts, int Ndft) {
     WoLayout y{};
-    const bool small = Ndft == 256, ahead = !fast;
+    const bool small = Ndft == 256;
     const int NH = Ndft / 2, NI = 49 * Ts, NIq = (NI + 3) & ~3, H = Ts / 2, L = 50 * Ts - 1;
     y.nhb = (L + H - 1) / H;
     int t = 0;
     y.FB = t;  t = wo_align16(t + Ndft * 8);
-    if (ahead) y.FW = y.FB + NH * 8;
+    y.FW = y.FB + NH * 8;
     y.TP = t;  t = wo_align16(t + 2 * NIq * 4);
-    y.FE = t;  t = wo_align16(t + (ahead ? 3 : 2) * NH * 4);
-    if (!ahead) { y.FW = t;  t = wo_align16(t + NH * 4); }
-    y.CK = t;  t = wo_align16(t + (ahead ? 2 : (fast ? 0 : 1)) * M * y.nhb * 8);
+    y.FE = t;  t = wo_align16(t + 3 * NH * 4);
+    y.CK = t;  t = wo_align16(t + 2 * M * y.nhb * 8);
     y.CT = t;  t = wo_align16(t + 32 * 4);
-    y.stride = ahead ? ((t + 31) & ~31) : ((t + 127) & ~127);
-    y.ntw = ahead ? 3 * Ndft / 4 : Ndft;                             // (the transform's largest twiddle index is 3 (Ndft/4 - 1))
+    y.stride = (t + 31) & ~31;
+    y.ntw = 3 * Ndft / 4;                                                        // (the transform's largest twiddle index is 3 (Ndft/4 - 1))
     int tab = 0;
     y.TW = tab;   tab = wo_align16(tab + y.ntw * 8);
     y.HANN = tab; tab = wo_align16(tab + Ndft * 4);
@@ -126,7 +125,7 @@ struct WrChanHdr {
     float  ppm;                 // fsk.h:80
     int    nin;                 // fsk.h:83
     int    slips_call;          // frames of the last launch whose nin differed from N (pipelined kernels: speculation misses)
-    int    uncertain_call;      // fast mode: frames of the last launch whose timing estimate fell within the guard band of a nin threshold
+    int    uncertain_call;      // (unused since the fast mode of round 2 was removed; kept so that the state layout stays)
     int    pad0;
     long long frames_total;     // frames demodulated since create
     long long frames_call;      // frames produced by the last launch

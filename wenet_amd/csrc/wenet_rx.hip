@@ -26,7 +26,7 @@
 extern "C" hipError_t wr_launch_demod(const WrDemodCfg *cfg, const WrChan *d_chans, int nchan, hipStream_t stream);
 extern "C" hipError_t wr_launch_demod_pipe(const WrDemodCfg *cfg, const WrChan *d_chans, int nchan, hipStream_t stream, int prof);
 extern "C" hipError_t wr_launch_demod_ex(const WrDemodCfg *cfg, const WrChan *d_chans, int nchan, hipStream_t stream, int prof);
-extern "C" hipError_t wr_launch_demod_oct(const WrDemodCfg *cfg, const WrChan *d_chans, int nchan, hipStream_t stream, int fast);
+extern "C" hipError_t wr_launch_demod_oct(const WrDemodCfg *cfg, const WrChan *d_chans, int nchan, hipStream_t stream);
 extern "C" hipError_t wr_launch_deframe(const WrDeframeChan *d_chans, int nchan, int mode, hipStream_t stream);
 extern "C" hipError_t wr_launch_decode(const WrDecodeArgs *args, hipStream_t stream);
 extern "C" hipError_t wr_launch_phi0(const uint4 *d_lut, const float *d_x, float *d_y, long long n, hipStream_t stream);
@@ -172,7 +172,7 @@ struct DemodTables {
 
     // configuration copy for the batch kernel with one wavefront per capture (demod_oct_impl.h), caps captures per workgroup;
     // o_ok == 0 in it if the geometry is not one it was written for (two tones, Ts 8 or 10 with P = Ts, one 256-point FFT per frame)
-    WrDemodCfg oct_cfg(int caps, bool fast = false) const {
+    WrDemodCfg oct_cfg(int caps) const {
         WrDemodCfg c = cfg;
         c.o_ok = 0;
         const bool small = cfg.M == 2 && (cfg.Ts == 8 || cfg.Ts == 10) && cfg.Ndft == 256;       // Wenet v1 / v2
@@ -181,7 +181,7 @@ struct DemodTables {
             cfg.N < cfg.Ndft + cfg.Ts / 2 || cfg.N + cfg.Ts / 2 >= 2 * cfg.Ndft || getenv("WENET_RX_NO_OCT") != nullptr)
             return c;
         const int NH = cfg.Ndft / 2;
-        const WoLayout y = wo_layout(cfg.M, cfg.Ts, cfg.Ndft, fast);     // (wenet_internal.h: the kernel uses the same function at compile time)
+        const WoLayout y = wo_layout(cfg.M, cfg.Ts, cfg.Ndft);     // (wenet_internal.h: the kernel uses the same function at compile time)
         if (cfg.L != 50 * cfg.Ts - 1 || cfg.NI != 49 * cfg.Ts) return c;
         c.o_nhb = y.nhb;
         c.o_off_FB = y.FB; c.o_off_FW = y.FW; c.o_off_TP = y.TP; c.o_off_FE = y.FE; c.o_off_CK = y.CK; c.o_off_CT = y.CT;
@@ -804,7 +804,7 @@ int run_dense(int kind, const void *in, int npk, int n, int mode, int max_iter, 
     if (!g_dec.d_in.reserve(in_bytes) || !g_dec.d_out.reserve((size_t)npk * sizeof(WrPacketOut)) || !g_dec.d_npk.reserve(16)) return -2;
     if (llr_host && !g_dec.d_llr.reserve((size_t)npk * n * 4)) return -2;
     if (bits_host && !g_dec.d_bits.reserve((size_t)npk * WR_NCODE)) return -2;
-    if (!g_dec.d_esn0.reserve((size_t)npk * 8)) return -2;
+    if (!g_dec.d_esn0.reserve((size_t)npk * 8 + 256)) return -2;        // (+ the work counter behind the last estimate)
     WR_CHECK(hipMemcpy(g_dec.d_in.p, in, in_bytes, hipMemcpyHostToDevice), -3);
     WR_CHECK(hipMemset(g_dec.d_out.p, 0, (size_t)npk * sizeof(WrPacketOut)), -3);
     WR_CHECK(hipMemcpy(g_dec.d_npk.p, &npk, 4, hipMemcpyHostToDevice), -3);
@@ -820,7 +820,7 @@ int run_dense(int kind, const void *in, int npk, int n, int mode, int max_iter, 
     a.llr_out = llr_host ? g_dec.d_llr.as<float>() : nullptr;
     a.bits_out = bits_host ? g_dec.d_bits.as<uint8_t>() : nullptr;
     a.esn0 = g_dec.d_esn0.as<double>();
-    a.work = (unsigned *)(g_dec.d_esn0.as<double>() + npk);            // (DevBuf::reserve leaves >= 256 bytes of slack)
+    a.work = (unsigned *)(g_dec.d_esn0.as<double>() + npk);            // (inside the 256 bytes reserved behind the estimates)
     fill_decode_tables(a, t);
     WR_CHECK(wr_launch_decode(&a, 0), -4);
     WR_CHECK(hipDeviceSynchronize(), -4);
@@ -894,7 +894,7 @@ extern "C" long wenet_deframer_push(wenet_deframer *d, const float *symbols, lon
     const long long n = (long long)d->carry.size();
     if (n == 0) return 0;
     const int max_pk = (int)(n / d->spp + 1);
-    if (!d->d_sd.reserve((size_t)n * 4) || !d->d_starts.reserve((size_t)max_pk * 8) || !d->d_out.reserve((size_t)max_pk * sizeof(WrPacketOut)) || !d->d_esn0.reserve((size_t)max_pk * 8)) return -2;
+    if (!d->d_sd.reserve((size_t)n * 4) || !d->d_starts.reserve((size_t)max_pk * 8) || !d->d_out.reserve((size_t)max_pk * sizeof(WrPacketOut)) || !d->d_esn0.reserve((size_t)max_pk * 8 + 256)) return -2;
     WR_CHECK(hipMemcpy(d->d_sd.p, d->carry.data(), (size_t)n * 4, hipMemcpyHostToDevice), -3);
     WrDeframeState st;
     memset(&st, 0, sizeof(st));
@@ -941,9 +941,7 @@ struct wenet_rx {
     DemodTables tab;
     int mode = 1, max_iter = 10, spp = 3230;
     bool want_trace = false, want_llr = false;
-    int fast = 0;                                        // 1: parity-ladder rung P3 demodulator (demod_oct_impl.h, FAST) with exact re-runs
     const char *last_kernel = "";                        // demod kernel of the last enqueue
-    long long fast_flagged = 0;                          // captures of the last fast batch that were re-run through the exact kernel
     int nchan = 0, max_pk = 0;
     std::vector<long long> sd_off, cap_frames;           // per channel: float offset into d_sd, frame capacity
     DevBuf d_states, d_chans, d_chans2, d_dchans, d_dstates, d_sd, d_starts, d_out, d_trace, d_llr, d_raw, d_prof, d_esn0, d_census, d_big;
@@ -1020,9 +1018,7 @@ extern "C" int wenet_rx_packet_census(wenet_rx *rx, int ch, long long counts[8])
 }
 extern "C" void wenet_rx_enable_trace(wenet_rx *rx, int on) { if (rx) { rx->want_trace = on != 0; rx->tab.cfg.stats = on ? 1 : 0; } }
 extern "C" void wenet_rx_enable_llr_dump(wenet_rx *rx, int on) { if (rx) rx->want_llr = on != 0; }
-extern "C" void wenet_rx_set_fast(wenet_rx *rx, int on) { if (rx) rx->fast = on ? 1 : 0; }
 extern "C" const char *wenet_rx_last_kernel(wenet_rx *rx) { return rx ? rx->last_kernel : ""; }
-extern "C" long long wenet_rx_fast_reruns(wenet_rx *rx) { return rx ? rx->fast_flagged : -1; }
 
 // raw[i]: device address of capture i.  host_src != nullptr: its content still has to be copied there from host_src[i];
 // the batch is then cut into sub-batches whose uploads (copy stream) overlap the kernels of the previous sub-batch.
@@ -1150,8 +1146,8 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const lon
         }
         WrDemodCfg oct_cfg;
         bool use_oct = false;
-        if (oct_caps > 0 || rx->fast) {
-            oct_cfg = rx->tab.oct_cfg(oct_caps > 0 ? oct_caps : 7, rx->fast != 0);
+        if (oct_caps > 0) {
+            oct_cfg = rx->tab.oct_cfg(oct_caps);
             use_oct = oct_cfg.o_ok != 0 && fmt == WENET_FMT_CU8;
         }
         launch_cfg.p_tsum_split = getenv("WENET_RX_TSUM_SPLIT") ? atoi(getenv("WENET_RX_TSUM_SPLIT")) : ((n_sel > wenet_rx_device_info(1)) ? 1 : 0);
@@ -1159,11 +1155,12 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const lon
         DemodChoice dc; dc.use_oct = use_oct; dc.oct_cfg = oct_cfg; dc.launch_cfg = launch_cfg;
         return dc;
     };
-    DemodChoice whole = choose_demod(nchan);
+    const DemodChoice whole = choose_demod(nchan);
     const bool use_oct = whole.use_oct;
-    WrDemodCfg &oct_cfg = whole.oct_cfg;
-    WrDemodCfg &launch_cfg = whole.launch_cfg;
-    const int oct_fast = use_oct && rx->fast ? 1 : 0;
+    auto kernel_name = [](const DemodChoice &d) -> const char * {
+        return d.use_oct ? "wenet_demod_oct_kernel"
+                         : (d.launch_cfg.p_tri ? "wenet_demod_tri_kernel" : (d.launch_cfg.pipe_ok && !d.launch_cfg.big ? "wenet_demod_pipe_kernel" : "wenet_demod_kernel"));
+    };
     if (use_oct && !host_src) {
         // The captures of a workgroup advance in lock-step and a workgroup lasts as long as its longest capture: deal the captures to the
         // workgroups by length (longest first; the table's order decides nothing else -- every entry carries its own buffers), so that the
@@ -1180,8 +1177,7 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const lon
             WR_CHECK(hipStreamSynchronize(stream), -3);
         }
     }
-    rx->last_kernel = use_oct ? (oct_fast ? "wenet_demod_oct_kernel<fast>" : "wenet_demod_oct_kernel")
-                              : (launch_cfg.p_tri ? "wenet_demod_tri_kernel" : (launch_cfg.pipe_ok && !launch_cfg.big ? "wenet_demod_pipe_kernel" : "wenet_demod_kernel"));
+    rx->last_kernel = kernel_name(whole);                                // (host-fed: the last sub-batch's, set in the loop below)
     // WENET_RX_PROFILE: 1 = instrumented pipelined kernel, 2 = instrumented one-wave sequential kernel, 3 = production
     // kernels with the per-channel stamp buffer attached (streamed sequential kernel: cycle stamps of one frame)
     const int prof = rx->profile ? (getenv("WENET_RX_PROFILE")[0] == '2' ? 2 : (getenv("WENET_RX_PROFILE")[0] == '3' ? 0 : 1)) : 0;
@@ -1222,45 +1218,18 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const lon
         // A capture is a serial job, so the batch demodulator works in rounds of the captures a device holds (two workgroups per CU); what is
         // left over after the full rounds of a device-resident batch is launched as a batch of its own size -- sixteen captures through the
         // pipelined kernel take 96 ms, a nearly empty round of the batch demodulator 177.
-        const int round_caps = use_oct ? 2 * oct_cfg.o_caps * ncu : 0;
-        const int full = (use_oct && !host_src && !oct_fast && getenv("WENET_RX_OCT") == nullptr && round_caps > 0 && n > round_caps) ? (n / round_caps) * round_caps : n;
-        if (use_oct) WR_CHECK(wr_launch_demod_oct(&oct_cfg, rx->d_chans.as<WrChan>() + lo, full, stream, oct_fast), -4);
-        else WR_CHECK(wr_launch_demod_ex(&launch_cfg, rx->d_chans.as<WrChan>() + lo, n, stream, prof), -4);
+        // (a host-fed batch arrives in sub-batches of at most three captures per CU, each launched on its own: the kernel is chosen for the
+        // sub-batch's size, not the whole batch's -- its uploads, not the kernels, set the pace)
+        const DemodChoice sub = host_src ? choose_demod(n) : whole;
+        if (host_src && k == rx->nchunks - 1) rx->last_kernel = kernel_name(sub);
+        const int round_caps = sub.use_oct ? 2 * sub.oct_cfg.o_caps * ncu : 0;
+        const int full = (sub.use_oct && !host_src && getenv("WENET_RX_OCT") == nullptr && round_caps > 0 && n > round_caps) ? (n / round_caps) * round_caps : n;
+        if (sub.use_oct) WR_CHECK(wr_launch_demod_oct(&sub.oct_cfg, rx->d_chans.as<WrChan>() + lo, full, stream), -4);
+        else WR_CHECK(wr_launch_demod_ex(&sub.launch_cfg, rx->d_chans.as<WrChan>() + lo, n, stream, prof), -4);
         if (full < n) {
             DemodChoice rest = choose_demod(n - full);
-            if (rest.use_oct) WR_CHECK(wr_launch_demod_oct(&rest.oct_cfg, rx->d_chans.as<WrChan>() + lo + full, n - full, stream, 0), -4);
+            if (rest.use_oct) WR_CHECK(wr_launch_demod_oct(&rest.oct_cfg, rx->d_chans.as<WrChan>() + lo + full, n - full, stream), -4);
             else WR_CHECK(wr_launch_demod_ex(&rest.launch_cfg, rx->d_chans.as<WrChan>() + lo + full, n - full, stream, 0), -4);
-        }
-        if (oct_fast) {
-            // Fast mode: a capture with a frame whose timing estimate fell within the guard band of a nin threshold (fsk.c:900-907)
-            // may have taken the other branch than the reference; it is demodulated again, from reset state, by an exact kernel
-            // (the decisions of all other captures are the reference's: verified frame by frame in tests/test_gpu_oct.py).
-            WR_CHECK(hipMemcpyAsync(rx->h_states.data() + (size_t)lo * c.st_floats, rx->d_states.as<float>() + (size_t)lo * c.st_floats,
-                                    stb * n, hipMemcpyDeviceToHost, stream), -3);
-            WR_CHECK(hipStreamSynchronize(stream), -3);
-            std::vector<WrChan> redo;
-            for (int i = lo; i < hi; i++)
-                if (((const WrChanHdr *)&rx->h_states[(size_t)i * c.st_floats])->uncertain_call > 0) {
-                    redo.push_back(chans[i]);
-                    WR_CHECK(hipMemcpyAsync(chans[i].state, st0.data(), stb, hipMemcpyHostToDevice, stream), -3);
-                }
-            if (k == 0) rx->fast_flagged = 0;
-            rx->fast_flagged += (long long)redo.size();
-            if (!redo.empty()) {
-                if (!rx->d_chans2.reserve(sizeof(WrChan) * redo.size())) return -2;
-                WR_CHECK(hipMemcpyAsync(rx->d_chans2.p, redo.data(), sizeof(WrChan) * redo.size(), hipMemcpyHostToDevice, stream), -3);
-                WR_CHECK(hipStreamSynchronize(stream), -3);                  // (redo goes out of scope)
-                const int nr = (int)redo.size();
-                if (nr >= 4 * ncu) {
-                    const WrDemodCfg exact_cfg = rx->tab.oct_cfg(oct_cfg.o_caps, false);                 // (the exact kernel has its own LDS layout)
-                    WR_CHECK(wr_launch_demod_oct(&exact_cfg, rx->d_chans2.as<WrChan>(), nr, stream, 0), -4);
-                }
-                else {
-                    WrDemodCfg rc = (2 * nr >= 3 * ncu) ? rx->tab.tri_cfg() : (nr > 2 * ncu ? rx->tab.raw_cfg() : rx->tab.cfg);
-                    rc.p_tsum_split = (rc.p_tri || nr > ncu) ? 1 : 0;
-                    WR_CHECK(wr_launch_demod_ex(&rc, rx->d_chans2.as<WrChan>(), nr, stream, 0), -4);
-                }
-            }
         }
         WR_CHECK(hipEventRecord(e.ev[1], stream), -4);
         WR_CHECK(wr_launch_deframe(rx->d_dchans.as<WrDeframeChan>() + lo, n, rx->mode, stream), -4);

@@ -35,14 +35,6 @@ class RxBatch:
     def enable_llr_dump(self, on=True):
         self._L.wenet_rx_enable_llr_dump(self._h, 1 if on else 0)
 
-    def set_fast(self, on=True):
-        """fast mode (parity-ladder rung P3, include/wenet_rx.h): LLRs within 2e-5 relative of the reference's instead of bit-identical (slower than exact mode: DESIGN.md 7)."""
-        self._L.wenet_rx_set_fast(self._h, 1 if on else 0)
-
-    def fast_reruns(self):
-        """captures of the last fast-mode batch that the library demodulated again with the exact kernel"""
-        return int(self._L.wenet_rx_fast_reruns(self._h))
-
     def last_kernel(self):
         return self._L.wenet_rx_last_kernel(self._h).decode()
 
