@@ -18,7 +18,7 @@ Prints ONE JSON line (see the contract in the task description) with these extra
                 host in the three shapes of SURVEY.md 8d / benchmarking/test_demod.py: (a) the harness's
                 own `--stats=100 ... 2>stats` pipe, (b) stats off, (c) all cores through xargs -P;
                 medians of three repetitions; packets must match the GPU's
-  other_workloads (N = 1 only, outside the timed region) fast mode, a slipping signal (100 ppm symbol-clock
+  other_workloads (N = 1 only, outside the timed region) a slipping signal (100 ppm symbol-clock
                 error), the host-fed rate (PCIe included), one capture alone
 """
 import argparse
@@ -126,8 +126,7 @@ def load_pmc_profile(kernel_name, inst, captures):
         except Exception:
             continue
         for k, v in d.get("kernels", {}).items():
-            if kernel_name.split("<")[0] in k and ("<fast>" in kernel_name) == bool(v.get("fast", False)) and \
-                    (inst is None or inst in k) and d.get("captures") == captures:
+            if kernel_name.split("<")[0] in k and not v.get("fast", False) and (inst is None or inst in k) and d.get("captures") == captures:
                 best = dict(v, file=os.path.relpath(pj, ROOT), captures=d.get("captures"), samples_in_launch=d.get("samples_in_launch"))
     return best
 
@@ -143,10 +142,9 @@ def main():
     ap.add_argument("--ebno", type=float, default=8.0)
     ap.add_argument("--ppm", type=float, default=0.0, help="symbol-clock error of the synthetic transmitters")
     ap.add_argument("--config", default="v2", choices=["v1", "v2", "4fsk"])
-    ap.add_argument("--fast", action="store_true", help="time the fast mode (parity-ladder rung P3) instead of the exact mode")
     ap.add_argument("--max-iter", type=int, default=10, help="LDPC MAX_ITER (10 in the reference CLIs; BASELINE config 4 asks for 50)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the other_workloads block (fast mode, slipping signal, host-fed, one capture)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the other_workloads block (slipping signal, host-fed, one capture)")
     ap.add_argument("--no-single-stream", action="store_true", help="(kept for the profiling scripts: implies nothing else is launched after the timed steps)")
     args = ap.parse_args()
     if args.no_single_stream:
@@ -203,8 +201,6 @@ def main():
     ns = [nsamp] * B
 
     rx = RxBatch(cfg.Fs, cfg.Rs, cfg.M, framing=cfg.mode, max_iter=args.max_iter)
-    if args.fast:
-        rx.set_fast()
 
     def step(r=rx, p=ptrs, n=ns):
         r.enqueue_device(p, n, "cu8")
@@ -271,7 +267,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "mode": "fast (P3)" if args.fast else "exact (bit-identical to the reference pipe)",
+            "mode": "exact (bit-identical to the reference pipe)",
             "datagen": {"by": "wenet_tx_modulate (GPU)", "ms": round(datagen_s * 1e3, 1),
                         "gsamples_per_s": round(B * nsamp / datagen_s / 1e9, 2)},
             "config": {"workload": f"{cfg.name} {cfg.M}-FSK Rs={cfg.Rs} Fs={cfg.Fs} cu8 Eb/N0={args.ebno}dB "
@@ -294,19 +290,6 @@ def main():
             line["cpu_baseline"] = None
         if world == 1 and not args.no_extras:
             other = {}
-            # the other arithmetic (exact <-> fast) on the same captures
-            r2 = RxBatch(cfg.Fs, cfg.Rs, cfg.M, framing=cfg.mode, max_iter=args.max_iter)
-            if not args.fast:
-                r2.set_fast()
-            step(r2)
-            s2, k2 = timed(2, r2)
-            other["fast_mode" if not args.fast else "exact_mode"] = {
-                "msamples_per_s": round(2 * B * nsamp / s2 / 1e6, 1), "demod_ms": round(float(k2[0]), 2), "kernel": r2.last_kernel(),
-                "captures_rerun_exactly": r2.fast_reruns() if not args.fast else None,
-                "packets_valid": sum(int(r2.packets(c)["crc_ok"].sum()) for c in range(B)),
-                "note": "P3: table phasors + tree sums, tone bins / nin as exact mode; captures with a frame inside the nin guard band are demodulated "
-                        "again by the exact kernel within the same call (tests/test_gpu_oct.py: LLRs within 2e-5 relative)"}
-            r2.close()
             # one capture alone (BASELINE config 2 taken literally: the '>= 50x real time on one stream' target)
             single = RxBatch(cfg.Fs, cfg.Rs, cfg.M, framing=cfg.mode, max_iter=args.max_iter)
             step(single, ptrs[:1], ns[:1])

@@ -24,11 +24,14 @@ def _captures(cfg, seed0):
     return caps
 
 
-@pytest.mark.parametrize("name,group", [("v2", 7), ("v1", 7), ("v2", 3), ("v1", 15), ("v2", 1)])
-def test_exact_mode_equals_oracle(name, group, monkeypatch):
+@pytest.mark.parametrize("name,group,nd", [("v2", 7, 1), ("v1", 7, 1), ("v2", 3, 1), ("v1", 15, 1), ("v2", 1, 1),
+                                           ("v2", 14, 2), ("v1", 14, 2), ("v2", 5, 2), ("v1", 1, 2)])
+def test_exact_mode_equals_oracle(name, group, nd, monkeypatch):
     """Different lengths and SNRs, heavy clock errors (nin != N on many frames: the estimator run made ahead with nin = N is
-    repeated), an empty capture, a silent one; every capture equals the oracle in any slot and with any group size."""
+    repeated), an empty capture, a silent one; every capture equals the oracle in any slot and with any group size -- with one duty
+    wavefront per workgroup (chains and sums in turn) and with two (a chain wave and a sum wave, the chain pass straddling the barrier)."""
     monkeypatch.setenv("WENET_RX_OCT", str(group))
+    monkeypatch.setenv("WENET_RX_OCT_ND", str(nd))
     cfg = siggen.CONFIGS[name]()
     caps = _captures(cfg, 600)
     rx = RxBatch(cfg.Fs, cfg.Rs, cfg.M, framing=cfg.mode)
@@ -95,28 +98,41 @@ def test_rare_paths_of_the_run_ahead_schedule(group, monkeypatch):
 
 
 def test_large_batch_picks_the_kernel_by_itself():
-    """From six captures per CU on the library takes the one-wavefront-per-capture kernel without being told; spot-check captures
-    of such a batch against the oracle."""
+    """From six captures per CU on the library takes the one-wavefront-per-capture kernel for a device-resident batch without being told; the
+    same batch fed from HOST buffers goes through in sub-batches of at most three captures per CU, each launched with the kernel that fits its
+    own size (the pipelined ones).  Spot-check captures of both against the oracle."""
+    import torch
     from wenet_amd import lib
     ncu = lib.load().wenet_rx_device_info(1)
     cfg = siggen.config_v2()
     base = [siggen.make_capture(cfg, 2, 8.0 + 0.5 * k, seed=650 + k, ppm=40.0 * k)[0] for k in range(8)]
     caps = [base[i % 8][: base[i % 8].size - 2 * (i % 5) * 480] for i in range(6 * ncu + 3)]
     rx = RxBatch(cfg.Fs, cfg.Rs, cfg.M, framing=cfg.mode)
-    rx.process(caps, "cu8")
+    dev = [torch.from_numpy(c).cuda() for c in caps]
+    rx.enqueue_device([int(d.data_ptr()) for d in dev], [d.numel() // 2 for d in dev], "cu8")
+    rx.collect()
     assert rx.last_kernel() == "wenet_demod_oct_kernel"
-    for i in list(range(0, len(caps), 97)) + [len(caps) - 1]:
+    picks = list(range(0, len(caps), 97)) + [len(caps) - 1]
+    want = {}
+    for i in picks:
         sd, _ = ol.oracle_demod(caps[i], "cu8", cfg.Fs, cfg.Rs, cfg.M)
+        want[i] = (sd, ol.oracle_deframe(sd, cfg.mode))
         assert bits_equal(rx.soft(i), sd), i
-        ref = ol.oracle_deframe(sd, cfg.mode)
-        assert rx.npackets(i) == ref["n"] and (rx.packets(i)["bytes"] == ref["bytes"]).all()
+        assert rx.npackets(i) == want[i][1]["n"] and (rx.packets(i)["bytes"] == want[i][1]["bytes"]).all()
+    rx.process(caps, "cu8")                                        # host-fed: more than three captures per CU -> several sub-batches
+    assert rx.last_kernel() in ("wenet_demod_tri_kernel", "wenet_demod_pipe_kernel")
+    for i in picks:
+        assert bits_equal(rx.soft(i), want[i][0]), i
+        assert rx.npackets(i) == want[i][1]["n"] and (rx.packets(i)["bytes"] == want[i][1]["bytes"]).all()
     rx.close()
 
 
-def test_exact_mode_4fsk_ts32_equals_oracle(monkeypatch):
+@pytest.mark.parametrize("group,nd", [(2, 1), (4, 2), (3, 2)])
+def test_exact_mode_4fsk_ts32_equals_oracle(group, nd, monkeypatch):
     """The large geometry of the batch kernel (BASELINE config 4: 4-FSK, Rs 57 600, Fs 1 843 200 -> Ts 32, 1024-point estimator, two
     soft decisions per symbol), forced here: every capture equals the oracle bit for bit, slips and ragged ends included."""
-    monkeypatch.setenv("WENET_RX_OCT", "2")
+    monkeypatch.setenv("WENET_RX_OCT", str(group))
+    monkeypatch.setenv("WENET_RX_OCT_ND", str(nd))
     cfg = siggen.config_4fsk()
     spec = ((4, 8.0, 0.0), (2, 12.0, 150.0), (3, 6.5, -300.0), (1, 20.0, 0.0), (2, 9.0, 2000.0), (2, 7.0, -2500.0))
     caps = [siggen.make_capture(cfg, n, eb, seed=740 + i, ppm=ppm)[0] for i, (n, eb, ppm) in enumerate(spec)]

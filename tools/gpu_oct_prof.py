@@ -12,6 +12,8 @@ caps = sys.argv[3] if len(sys.argv) > 3 else "7"
 cfgname = sys.argv[4] if len(sys.argv) > 4 else "v2"
 os.environ["WENET_RX_PROFILE"] = "4"
 os.environ["WENET_RX_OCT"] = caps
+if len(sys.argv) > 5:
+    os.environ["WENET_RX_OCT_ND"] = sys.argv[5]
 import numpy as np
 import torch
 from wenet_amd import siggen
@@ -37,13 +39,14 @@ for _ in range(2):
 print("kernel", rx.last_kernel(), "captures", B, "demod ms", round(rx.last_ms(0), 3), "Gsamples/s", round(B * nsamp / rx.last_ms(0) / 1e6, 2))
 L = rx._L
 L.wenet_rx_debug_profile.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
-buf = (C.c_longlong * 26)()
+buf = (C.c_longlong * 32)()
 for ch in range(0, B, int(caps)):
     n = L.wenet_rx_debug_profile(rx._h, ch, buf)
     v = list(buf)
     fr = max(v[6], 1)
     print(f"group@{ch}: frames {v[6]}; per frame: wave 0: decide+E-ahead+wait {v[0] / fr:.0f} (busy {v[4] / fr:.0f}), mix/integ {v[1] / fr:.0f}, wait sums {v[2] / fr:.0f}"
           f" [T1 to publish {v[3] / fr:.0f}, +T2+prefetch {(v[5] - v[3]) / fr:.0f}, +FFT ahead {(v[4] - v[5]) / fr:.0f}]"
-          f" | duty: wait nin {v[8] / fr:.0f}, chains {v[9] / fr:.0f}, barriers {v[10] / fr:.0f}, sums {v[11] / fr:.0f} | total/frame {sum(v[8:12]) / fr:.0f}")
+          f" | duty/chain wave: wait requests {v[8] / fr:.0f}, chain part 1 {v[9] / fr:.0f}, barrier 1 {v[10] / fr:.0f}, chain part 2 {v[12] / fr:.0f}, sums {v[13] / fr:.0f}, barrier 2 {v[11] / fr:.0f}"
+          f" | sum wave (ND 2): to barrier 1 {v[18] / fr:.0f}, sums + estimates {v[21] / fr:.0f}, barrier 2 {v[19] / fr:.0f} | total/frame {sum(v[8:14]) / fr:.0f}")
     if ch >= 3 * int(caps):
         break

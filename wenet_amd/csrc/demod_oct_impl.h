@@ -33,7 +33,7 @@
 
 #pragma clang fp contract(off)
 
-#define WO_CAPS_MAX 15               // capture waves per workgroup (cfg.o_caps of them) + the duty wave (NCO chains, timing sums) <= 16 wavefronts
+#define WO_CAPS_MAX 15               // capture waves per workgroup (cfg.o_caps of them) + the duty wave(s) (NCO chains, timing sums) <= 16 wavefronts
 #ifndef WO_WAVES_PER_EU
 #define WO_WAVES_PER_EU 4            // wavefronts per SIMD the register allocation aims at: 4 -> 128 VGPRs, two workgroups of 7 + 1 waves per CU
 #endif
@@ -43,7 +43,8 @@
 
 namespace {
 
-enum { OC_NIN = 0, OC_ALIVE = 1,
+enum { OC_SELFMASK = 31 /* (capture 0's block only) ND == 2: sum wave -> chain wave, the captures whose next chain is started without waiting */,
+       OC_NIN = 0, OC_ALIVE = 1,
        OC_SEQ = 2 /* frames whose nin, bins and alive flag are published: the duty wave starts a frame's chains on it */,
        OC_TC = 4 /* float re, im: timing sum */,
        OC_FBIN = 8 /* [4] tone bins of this frame */, OC_FBINP = 12 /* [4] previous frame's, first-run rule applied (fsk.c:750-753) */,
@@ -66,7 +67,9 @@ typedef __attribute__((address_space(3))) float oct_lds_f32;
 // hot ones are cast to the global address space and indexed with 32-bit lane offsets from a wave-uniform base (a capture is < 2^31 samples).
 typedef const __attribute__((address_space(1))) unsigned short oct_g_u16;
 typedef const __attribute__((address_space(1))) unsigned oct_g_u32;
+typedef const __attribute__((address_space(1))) char oct_g_ci8;
 typedef __attribute__((address_space(1))) float oct_g_f32;
+typedef const __attribute__((address_space(1))) float oct_g_f32c;
 typedef __attribute__((address_space(1))) v2f oct_g_f32x2;              // (the clang vector type: HIP's float2 is a class, bound to the generic address space)
 typedef const __attribute__((address_space(1))) v2f oct_g_cf32x2;
 
@@ -75,6 +78,42 @@ __device__ __forceinline__ float lane_up(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130 /* wave_shl:1 */, 0xf, 0xf, true));
 }
 __device__ __forceinline__ v2f lane_up(v2f v) { return (v2f){lane_up(v.x), lane_up(v.y)}; }
+// lane_up(run) + d, component by component: two v_add_f32 with the DPP read folded in (the packed add cannot take a DPP operand: it costs two
+// v_mov_dpp first).  The empty asm keeps the vectoriser from packing the two adds again.
+__device__ __forceinline__ v2f lane_up_add(v2f run, v2f d) {
+    float ax = lane_up(run.x) + d.x;
+    asm("" : "+v"(ax));
+    const float ay = lane_up(run.y) + d.y;
+    return (v2f){ax, ay};
+}
+// a wave-uniform 64-bit value the compiler carries in vector registers -> a scalar register pair (everything computed from it is then
+// scalar arithmetic, and loads indexed from it take the base from SGPRs)
+__device__ __forceinline__ long long uni64(long long v) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+// maximum over the wavefront of NON-NEGATIVE floats (compared as unsigned integers: same order, no NaN canonicalisation), in six DPP steps --
+// the cross-lane shuffles of __shfl_xor go through the LDS crossbar (ds_bpermute: an address computation, an LDS round trip and a wait each)
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ unsigned dpp_umax(unsigned v) {
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROWMASK, 0xf, false);
+    return o > v ? o : v;
+}
+__device__ __forceinline__ float wave_max_nonneg(float x) {
+    unsigned v = __float_as_uint(x);
+    v = dpp_umax<0xB1, 0xf>(v);                                          // quad_perm:[1,0,3,2]
+    v = dpp_umax<0x4E, 0xf>(v);                                          // quad_perm:[2,3,0,1]
+    v = dpp_umax<0x141, 0xf>(v);                                         // row_half_mirror
+    v = dpp_umax<0x140, 0xf>(v);                                         // row_mirror: every lane holds its row's maximum
+    v = dpp_umax<0x142, 0xa>(v);                                         // row_bcast:15 into rows 1 and 3
+    v = dpp_umax<0x143, 0xc>(v);                                         // row_bcast:31 into rows 2 and 3: lane 63 holds the wave's maximum
+    return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)v, 63));
+}
+// kiss_fft's C_MUL (_kiss_fft_guts.h:87-90) = cmul(): the packed three-instruction form (left to itself hipcc builds it from five instructions and two wait states)
+__device__ __forceinline__ float2 cmul_f2(float2 a, float2 b) {
+    const v2f r = cmul_pk((v2f){a.x, a.y}, (v2f){b.x, b.y});
+    return make_float2(r.x, r.y);
+}
 
 // x * conj(p) = (x.x p.x + x.y p.y, x.y p.x - x.x p.y): the products and sums of c_mul(x, c_conj(p)) (comp_prim.h:47-65), each rounded
 // once, in three packed instructions
@@ -152,7 +191,8 @@ __device__ __forceinline__ float nco_steps_split(float own, float k1, float k2) 
 // Geometries: (M 2, TS 8 | 10, NDFT 256) = Wenet v1 / v2; (M 4, TS 32, NDFT 1024) = BASELINE config 4 (4-FSK, Fs 1 843 200).  The small ones keep every
 // table in LDS and fetch their samples a frame ahead; the large one reads three of the tables through the caches and loads its samples
 // where it uses them (the registers they would sit in are worth more than the microsecond in a 35 us frame).
-template <int M, int TS, int NDFT>
+// ND = number of duty wavefronts: 1 (the chain, later the sums, on one wave) or 2 (a chain wave and a sum wave: see the frame loop)
+template <int M, int TS, int NDFT, int ND>
 // (launch bounds: the LDS of the large geometry allows <= 10 wavefronts per CU anyway, so it may have 256 VGPRs)
 __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WAVES_PER_EU) void wenet_demod_oct_kernel(WrDemodCfg cfg, const WrChan *chans, int nchan) {
     static_assert(M == 2 || M == 4, "two or four tones");
@@ -165,7 +205,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int G = cfg.o_caps;                                            // captures (= capture waves) of this workgroup
-    const bool is_cap = wave < G, is_chain = wave == G;      // one duty wave: the chain, later the sums
+    const bool is_cap = wave < G, is_chain = wave == G, is_sum = wave == G + ND - 1;      // ND == 1: one duty wave, the chain and later the sums
     const int cap = is_cap ? wave : 0;
     const int ch = blockIdx.x * G + cap;
     const bool present = is_cap && ch < nchan;
@@ -185,7 +225,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
     const float  *hann_t = (const float *)(smem_all + (G * LY.stride + LY.HANN));
     const float2 *dphi_t = (const float2 *)(smem_all + (G * LY.stride + LY.DPHI));
     const int    *src_t = SMALL ? (const int *)(smem_all + (G * LY.stride + LY.SRC)) : cfg.fft_src;
-    oct_g_cf32x2 *pft_t = (oct_g_cf32x2 *)cfg.phi_ft;                    // (read through the caches: one coalesced pass per frame)
+    oct_g_f32c *pft_pl = (oct_g_f32c *)cfg.phi_ft_planes;                // timing oscillator, a row of real and a row of imaginary parts (read through the caches: one coalesced pass per frame)
     const float2 *back_t = cfg.backoff_tab;                              // (one entry per chain)
     const int ctw = LY.stride / 4;
     const int *CT0 = (const int *)(smem_all + LY.CT);
@@ -205,6 +245,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
     float *st_sd = C.state + cfg.st_sd_last;
     oct_g_u16 *raw16 = (oct_g_u16 *)C.raw;
     const long long last_smp = C.nsamples > 0 ? C.nsamples - 1 : 0;
+    const long long nsamp_u = uni64(C.nsamples);                         // (the capture's length, certainly in scalar registers)
 
     // ---- shared tables and carried state -> LDS / registers ------------------------------------
     {
@@ -271,10 +312,11 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
     auto prefetch_est = [&](long long off_j) __attribute__((always_inline)) {
         if (!SMALL) { est_off = off_j; return; }                         // (loaded inside estimate_fft)
         const int ln = fresh_lane();
-        if (off_j + Ndft <= C.nsamples) {                                // the whole transform window is inside the capture: no index clamping
-            oct_g_u16 *p = raw16 + off_j;
+        off_j = uni64(off_j);                                            // (scalar: the window test is a scalar branch, the loads take their base from SGPRs)
+        if (off_j + Ndft <= nsamp_u) {                                // the whole transform window is inside the capture: no index clamping
+            oct_g_ci8 *pb = (oct_g_ci8 *)(raw16 + off_j);
 #pragma unroll
-            for (int j = 0; j < NE; j++) epre[j] = p[(unsigned)src_t[4 * (ln + 64 * (j >> 2)) + (j & 3)]];
+            for (int j = 0; j < NE; j++) epre[j] = *(oct_g_u16 *)(pb + 2u * (unsigned)src_t[4 * (ln + 64 * (j >> 2)) + (j & 3)]);
         } else {                                                         // (a run ahead of the capture's end: its result is never used)
 #pragma unroll
             for (int j = 0; j < NE; j++) { long long a = off_j + src_t[4 * (ln + 64 * (j >> 2)) + (j & 3)]; epre[j] = raw16[a < last_smp ? a : last_smp]; }
@@ -284,12 +326,13 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
     // one; slot_align() shifts them down by a sample when the first one is odd -- at the point of use, so the loads stay in flight.
     auto prefetch_slot = [&](long long off_j, int nin_j) __attribute__((always_inline)) {
         const int ln = fresh_lane(), slot = ln < NBLK ? ln : NBLK - 1;    // (idle lanes repeat the last slot: always inside the frame)
-        const long long b0 = off_j - (Nmem - nin_j);                     // buffer position 0 (negative only in a launch's first frame)
-        if (b0 >= 0 && b0 + Nmem + 1 <= C.nsamples) {                    // positions 0 .. Nmem (one past the window) are samples of the capture
-            oct_g_u32 *p = (oct_g_u32 *)(raw16 + (b0 & ~1LL));              // (wave-uniform; the lane's part is a 32-bit dword offset)
-            const unsigned so = (unsigned)(TS / 2 * slot);
+        const long long b0 = uni64(off_j - (Nmem - nin_j));              // buffer position 0 (negative only in a launch's first frame); scalar
+        if (b0 >= 0 && b0 + Nmem + 1 <= nsamp_u) {                    // positions 0 .. Nmem (one past the window) are samples of the capture
+            // (scalar base + the lane's 32-bit byte offset + an immediate: one address register for all the loads)
+            oct_g_ci8 *pb = (oct_g_ci8 *)(raw16 + (b0 & ~1LL));
+            const unsigned sob = (unsigned)(TS / 2 * slot) * 4u;
 #pragma unroll
-            for (int u = 0; u < TS / 2 + 1; u++) xr[u] = p[so + u];
+            for (int u = 0; u < TS / 2 + 1; u++) xr[u] = *(oct_g_u32 *)(pb + sob + 4 * u);
         } else {                                                         // first frame (window starts in the carried samp_old[]) / capture's last sample
             // the same dwords sample by sample: position e of the capture, from the carried samples (they came from cu8 input or are the
             // zeros of a reset: exact inverse of the conversion) below 0, the capture's last sample repeated beyond it (never used)
@@ -367,9 +410,9 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
                 const int bf = ln + 64 * jb;
                 const int blk = bf >> lgm, k = bf & (m - 1);
                 float2 *F = FB + blk * m * 4 + k;
-                const float2 s0 = cmul(F[m], tw_t[k * fs]);
-                const float2 s1 = cmul(F[2 * m], tw_t[k * fs * 2]);
-                const float2 s2 = cmul(F[3 * m], tw_t[k * fs * 3]);
+                const float2 s0 = cmul_f2(F[m], tw_t[k * fs]);
+                const float2 s1 = cmul_f2(F[2 * m], tw_t[k * fs * 2]);
+                const float2 s2 = cmul_f2(F[3 * m], tw_t[k * fs * 3]);
                 float2 o0, o1, o2, o3;
                 bfly4(F[0], s0, s1, s2, o0, o1, o2, o3);
                 F[0] = o0; F[m] = o1; F[2 * m] = o2; F[3 * m] = o3;
@@ -382,9 +425,9 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
             for (int jb = 0; jb < NBF; jb++) {
                 const int k = ln + 64 * jb;
                 float2 *F = FB + k;
-                const float2 s0 = cmul(F[m], tw_t[k]);
-                const float2 s1 = cmul(F[2 * m], tw_t[2 * k]);
-                const float2 s2 = cmul(F[3 * m], tw_t[3 * k]);
+                const float2 s0 = cmul_f2(F[m], tw_t[k]);
+                const float2 s1 = cmul_f2(F[2 * m], tw_t[2 * k]);
+                const float2 s2 = cmul_f2(F[3 * m], tw_t[3 * k]);
                 float2 o0, o1, o2, o3;
                 bfly4(F[0], s0, s1, s2, o0, o1, o2, o3);
                 F[0] = o0; F[m] = o1;
@@ -416,9 +459,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
             float bv = e[0];
 #pragma unroll
             for (int kk = 1; kk < NPL; kk++) bv = __builtin_fmaxf(bv, e[kk]);
-#pragma unroll
-            for (int sh = 32; sh >= 1; sh >>= 1) bv = __builtin_fmaxf(bv, __shfl_xor(bv, sh, 64));
-            const float wm = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(bv)));
+            const float wm = wave_max_nonneg(bv);                        // (magnitudes and zeros: non-negative)
             int imax = 0;
             if (wm > 0.f) {
                 bool found = false;
@@ -459,12 +500,13 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
     float pv_r = 0.f, pv_i = 0.f;                                        // the previous frame's timing vector (0, 0: none)
     // D(j): mix, integrate, timing products
     // omask: which of the TS outputs per tone are parked (bit r); realign = false when the slot dwords were aligned by an earlier call
-    auto dstage = [&](long long off_j, int nin_j, unsigned omask, bool realign) __attribute__((always_inline)) {
+    auto dstage = [&](long long off_j, int nin_j, unsigned omask_j, bool realign) __attribute__((always_inline)) {
+        const unsigned omask = (unsigned)__builtin_amdgcn_readfirstlane((int)omask_j);     // (wave-uniform: the tests on its bits are scalar branches)
         const int nold = Nmem - nin_j;
         if (realign) { if (!SMALL) prefetch_slot(off_j, nin_j); slot_align(off_j, nin_j); }
         const int ln = fresh_lane(), slot = ln < NBLK ? ln : NBLK - 1;
         constexpr bool FT1_LDS = TS > 10;                                // the per-output power sums: registers, or (large slots) the products' re row
-        float ft1[FT1_LDS ? 1 : TS];
+        v2f ft1[FT1_LDS ? 1 : TS / 2];                                   // (pairs: outputs r, r + 1 -- the operands of the packed timing products)
         float pw[FT1_LDS ? TS : 1];
         v2f xs[SMALL ? 1 : TS];                                          // large geometry (256 VGPRs): the slot's samples converted once for all tones
         if (!SMALL) {
@@ -494,7 +536,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
             }
             const v2f sq = f * f;                                        // fsk.c:862-868
             const float a = sq.x + sq.y;
-            if (!FT1_LDS) ft1[r] = (m == 0) ? a : ft1[r] + a;
+            if (!FT1_LDS) ft1[FT1_LDS ? 0 : r / 2][r & 1] = (m == 0) ? a : ft1[FT1_LDS ? 0 : r / 2][r & 1] + a;
             else pw[r] = a;                                              // (this tone's powers; added to the row after the tone, in one go)
         };
 #pragma unroll(FT1_LDS ? 1 : M)                                         // (large slots: one tone's code, run M times -- d[] alone is 2 TS registers)
@@ -518,7 +560,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
             v2f run = (v2f){0.f, 0.f} + d[0];
             static_for<1, TS>([&](auto rc) __attribute__((always_inline)) {
                 constexpr int r = decltype(rc)::value;
-                v2f acc = lane_up(run) + d[r];
+                v2f acc = lane_up_add(run, d[r]);
                 acc = pk_add_seq<TS - 1 - r>(acc, &d[r < TS - 1 ? r + 1 : r]);
                 put_out(m, r, acc);
                 run = run + d[r];
@@ -537,11 +579,13 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
         if (ln < NOUT) {
 #pragma unroll
             for (int r = 0; r < TS; r += 2) {                        // fsk.c:870-871: the products; the duty wave adds them in order
-                const v2f pa = pft_t[TS * ln + r], pb = pft_t[TS * ln + r + 1];
-                const float fa = FT1_LDS ? Trow[r] : ft1[FT1_LDS ? 0 : r], fb = FT1_LDS ? Trow[r + 1] : ft1[FT1_LDS ? 0 : r + 1];
-                const v2f ta = (v2f){fa, fa} * (v2f){pa.x, pa.y}, tb = (v2f){fb, fb} * (v2f){pb.x, pb.y};
-                *(float2 *)(TPf + TS * ln + r) = make_float2(ta.x, tb.x);
-                *(float2 *)(TPf + NIq + TS * ln + r) = make_float2(ta.y, tb.y);
+                // outputs r, r + 1 at once: (ft1[r] re(phi_ft[r]), ft1[r+1] re(phi_ft[r+1])) and the same with the imaginary parts -- the
+                // products of fsk.c:870-871, one packed multiply per row pair (the oscillator comes as two planes for this)
+                const v2f f2 = FT1_LDS ? *(const v2f *)(Trow + r) : ft1[FT1_LDS ? 0 : r / 2];
+                const v2f pre = *(oct_g_cf32x2 *)(pft_pl + TS * ln + r), pim = *(oct_g_cf32x2 *)(pft_pl + NIq + TS * ln + r);
+                const v2f tre = f2 * pre, tim = f2 * pim;
+                *(v2f *)(TPf + TS * ln + r) = tre;
+                *(v2f *)(TPf + NIq + TS * ln + r) = tim;
             }
         }
         wave_sync();
@@ -559,11 +603,11 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
     // rx_timing within W - 0.06 samples of rt
     auto window_mask = [&](int low, int extra = 0) __attribute__((always_inline)) -> unsigned {
         constexpr int W = wo_park_halfwidth(TS);
-        unsigned mk = 0;
-#pragma unroll
-        for (int j = -W; j <= W + 1; j++) { const int x = low + j + TS; mk |= 1u << ((x >= TS ? x - TS : x) % TS); }   // (low >= -TS/2: x >= 0; the % folds away for x < 2 TS)
-        if (extra) { const int x = low + (extra < 0 ? -W - 1 : W + 2) + TS; mk |= 1u << ((x >= TS ? x - TS : x) % TS); }   // one more on the side the estimate sits nearer to
-        return mk;
+        // 2 W + 2 consecutive outputs from low - W on, modulo TS (low >= -TS/2, so low - W + TS >= 0): one run of bits, rotated within TS bits
+        int st = low - W - (extra < 0 ? 1 : 0) + TS;                     // (extra: one more output, on the side the estimate sits nearer to)
+        st = st >= TS ? st - TS : st;
+        const unsigned long long pat = (unsigned long long)((1u << (2 * W + 2 + (extra ? 1 : 0))) - 1u) << st;
+        return (unsigned)((pat | (pat >> TS)) & ALLOUT);
     };
     v2f t2a[M], t2b[M];                                                  // the parked outputs the frame's symbols are resampled from
     auto tstage2_load = [&]() __attribute__((always_inline)) {
@@ -626,10 +670,19 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
     // ================================ narrow stages (exact mode) ===============================
     // C(j) of the captures in `mask`, lane-split form: lanes 2 (M c + m), + 1 carry re, im of tone m of capture c (plain instructions, half the
     // SIMD time of a packed chain: the capture waves of the duty wave's SIMD mix their frames meanwhile)
-    auto chain_split = [&](int mask) __attribute__((always_inline)) {
+    // A pass is written in two parts so that, with a chain wave of its own (ND == 2), it can straddle the workgroup barrier: part 1 = set-up, the
+    // blocks around the switch to this frame's estimate and the first CH_TRIPS1 trips of eight checkpoints, part 2 = the rest.  What lives
+    // across the parts (ch_*) stays in the chain wave's registers.
+    constexpr int CH_FULL = L / H, CH_TRIPS = (CH_FULL - 5) / 8, CH_TRIPS1 = ND == 2 ? CH_TRIPS * 11 / 20 : CH_TRIPS;
+    float ch_k1 = 0.f, ch_k2 = 0.f;
+    float *ch_ck = nullptr;
+    int ch_hb = 0;
+    bool ch_on = false;
+    auto chain_part1 = [&](int mask) __attribute__((always_inline)) {
         const int q = lane >> 1, part = lane & 1;
         const int cc = q / M;
-        if (cc >= G || !((mask >> cc) & 1)) return;
+        ch_on = cc < G && ((mask >> cc) & 1);
+        if (!ch_on) return;
         const int m = q % M;
         const int *CTc = CT0 + cc * ctw;
         float *ck = (float *)((v2f *)(smem_all + cc * LY.stride + LY.CK) + CTc[OC_CREG] * M * NHB + m * NHB) + part;
@@ -641,13 +694,13 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
         own_s = nco_step_split(own_s, bo.x, part ? bo.y : -bo.y);       // fsk.c:758-759: the products and sums of cmul_pk(bo, own)
         const float2 d0 = dphi_t[bp], d1 = dphi_t[bc];
         float k1 = d0.x, k2 = part ? d0.y : -d0.y;
-        const int hsw = nold / H;
+        const int hsw = nold / H;                                        // 3, 4 or 5: the half symbol that starts with the new samples
         int hb = 0;
         auto blocks = [&](int upto) __attribute__((always_inline)) {
 #pragma unroll 1
             for (; hb < upto; hb++) { ck[2 * hb] = own_s; own_s = nco_steps_split<H>(own_s, k1, k2); }
         };
-        auto swtch = [&]() __attribute__((always_inline)) {                                             // fsk.c:785-788
+        auto swtch = [&]() __attribute__((always_inline)) {                                             // fsk.c:785-788: normalise, continue with this frame's estimate
             if (hb == hsw) {
                 const float oth = __shfl_xor(own_s, 1, 64);
                 const float re = part ? oth : own_s, im = part ? own_s : oth;
@@ -657,16 +710,28 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
             }
         };
         blocks(3); swtch(); blocks(4); swtch(); blocks(5); swtch();
-        const int full = L / H;
 #pragma unroll 1
-        for (; hb + 8 <= full; hb += 8) {                                // (eight checkpoints per trip, no more: the trip count is a constant, and a fully unrolled chain is 10 KB of code)
+        for (int t = 0; t < CH_TRIPS1; t++, hb += 8) {                   // (eight checkpoints per trip, no more: a fully unrolled chain is 10 KB of code)
 #pragma unroll
             for (int k = 0; k < 8; k++) { ck[2 * (hb + k)] = own_s; own_s = nco_steps_split<H>(own_s, k1, k2); }
         }
-        blocks(full);
-        if (full * H < L) {
+        ch_k1 = k1; ch_k2 = k2; ch_ck = ck; ch_hb = hb;
+    };
+    auto chain_part2 = [&]() __attribute__((always_inline)) {
+        if (!ch_on) return;
+        const float k1 = ch_k1, k2 = ch_k2;
+        float *ck = ch_ck;
+        int hb = ch_hb;
+#pragma unroll 1
+        for (int t = CH_TRIPS1; t < CH_TRIPS; t++, hb += 8) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) { ck[2 * (hb + k)] = own_s; own_s = nco_steps_split<H>(own_s, k1, k2); }
+        }
+#pragma unroll 1
+        for (; hb < CH_FULL; hb++) { ck[2 * hb] = own_s; own_s = nco_steps_split<H>(own_s, k1, k2); }
+        if (CH_FULL * H < L) {
             ck[2 * hb] = own_s;
-            for (int s = full * H; s < L; s++) own_s = nco_step_split(own_s, k1, k2);
+            for (int st = CH_FULL * H; st < L; st++) own_s = nco_step_split(own_s, k1, k2);
         }
     };
 
@@ -735,8 +800,8 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
         //   redo_d   (ready) the parked integrator outputs did not cover the resampling points: mix the frame again, parking everything
         if (is_chain) __builtin_amdgcn_s_setprio(2);
 #ifdef WR_WITH_PROF
-        const bool pp = C.prof != nullptr && lane == 0 && (wave == 0 || is_chain);
-        long long *pr = C.prof + (is_chain ? 8 : 0);
+        const bool pp = C.prof != nullptr && lane == 0 && (wave == 0 || is_chain || is_sum);
+        long long *pr = C.prof + (is_chain ? 8 : (is_sum ? 16 : 0));     // (ND == 2: wave 0 | chain wave | sum wave)
         long long pt[6] = {0, 0, 0, 0, 0, 0}, t0 = pp ? (long long)__builtin_readcyclecounter() : 0;
 #define WO_STAMP(k) do { if (pp) { const long long t1 = (long long)__builtin_readcyclecounter(); pt[k] += t1 - t0; t0 = t1; } } while (0)
 #define WO_SUB(k) do { if (pp) { const long long t1 = (long long)__builtin_readcyclecounter(); pt[k] += t1 - t0; } } while (0)   /* since the last WO_STAMP */
@@ -773,67 +838,82 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
             request(0, nin, b_w, b_pv, ckpar, alive, 1);
         }
         // One copy of the loop per role: a wave never changes its role, so inside its copy only that role's values are live.
-        if (is_chain) {
+        // Duty wave(s).  ND == 1: one wave runs the chains in phases C + A and the sums in phase B.  ND == 2: a chain wave and a sum wave -- the
+        // chain wave's pass starts as before but need not end before the first barrier (part 2 runs beside the sums, phase B), so neither the
+        // chain nor the sums wait for the other: the workgroup's iteration is no longer chain + sums but max(chain, capture work) -- and two
+        // duty waves serve fourteen captures (one workgroup per CU), half the narrow-stage instructions per capture.
+        if (is_chain || is_sum) {
+            if (is_sum) __builtin_amdgcn_s_setprio(2);
             float own_m1 = own_s;                                        // the phasors before the last chain that was run
             int mask = (1 << G) - 1;
             int selfmask = 0;                                            // captures whose next chain is the speculative one they wrote down beforehand
             for (long long kf = 0;; kf++) {
-                for (int c = 0; c < G; c++)
-                    if (((mask & ~selfmask) >> c) & 1)
-                        while (__hip_atomic_load((int *)&CT0[c * ctw + OC_SEQ], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (int)(kf + 1)) __builtin_amdgcn_s_sleep(1);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                WO_STAMP(0);
-                constexpr int LPC = 2 * M;                               // chain lanes per capture
-                const int cc = lane / LPC;
-                int req = 0;
-                if (cc < G && ((mask >> cc) & 1)) req = CT0[cc * ctw + OC_REQ];
-                if (req == OC_REQ_SPEC) own_m1 = own_s;
-                else if (req == OC_REQ_TRUE || req == OC_REQ_DEAD) own_s = own_m1;
-                const unsigned long long bal = __ballot(req == OC_REQ_SPEC || req == OC_REQ_TRUE);
-                int m2 = 0;
-                for (int c = 0; c < G; c++) m2 |= (int)((bal >> (c * LPC)) & 1ull) << c;
-                if (m2) { chain_split(m2); ran |= m2; }
-                WO_STAMP(1);
-                lds_barrier();                                           // timing products of the frames in work; checkpoints of the requested chains
+                if (is_chain) {
+                    for (int c = 0; c < G; c++)
+                        if (((mask & ~selfmask) >> c) & 1)
+                            while (__hip_atomic_load((int *)&CT0[c * ctw + OC_SEQ], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (int)(kf + 1)) __builtin_amdgcn_s_sleep(1);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    WO_STAMP(0);
+                    constexpr int LPC = 2 * M;                           // chain lanes per capture
+                    const int cc = lane / LPC;
+                    int req = 0;
+                    if (cc < G && ((mask >> cc) & 1)) req = CT0[cc * ctw + OC_REQ];
+                    if (req == OC_REQ_SPEC) own_m1 = own_s;
+                    else if (req == OC_REQ_TRUE || req == OC_REQ_DEAD) own_s = own_m1;
+                    const unsigned long long bal = __ballot(req == OC_REQ_SPEC || req == OC_REQ_TRUE);
+                    int m2 = 0;
+                    for (int c = 0; c < G; c++) m2 |= (int)((bal >> (c * LPC)) & 1ull) << c;
+                    ch_on = false;
+                    if (m2) { chain_part1(m2); ran |= m2; if (ND == 1) chain_part2(); }
+                    WO_STAMP(1);
+                }
+                lds_barrier();                                           // timing products of the frames in work; (ND == 1) checkpoints of the requested chains
                 WO_STAMP(2);
+                if (ND == 2 && is_chain) chain_part2();                  // (its checkpoints are read after the second barrier)
+                WO_STAMP(4);
                 mask &= alive_mask();
                 if (!mask) break;
                 // The sums, and straight away the timing estimate of every capture (one lane each: atan2f, the double division, nin -- once
                 // per workgroup instead of once per capture wave).  If nin stays N and the capture said beforehand that it then has another
                 // frame and that its parked outputs are sure to cover the resampling points (all parked, or the timing vector near the
-                // previous one), its next request can only be the speculative chain it wrote down in phase B: the duty wave starts that
+                // previous one), its next request can only be the speculative chain it wrote down in phase B: the chain is started
                 // without waiting for the capture wave.
-                const float acc = tsum(mask);
-                const float oth = __shfl_xor(acc, 1, 64);
-                bool self = false;
-                {
-                    const int sc = lane >> 1;
-                    if (sc < G && ((mask >> sc) & 1) && !(lane & 1)) {
-                        int *CTc = (int *)(smem_all + sc * LY.stride + LY.CT);
-                        const int fl = CTc[OC_FLAGS];
-                        int ord = 0;
-                        const float tcr = acc, tci = oth;
-                        if ((fl & 4) && !((tcr != tcr) || (tci != tci))) {       // (a NaN frame, fsk.c:878-880, is left to the capture wave)
-                            const float pvr = ((const float *)CTc)[OC_PV], pvi = ((const float *)CTc)[OC_PV + 1];
-                            const float dot = tcr * pvr + tci * pvi;
-                            const float n2 = (tcr * tcr + tci * tci) * (pvr * pvr + pvi * pvi);
-                            const bool near = dot > 0.f && dot * dot > cfg.o_near_cos2 * n2;
-                            const float at = wg_atan2f(tci, tcr);                                           // fsk.c:884
-                            const float nrt = (float)((double)at / (2 * 3.14159265358979323846));
-                            const float rxt = nrt * cfg.P_f;
-                            const int low = (int)floorf(rxt), high = (int)ceilf(rxt);
-                            const int nnc = at > cfg.o_at_hi ? 2 : (at < cfg.o_at_lo ? 0 : 1);               // fsk.c:900-907
-                            self = (fl & 1) && nnc == 1 && ((fl & 2) || near);
-                            ord = 1 | (self ? 2 : 0) | (near ? 4 : 0) | (nnc << 4) | ((low + 64) << 8) | ((high + 64) << 16);
-                            ((float *)CTc)[OC_O_NRT] = nrt; ((float *)CTc)[OC_O_FRACT] = rxt - (float)low; ((float *)CTc)[OC_O_RXT] = rxt;
+                if (is_sum) {
+                    const float acc = tsum(mask);
+                    const float oth = __shfl_xor(acc, 1, 64);
+                    bool self = false;
+                    {
+                        const int sc = lane >> 1;
+                        if (sc < G && ((mask >> sc) & 1) && !(lane & 1)) {
+                            int *CTc = (int *)(smem_all + sc * LY.stride + LY.CT);
+                            const int fl = CTc[OC_FLAGS];
+                            int ord = 0;
+                            const float tcr = acc, tci = oth;
+                            if ((fl & 4) && !((tcr != tcr) || (tci != tci))) {       // (a NaN frame, fsk.c:878-880, is left to the capture wave)
+                                const float pvr = ((const float *)CTc)[OC_PV], pvi = ((const float *)CTc)[OC_PV + 1];
+                                const float dot = tcr * pvr + tci * pvi;
+                                const float n2 = (tcr * tcr + tci * tci) * (pvr * pvr + pvi * pvi);
+                                const bool near = dot > 0.f && dot * dot > cfg.o_near_cos2 * n2;
+                                const float at = wg_atan2f(tci, tcr);                                           // fsk.c:884
+                                const float nrt = (float)((double)at / (2 * 3.14159265358979323846));
+                                const float rxt = nrt * cfg.P_f;
+                                const int low = (int)floorf(rxt), high = (int)ceilf(rxt);
+                                const int nnc = at > cfg.o_at_hi ? 2 : (at < cfg.o_at_lo ? 0 : 1);               // fsk.c:900-907
+                                self = (fl & 1) && nnc == 1 && ((fl & 2) || near);
+                                ord = 1 | (self ? 2 : 0) | (near ? 4 : 0) | (nnc << 4) | ((low + 64) << 8) | ((high + 64) << 16);
+                                ((float *)CTc)[OC_O_NRT] = nrt; ((float *)CTc)[OC_O_FRACT] = rxt - (float)low; ((float *)CTc)[OC_O_RXT] = rxt;
+                            }
+                            CTc[OC_ORD] = ord;
                         }
-                        CTc[OC_ORD] = ord;
                     }
+                    const unsigned long long sb = __ballot(self);
+                    selfmask = 0;
+                    for (int c = 0; c < G; c++) selfmask |= (int)((sb >> (2 * c)) & 1ull) << c;
+                    if (ND == 2 && lane == 0) ((int *)smem_all)[LY.CT / 4 + OC_SELFMASK] = selfmask;
                 }
-                const unsigned long long sb = __ballot(self);
-                selfmask = 0;
-                for (int c = 0; c < G; c++) selfmask |= (int)((sb >> (2 * c)) & 1ull) << c;
+                WO_STAMP(5);
                 lds_barrier();                                           // timing sums
+                if (ND == 2 && is_chain) selfmask = __builtin_amdgcn_readfirstlane(CT0[OC_SELFMASK]);
                 WO_STAMP(3);
             }
         } else {
@@ -846,7 +926,8 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
                     }
                     // estimator runs of this phase: after a slip E(k) with the true nin (tone search included), then -- always, unless it is done
                     // already -- the FFT of the newest frame the schedule looks at, assuming it (and the frames before it) have nin = N
-                    for (int e = (!ready && redo_e) ? 0 : 1; e < 2; e++) {
+                    // (ND == 2: that FFT runs in phase B, beside the sum wave's ordered sums -- the chain no longer has to be covered by phase A)
+                    for (int e = (!ready && redo_e) ? 0 : 1; e < (ND == 2 ? 1 : 2); e++) {
                         if (e == 1 && (ready ? redo_d : en_valid)) break;
                         estimate_fft(e == 0 ? nin : N);
                         if (e == 0) { estimate_pick_to((sw + 2) % 3, sw, b_w); prefetch_est(off + nin); }
@@ -859,6 +940,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
                 if (!mask) break;
                 if (alive) {
                     const bool ran_fft = ready ? !redo_d : !en_valid;
+                    if (ND == 2 && ran_fft) estimate_fft(N);
                     if (ran_fft) {
                         int fb[M];
                         const int si = ready ? (sw + 1) % 3 : sw;

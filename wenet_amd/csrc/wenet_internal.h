@@ -48,6 +48,7 @@ struct WrDemodCfg {
     const float2 *dphi_tab;             // [Ndft/2] e^{j 2 pi f/Fs}, f = bin*Fs/Ndft (fsk.c:763)
     const float2 *backoff_tab;          // [3][Ndft/2] fsk.c:758 for nin = N-Ts/2, N, N+Ts/2
     const float2 *phi_ft;               // [NI]     running product of e^{j 2 pi/P} (fsk.c:858-873)
+    const float *phi_ft_planes;         // [2][(NI+3)&~3] the same as a row of real parts and a row of imaginary parts (batch kernel)
     const float  *bin_freq;             // [Ndft/2] (float)bin*((float)Fs/(float)Ndft) (fsk.c:671)
     // LDS carve-up (bytes)
     int off_X, off_FB, off_PH, off_FI, off_FE, off_FW, off_SD, off_SC, lds_bytes;
@@ -69,6 +70,7 @@ struct WrDemodCfg {
     // batch kernel, one wavefront per capture (demod_oct_impl.h): o_caps captures per workgroup, each with an LDS block of
     // o_cap_stride bytes (o_off_FB .. o_off_CT inside it), the tables once behind the blocks; o_ok = geometry supported
     int o_ok, o_caps, o_cap_stride, o_lds_bytes, o_nhb, o_first_bins, o_ntw;
+    int o_nd;                            // duty wavefronts per workgroup: 1 (chains and sums on one wave) or 2 (a chain wave and a sum wave)
     int o_off_FB, o_off_TP, o_off_FE, o_off_FW, o_off_CK, o_off_CT;
     int o_off_TW, o_off_HANN, o_off_SRC, o_off_DPHI, o_off_PFT, o_off_BACK;
     float o_near_cos2;                   // cos^2 of the angle the timing vector may turn between frames while the parked outputs stay valid

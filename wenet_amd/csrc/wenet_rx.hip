@@ -172,9 +172,12 @@ struct DemodTables {
 
     // configuration copy for the batch kernel with one wavefront per capture (demod_oct_impl.h), caps captures per workgroup;
     // o_ok == 0 in it if the geometry is not one it was written for (two tones, Ts 8 or 10 with P = Ts, one 256-point FFT per frame)
-    WrDemodCfg oct_cfg(int caps) const {
+    // nd = duty wavefronts per workgroup (1: chains and sums on one wave; 2: a chain wave and a sum wave -- for workgroups that fill a CU)
+    WrDemodCfg oct_cfg(int caps, int nd = 1) const {
         WrDemodCfg c = cfg;
         c.o_ok = 0;
+        if (nd < 1 || nd > 2) return c;
+        c.o_nd = nd;
         const bool small = cfg.M == 2 && (cfg.Ts == 8 || cfg.Ts == 10) && cfg.Ndft == 256;       // Wenet v1 / v2
         const bool large = cfg.M == 4 && cfg.Ts == 32 && cfg.Ndft == 1024;                        // BASELINE config 4 (4-FSK, Fs 1 843 200)
         if (cfg.big || !(small || large) || cfg.P != cfg.Ts || cfg.Nsym != WR_NSYM ||
@@ -190,9 +193,9 @@ struct DemodTables {
         const int tab = y.tab, o_tw = y.TW, o_hann = y.HANN, o_dphi = y.DPHI, o_src = y.SRC, o_pft = 0, o_back = y.BACK;
         const int max_caps = (160 * 1024 - tab) / c.o_cap_stride;
         if (caps < 1) caps = 1;
-        if (caps > 15) caps = 15;
+        if (caps > 16 - nd) caps = 16 - nd;
         if (caps > max_caps) caps = max_caps;
-        if (large && caps > 7) caps = 7;                                // (its kernel is built for workgroups of <= 512 threads: 256 VGPRs)
+        if (large && caps > 8 - nd) caps = 8 - nd;                      // (its kernel is built for workgroups of <= 512 threads: 256 VGPRs)
         if (caps < 1) return c;
         c.o_caps = caps;
         const int base = caps * c.o_cap_stride;
@@ -383,7 +386,7 @@ struct DemodTables {
         size_t bytes = 0;
         auto place = [&](size_t sz) { size_t at = bytes; bytes = (bytes + sz + 255) & ~(size_t)255; return at; };
         const size_t a_hann = place(Ndft * 4), a_tw = place(Ndft * 8), a_src = place(Ndft * 4), a_dphi = place(NH * 8),
-                     a_back = place(3 * NH * 8), a_pft = place(cfg.NI * 8), a_binf = place(NH * 4);
+                     a_back = place(3 * NH * 8), a_pft = place(cfg.NI * 8), a_binf = place(NH * 4), a_pftp = place((size_t)2 * ((cfg.NI + 3) & ~3) * 4);
         if (!blob.reserve(bytes)) return false;
         char *base = blob.as<char>();
         WR_CHECK(hipMemcpy(base + a_hann, hann.data(), Ndft * 4, hipMemcpyHostToDevice), false);
@@ -393,12 +396,19 @@ struct DemodTables {
         WR_CHECK(hipMemcpy(base + a_back, backoff.data(), 3 * NH * 8, hipMemcpyHostToDevice), false);
         WR_CHECK(hipMemcpy(base + a_pft, phift.data(), cfg.NI * 8, hipMemcpyHostToDevice), false);
         WR_CHECK(hipMemcpy(base + a_binf, binf.data(), NH * 4, hipMemcpyHostToDevice), false);
+        {   // the timing oscillator as two planes (batch kernel: packed products of neighbouring outputs)
+            const int NIq = (cfg.NI + 3) & ~3;
+            std::vector<float> pl((size_t)2 * NIq, 0.f);
+            for (int i = 0; i < cfg.NI; i++) { pl[i] = phift[i].r; pl[NIq + i] = phift[i].i; }
+            WR_CHECK(hipMemcpy(base + a_pftp, pl.data(), pl.size() * 4, hipMemcpyHostToDevice), false);
+        }
         cfg.hann = (const float *)(base + a_hann);
         cfg.tw = (const float2 *)(base + a_tw);
         cfg.fft_src = (const int *)(base + a_src);
         cfg.dphi_tab = (const float2 *)(base + a_dphi);
         cfg.backoff_tab = (const float2 *)(base + a_back);
         cfg.phi_ft = (const float2 *)(base + a_pft);
+        cfg.phi_ft_planes = (const float *)(base + a_pftp);
         cfg.bin_freq = (const float *)(base + a_binf);
         host_binf = binf;
         ok = true;
@@ -1129,16 +1139,19 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const lon
         // (demod_oct_impl.h).  A capture advances one frame per ~20 k cycles there (the pipelined kernels: 11.5 k), so it takes over once
         // the CUs hold several captures each.  WENET_RX_OCT=<caps> forces it
         // (tests), WENET_RX_NO_OCT turns it off.  Traces with Eb/N0 accumulators and profiling stay with the pipelined kernels.
-        int oct_caps = 0;
+        int oct_caps = 0, oct_nd = 1;
         if (fmt == WENET_FMT_CU8 && (!rx->profile || getenv("WENET_RX_PROFILE")[0] == '4')) {
             const char *force = getenv("WENET_RX_OCT");
             // measured (tools/gpu_batch_sweep.py, 10 s captures, 256 CUs, demod ms): the three-capture pipelined kernel takes 103 per round of 768
             // captures; workgroups of four captures 179 up to one per CU, 203 up to two per CU; workgroups of seven 195 up to one per CU,
             // 245..255 up to two per CU.  Hence: up to 3 captures per CU pipelined, then whichever workgroup size needs fewer per CU.
-            if (force) oct_caps = atoi(force) > 0 ? atoi(force) : 7;
+            if (force) { oct_caps = atoi(force) > 0 ? atoi(force) : 7; oct_nd = (c.M == 2 ? oct_caps > 7 : oct_caps > 2) ? 2 : 1; }
             else if (!rx->want_trace && c.M == 2 && n_sel > 3 * wenet_rx_device_info(1)) {
                 const int ncu = wenet_rx_device_info(1);
-                oct_caps = n_sel <= 4 * ncu ? 4 : (n_sel <= 7 * ncu ? 7 : (n_sel <= 8 * ncu ? 4 : 7));
+                oct_caps = n_sel <= 4 * ncu ? 4 : (n_sel <= 7 * ncu ? 7 : 14);
+                // beyond seven captures per CU: ONE workgroup of fourteen captures with a chain wave and a sum wave (round 3) instead of two
+                // workgroups of seven with one duty wave each
+                if (oct_caps == 14) oct_nd = 2;
             }
             // the 4-FSK / Ts 32 geometry (BASELINE config 4): 30 KB of LDS per capture = four captures per CU as two workgroups of two;
             // from two captures per CU on it beats the sequential kernel's one capture per CU (34 vs 11.5 Gsamples/s at 1024 captures)
@@ -1147,7 +1160,8 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const lon
         WrDemodCfg oct_cfg;
         bool use_oct = false;
         if (oct_caps > 0) {
-            oct_cfg = rx->tab.oct_cfg(oct_caps);
+            if (getenv("WENET_RX_OCT_ND")) oct_nd = atoi(getenv("WENET_RX_OCT_ND")) == 2 ? 2 : 1;
+            oct_cfg = rx->tab.oct_cfg(oct_caps, oct_nd);
             use_oct = oct_cfg.o_ok != 0 && fmt == WENET_FMT_CU8;
         }
         launch_cfg.p_tsum_split = getenv("WENET_RX_TSUM_SPLIT") ? atoi(getenv("WENET_RX_TSUM_SPLIT")) : ((n_sel > wenet_rx_device_info(1)) ? 1 : 0);
@@ -1222,7 +1236,7 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const lon
         // sub-batch's size, not the whole batch's -- its uploads, not the kernels, set the pace)
         const DemodChoice sub = host_src ? choose_demod(n) : whole;
         if (host_src && k == rx->nchunks - 1) rx->last_kernel = kernel_name(sub);
-        const int round_caps = sub.use_oct ? 2 * sub.oct_cfg.o_caps * ncu : 0;
+        const int round_caps = sub.use_oct ? (sub.oct_cfg.o_nd == 2 ? 1 : 2) * sub.oct_cfg.o_caps * ncu : 0;     // captures a device holds at once
         const int full = (sub.use_oct && !host_src && getenv("WENET_RX_OCT") == nullptr && round_caps > 0 && n > round_caps) ? (n / round_caps) * round_caps : n;
         if (sub.use_oct) WR_CHECK(wr_launch_demod_oct(&sub.oct_cfg, rx->d_chans.as<WrChan>() + lo, full, stream), -4);
         else WR_CHECK(wr_launch_demod_ex(&sub.launch_cfg, rx->d_chans.as<WrChan>() + lo, n, stream, prof), -4);
@@ -1430,8 +1444,8 @@ extern "C" float wenet_rx_last_ms(wenet_rx *rx, int what) {
 // enqueue when WENET_RX_PROFILE was set; returns the number of counters
 extern "C" int wenet_rx_debug_profile(wenet_rx *rx, int ch, long long *out12) {
     if (!rx || !rx->profile || ch < 0 || ch >= rx->nchan) return 0;
-    if (hipMemcpy(out12, rx->d_prof.as<long long>() + (size_t)ch * 32, 26 * 8, hipMemcpyDeviceToHost) != hipSuccess) return 0;
-    return 26;
+    if (hipMemcpy(out12, rx->d_prof.as<long long>() + (size_t)ch * 32, 32 * 8, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return 32;
 }
 
 extern "C" int wenet_rx_device_info(int what) {

@@ -14,7 +14,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libwenet_rx.so")
+LIB_PATH = os.environ.get("WENET_RX_LIB") or os.path.join(_HERE, "libwenet_rx.so")     # (WENET_RX_LIB: a development build, e.g. tools/prof_build.sh)
 
 # every symbol include/wenet_rx.h declares
 EXPORTS = [
