@@ -13,7 +13,7 @@ and packet byte identical to the reference pipe).  N GPUs = N ranks, each with i
 Prints ONE JSON line (see the contract in the task description) with these extra objects:
   roofline      the demod kernel (dominant) against the 8 TB/s HBM peak, from HIP events around the kernel on
                 its launch stream; `traffic` and the `valu` block come from the committed rocprofv3 PMC
-                profile of THAT kernel at THIS batch (profiles/r02_pmc_*.json, tools/gpu_profile_round.sh)
+                profile of THAT kernel at THIS batch and of THESE sources (profiles/r*_pmc_*.json, tools/gpu_profile_round.sh)
   cpu_baseline  the reference C pipeline (oracle/_ref, built from the unmodified sources) timed on this
                 host in the three shapes of SURVEY.md 8d / benchmarking/test_demod.py: (a) the harness's
                 own `--stats=100 ... 2>stats` pipe, (b) stats off, (c) all cores through xargs -P;
@@ -48,7 +48,7 @@ def _pipe_cmd(ref_dir, cfg, framing, path, stats):
     return f"{demod} --cu8 -s {st}{cfg.M} {cfg.Fs} {cfg.Rs} {path} - 2>{err} | {l2} - - 2>/dev/null"
 
 
-def cpu_baseline(cfg, caps_host, framing, gpu_payloads, reps=3, comparable=True):
+def cpu_baseline(cfg, caps_host, framing, gpu_payloads, reps=3):
     """Reference pipeline `fsk_demod --cu8 -s M Fs Rs - - | {drs232,wenet}_ldpc - -` on host cores:
     (a) with --stats=100 and the stats stream kept (the shape of benchmarking/test_demod.py:26-43), one capture = 2 busy cores;
     (b) stats off; (c) every sample capture at once through xargs -P $(nproc).  Medians of `reps` repetitions."""
@@ -90,44 +90,47 @@ def cpu_baseline(cfg, caps_host, framing, gpu_payloads, reps=3, comparable=True)
             dt = statistics.median(t)
             legs[leg] = {"wall_s": round(dt, 4), "msamples_per_s": round(nsamp / dt / 1e6, 3), "x_realtime": round(nsamp / dt / cfg.Fs, 1),
                          "packets": npk, "cores": 2}
-        # (c) all sample captures at once; the per-capture output is checked once, outside the timed repetitions
-        for i, p in enumerate(paths[1:], 1):
-            out = subprocess.run(_pipe_cmd(ref_dir, cfg, framing, p, False), shell=True, stdout=subprocess.PIPE, check=True).stdout
-            same = same and out == gpu_payloads[i]
+        # (c) the whole host: logical_cpus / 2 captures at once = one two-process pipe per pair of logical CPUs (xargs -P); every pipe writes its
+        # packets to a file in the same tmpfs, all of them compared with the GPU's after the last repetition
         t = []
         listing = os.path.join(td, "list.txt")
         open(listing, "w").write("\n".join(paths) + "\n")
         demod = os.path.join(ref_dir, "fsk_demod")
         l2 = os.path.join(ref_dir, "drs232_ldpc" if framing == 1 else "wenet_ldpc")
-        cmd = (f"xargs -P {ncpu} -I{{}} sh -c '{demod} --cu8 -s {cfg.M} {cfg.Fs} {cfg.Rs} {{}} - 2>/dev/null | {l2} - - 2>/dev/null | wc -c' "
-               f"< {listing} > /dev/null")
+        cmd = (f"xargs -P {len(paths)} -I{{}} sh -c '{demod} --cu8 -s {cfg.M} {cfg.Fs} {cfg.Rs} {{}} - 2>/dev/null | {l2} - {{}}.pk 2>/dev/null' < {listing}")
         for _ in range(reps):
             t0 = time.perf_counter()
             subprocess.run(cmd, shell=True, check=True)
             t.append(time.perf_counter() - t0)
+        for i, p in enumerate(paths):
+            same = same and open(p + ".pk", "rb").read() == gpu_payloads[i]
         dt = statistics.median(t)
         legs["c_all_cores"] = {"wall_s": round(dt, 4), "msamples_per_s": round(len(paths) * nsamp / dt / 1e6, 3), "captures": len(paths),
-                               "xargs_P": ncpu, "logical_cpus": ncpu}
+                               "processes": 2 * len(paths), "logical_cpus": ncpu}
     return {"value": legs["b_stats_off"]["msamples_per_s"], "unit": "Msamples/s", "cores": 2, "kind": "reference",
             "sample": f"one 10 s capture of the batch through the literal 2-process pipe, stats off, median of {reps} repetitions (leg b); "
-                      f"legs a (--stats=100, the harness shape) and c ({len(paths)} captures, xargs -P {ncpu}) beside it",
-            "legs": legs, "packets_match_gpu": bool(same) if comparable else None,
-            **({} if comparable else {"packets_note": "not compared: the reference executables have MAX_ITER 10 compiled in (drs232_ldpc.c / wenet_ldpc.c), this run decodes with another iteration limit"})}
+                      f"legs a (--stats=100, the harness shape) and c ({len(paths)} captures at once = {2 * len(paths)} processes on {ncpu} logical CPUs) beside it",
+            "legs": legs, "packets_match_gpu": bool(same)}
 
 
 def load_pmc_profile(kernel_name, inst, captures):
     """Committed rocprofv3 PMC profile of the demod kernel that ran (profiles/r*_pmc_*.json): HBM bytes per IQ sample from separate
     FETCH_SIZE / WRITE_SIZE passes and the SQ counters behind the VALU figures.  None unless a profile of THIS kernel instantiation
-    (`inst` = its template arguments, e.g. "<2, 10, 256") at THIS batch size is committed."""
+    (`inst` = its template arguments, e.g. "<2, 10, 256") at THIS batch size is committed AND the profile carries the identity of the kernel
+    sources this process runs (wenet_amd/codeid.py, stamped by tools/gpu_profile_round.sh)."""
+    from wenet_amd import codeid
+    here = codeid.source_sha16()
     best = None
     for pj in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_*.json"))):
         try:
             d = json.load(open(pj))
         except Exception:
             continue
+        if d.get("source_sha16") != here:              # a profile of OTHER kernel sources (taken before the last change): not quoted
+            continue
         for k, v in d.get("kernels", {}).items():
             if kernel_name.split("<")[0] in k and not v.get("fast", False) and (inst is None or inst in k) and d.get("captures") == captures:
-                best = dict(v, file=os.path.relpath(pj, ROOT), captures=d.get("captures"), samples_in_launch=d.get("samples_in_launch"))
+                best = dict(v, file=os.path.relpath(pj, ROOT), captures=d.get("captures"), samples_in_launch=d.get("samples_in_launch"), source_sha16=d.get("source_sha16"))
     return best
 
 
@@ -138,6 +141,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--captures", type=int, default=int(os.environ.get("WENET_BENCH_CAPTURES", "3584")),
                     help="independent captures per GPU (3584 = 14 per CU = two workgroups of seven captures of the batch demodulator)")
+    ap.add_argument("--total-captures", type=int, default=0,
+                    help="a FIXED set of this many captures for the whole job, dealt to the ranks round-robin (capture index mod n_gpus, wenet_amd/shard.py: "
+                         "BASELINE configs 3 and 5 -- 64 / 128 captures over 8 GPUs); scaling is then 'strong'.  0: --captures per rank (weak scaling)")
+    ap.add_argument("--sweep", action="store_true", help="Eb/N0 rises from 4 to 12 dB over the capture index (BASELINE config 3) instead of --ebno for all")
     ap.add_argument("--seconds", type=float, default=10.0, help="length of each capture")
     ap.add_argument("--ebno", type=float, default=8.0)
     ap.add_argument("--ppm", type=float, default=0.0, help="symbol-clock error of the synthetic transmitters")
@@ -173,7 +180,18 @@ def main():
     cfg = siggen.CONFIGS[args.config]()
     nsym = int(args.seconds * cfg.Rs)
     nsamp = nsym * cfg.Ts
-    B = args.captures
+    # which captures this rank owns: its own --captures (weak scaling: per-GPU work fixed), or its round-robin share of --total-captures
+    if args.total_captures > 0:
+        from wenet_amd.shard import shard_indices
+        mine = shard_indices(args.total_captures, rank, world)           # global capture indices of this rank
+        n_all = args.total_captures
+    else:
+        mine = [rank * args.captures + i for i in range(args.captures)]
+        n_all = world * args.captures
+    B = len(mine)
+    if B == 0:
+        raise SystemExit(f"rank {rank}: no capture to process (--total-captures {args.total_captures} over {world} ranks)")
+    ebnos = [4.0 + 8.0 * g / max(n_all - 1, 1) for g in mine] if args.sweep else [args.ebno] * B
     # synthetic captures, born in HBM: random payloads -> frames -> M-FSK + AWGN by the library's own generator
     # kernels (include/wenet_tx.h; format pinned in tests/test_gpu_tx.py).  torch only owns the memory.
     from wenet_amd.tx import Tx
@@ -187,12 +205,12 @@ def main():
     tx.frame_packets_device(payloads.data_ptr(), B * nfr, symbols.data_ptr())
     caps = [torch.empty(2 * nsamp, dtype=torch.uint8, device=dev) for _ in range(B)]
     sym_ptrs = [symbols.data_ptr() + i * nfr * spp for i in range(B)]
-    seeds = [7000 + i + 100000 * rank for i in range(B)]
+    seeds = [7000 + g for g in mine] if args.total_captures > 0 else [7000 + i + 100000 * rank for i in range(B)]
 
     def modulate(ppm):
         torch.cuda.synchronize()
         tg = time.perf_counter()
-        tx.modulate_device(sym_ptrs, [nsym] * B, [c.data_ptr() for c in caps], args.ebno, ppm=(ppm if ppm else None), seeds=seeds)
+        tx.modulate_device(sym_ptrs, [nsym] * B, [c.data_ptr() for c in caps], ebnos, ppm=(ppm if ppm else None), seeds=seeds)
         torch.cuda.synchronize()
         return time.perf_counter() - tg
 
@@ -240,7 +258,7 @@ def main():
 
     npk_valid = sum(int(rx.packets(c)["crc_ok"].sum()) for c in range(B))
     npk_all = sum(rx.npackets(c) for c in range(B))
-    total_samples = world * B * nsamp * args.steps
+    total_samples = n_all * nsamp * args.steps                          # (all ranks' captures; --total-captures: the fixed set)
     value = total_samples / dt / 1e6
     kernel_name = rx.last_kernel()
 
@@ -259,19 +277,30 @@ def main():
             roof["traffic_source"] = (f"{prof['file']}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH_SIZE x2 on gfx950) of {kernel_name} "
                                       f"at {prof.get('captures')} captures; {prof['hbm_bytes_per_iq_sample']:.4f} B per IQ sample x samples of this launch")
             if "valu_busy" in prof:
-                roof["valu"] = {k: prof[k] for k in ("valu_busy", "valu_busy_packed_weighted", "lanes_active", "valu_insts_per_frame", "lds_busy",
-                                                     "lds_bank_conflict_ratio") if k in prof}
+                roof["valu"] = {k: prof[k] for k in ("valu_util", "valu_packed_share", "simd_cycles_per_valu_inst", "valu_busy", "lanes_active", "valu_insts_per_frame",
+                                                     "lds_busy", "lds_bank_conflict_ratio", "wave_cycles_share") if k in prof}
                 roof["valu"]["source"] = prof["file"]
+                roof["valu"]["source_sha16"] = prof.get("source_sha16")
+            if prof.get("valu_util"):
+                # the second ceiling (SURVEY.md 8d "state both"): what this instruction stream allows if every SIMD issued VALU work all the time --
+                # instructions per frame x calibrated SIMD cycles per instruction (profiles/r03_valu_calibration.json) against 1024 SIMDs x their clock
+                rate = B * nsamp / demod_s
+                roof["ceilings"] = {"hbm_gsamples_per_s": round(HBM_PEAK_GBS / ALGO_BYTES_PER_SAMPLE, 1),
+                                    "valu_gsamples_per_s": round(rate / prof["valu_util"] / 1e9, 1),
+                                    "achieved_gsamples_per_s": round(rate / 1e9, 1),
+                                    "note": "valu = the measured rate / calibrated VALU utilisation: the rate at which THIS kernel's instruction stream would saturate the SIMDs"}
         line = {
             "metric": "IQ Msamples/s demod+LDPC-decoded", "value": round(value, 3), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong" if args.total_captures > 0 else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "mode": "exact (bit-identical to the reference pipe)",
             "datagen": {"by": "wenet_tx_modulate (GPU)", "ms": round(datagen_s * 1e3, 1),
                         "gsamples_per_s": round(B * nsamp / datagen_s / 1e9, 2)},
-            "config": {"workload": f"{cfg.name} {cfg.M}-FSK Rs={cfg.Rs} Fs={cfg.Fs} cu8 Eb/N0={args.ebno}dB "
-                                   f"{args.seconds:g}s x {B} independent captures per GPU (BASELINE config {4 if cfg.M == 4 else 2} shape, batched)"
+            "config": {"workload": f"{cfg.name} {cfg.M}-FSK Rs={cfg.Rs} Fs={cfg.Fs} cu8 Eb/N0={'4..12 dB sweep' if args.sweep else str(args.ebno) + 'dB'} "
+                                   + (f"{args.seconds:g}s x {n_all} captures in all, capture i on rank i mod {world} (BASELINE config {3 if args.sweep else 5} shape)"
+                                      if args.total_captures > 0 else
+                                      f"{args.seconds:g}s x {B} independent captures per GPU (BASELINE config {4 if cfg.M == 4 else 2} shape, batched)")
                                    + (f", {args.ppm:g} ppm symbol-clock error" if args.ppm else ""),
                        "captures_per_gpu": B, "samples_per_capture": nsamp, "framing": cfg.mode, "ldpc_max_iter": args.max_iter},
             "x_realtime_aggregate": round(value * 1e6 / cfg.Fs, 1),
@@ -282,10 +311,21 @@ def main():
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
-            ncpu = max(2, min(B, 32, os.cpu_count() or 2))
+            ncpu = max(1, min(B, (os.cpu_count() or 2) // 2))              # leg (c) fills the host: one two-process pipe per pair of logical CPUs
             caps_host = [caps[i].cpu().numpy() for i in range(ncpu)]
-            gpu_payloads = [rx.valid_payloads(i) for i in range(ncpu)]
-            line["cpu_baseline"] = cpu_baseline(cfg, caps_host, cfg.mode, gpu_payloads, comparable=(args.max_iter == 10))
+            if args.max_iter == 10:
+                gpu_payloads = [rx.valid_payloads(i) for i in range(ncpu)]
+            else:
+                # the reference executables have MAX_ITER 10 compiled in (drs232_ldpc.c:39 / wenet_ldpc.c): their packets are compared with a
+                # second GPU pass over the sample captures at that limit
+                rx10 = RxBatch(cfg.Fs, cfg.Rs, cfg.M, framing=cfg.mode, max_iter=10)
+                step(rx10, ptrs[:ncpu], ns[:ncpu])
+                gpu_payloads = [rx10.valid_payloads(i) for i in range(ncpu)]
+                rx10.close()
+            line["cpu_baseline"] = cpu_baseline(cfg, caps_host, cfg.mode, gpu_payloads)
+            if args.max_iter != 10:
+                line["cpu_baseline"]["packets_note"] = (f"compared with a second GPU pass at MAX_ITER 10 (the limit compiled into the reference executables); "
+                                                        f"the timed GPU steps decode with MAX_ITER {args.max_iter}")
         else:
             line["cpu_baseline"] = None
         if world == 1 and not args.no_extras:

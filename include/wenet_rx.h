@@ -196,6 +196,16 @@ long long wenet_rx_get_llrs(wenet_rx *rx, int ch, float *llr, long long cap_pack
 /* (Round 2's wenet_rx_set_fast / wenet_rx_fast_reruns -- parity-ladder rung P3, SURVEY.md 8c -- are gone: the relaxed arithmetic was slower than
  * the exact kernels and missed the 1e-4 absolute LLR bound; DESIGN.md section 7 keeps the measurements.  Every mode of this library is rung P2:
  * bit-identical to the reference pipe.) */
+/* HIP device the handle lives on: the one that was current (hipGetDevice) when it was created.  Every call on a handle makes that device current
+ * for its duration and restores the caller's afterwards, so one process may hold handles on several GPUs (one host thread per device; a handle is
+ * not re-entrant).  Device addresses passed to wenet_rx_enqueue must belong to the handle's device. */
+int wenet_rx_get_device(wenet_rx *rx);
+/* Complex-float captures of the reference's benchmarking flow (benchmarking/generate_lowsnr.py:100-125 writes them, benchmarking/test_demod.py:26-43
+ * pipes them through `csdr convert_f_u8` / `csdr convert_f_s16` into fsk_demod --cu8 / --cs16): with to_fmt = WENET_FMT_CU8 or WENET_FMT_CS16 a
+ * WENET_FMT_CF32 batch is quantised on the GPU first -- (unsigned char)(x * 127.5 + 128) resp. (short)(x * 32767) on the interleaved I / Q floats, single
+ * precision, saturating -- and the chain runs on the quantised copy.  -1 (default): complex floats are demodulated as they are (the COMP[] of
+ * fsk_demod_sd()).  csdr is not part of the reference tree: PARITY UNPINNED for the two converters.  0 on success. */
+int wenet_rx_set_cf32_quantise(wenet_rx *rx, int to_fmt);
 /* name of the demodulator kernel the last enqueue launched (the library picks it by batch size, format and geometry) */
 const char *wenet_rx_last_kernel(wenet_rx *rx);
 /* timing of the last enqueue in milliseconds (HIP events on the launch stream):
@@ -203,8 +213,8 @@ const char *wenet_rx_last_kernel(wenet_rx *rx);
 float wenet_rx_last_ms(wenet_rx *rx, int what);
 
 /* library / device info: 0 = device count, 1 = multiprocessor count of the current device.
- * One device per process: the library works on the HIP device that is current when it is first used (bench.py: one rank = one
- * process = one GPU); calls made with another device current are refused. */
+ * Handles are per device (see wenet_rx_get_device): create them with the wanted device current; bench.py runs one rank = one process = one
+ * GPU, a single process may equally keep one handle (and one host thread) per GPU. */
 int wenet_rx_device_info(int what);
 const char *wenet_rx_version(void);
 

@@ -52,3 +52,18 @@ def test_two_ranks_on_one_gpu_over_gloo():
     # value = samples of ALL ranks / max-over-ranks time
     assert abs(d["value"] - 2 * 16 * nsamp * 2 / (d["ms_per_step"] * 2e-3) / 1e6) < 1e-3 * d["value"]
     assert d["packets_valid_per_step_rank0"] > 0
+
+
+def test_fixed_capture_set_sharded_round_robin_over_two_ranks():
+    """BASELINE configs 3 / 5 shape (a fixed set of captures, capture i on rank i mod n_gpus, Eb/N0 sweep 4..12 dB) through the code path the
+    8-GPU run will take -- bench.py --total-captures over wenet_amd/shard.py -- here with two ranks sharing the one GPU over gloo."""
+    env = dict(os.environ, WENET_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29519",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--total-captures", "9", "--sweep", "--seconds", "1", "--steps", "2", "--warmup", "1"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _line(r.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["captures_per_gpu"] == 5          # rank 0 owns captures 0, 2, 4, 6, 8
+    nsamp = d["config"]["samples_per_capture"]
+    assert abs(d["value"] - 9 * nsamp * 2 / (d["ms_per_step"] * 2e-3) / 1e6) < 1e-3 * d["value"]
+    assert "sweep" in d["config"]["workload"] and d["packets_valid_per_step_rank0"] > 0

@@ -14,6 +14,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <map>
 #include <mutex>
 #include <algorithm>
 #include <vector>
@@ -65,7 +66,10 @@ struct DevBuf {
     template <typename T> T *as() const { return (T *)p; }
 };
 
-int g_device = -1;          // the device the process works on (set once; include/wenet_rx.h: one device per process)
+// Devices.  A handle (wenet_fsk, wenet_deframer, wenet_rx) lives on the HIP device that was current when it was created: its tables, state and
+// scratch are allocated there, and every entry point makes that device current for the duration of the call (DeviceGuard) -- so one process can
+// hold handles on several GPUs, one host thread + stream set per device.  The code tables and the scratch of the
+// handle-less LDPC entry points exist once per device (ldpc_tables(), decode_scratch()).
 bool device_ready() {
     static std::once_flag once;
     static bool ok = false;
@@ -75,11 +79,21 @@ bool device_ready() {
             fprintf(stderr, "libwenet_rx: no HIP device available -- this library has no CPU fallback\n");
             return;
         }
-        if (hipGetDevice(&g_device) != hipSuccess) g_device = 0;
         ok = true;
     });
     return ok;
 }
+int current_device() { int d = 0; if (hipGetDevice(&d) != hipSuccess) d = 0; return d; }
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int dev) {
+        if (dev >= 0 && hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
 
 struct cpx { float r, i; };
 inline cpx cmulh(cpx a, cpx b) { cpx c; c.r = a.r * b.r - a.i * b.i; c.i = a.r * b.i + a.i * b.r; return c; }
@@ -574,17 +588,18 @@ struct LdpcTables {
     }
 };
 
-LdpcTables *ldpc_tables() {
+LdpcTables *ldpc_tables() {                                            // the code tables of the CURRENT device (built on first use)
     static std::mutex mu;
-    static LdpcTables *t = nullptr;
+    static std::map<int, LdpcTables *> per_device;
+    if (!device_ready()) return nullptr;
+    const int dev = current_device();
     std::lock_guard<std::mutex> g(mu);
-    if (!t) {
-        if (!device_ready()) return nullptr;
-        LdpcTables *n = new LdpcTables();
-        if (!n->build()) { delete n; return nullptr; }
-        t = n;
-    }
-    return t;
+    auto it = per_device.find(dev);
+    if (it != per_device.end()) return it->second;
+    LdpcTables *n = new LdpcTables();
+    if (!n->build()) { delete n; return nullptr; }
+    per_device[dev] = n;
+    return n;
 }
 
 void fill_decode_tables(WrDecodeArgs &a, const LdpcTables *t) {
@@ -597,6 +612,7 @@ void fill_decode_tables(WrDecodeArgs &a, const LdpcTables *t) {
 // L1 handle
 // ================================================================================================
 struct wenet_fsk {
+    int device = current_device();     // the HIP device the handle lives on
     DemodTables tab;
     DevBuf d_state, d_chan, d_raw, d_out, d_trace, d_dump, d_big;
     WrChanHdr hdr;                 // host copy after the last launch
@@ -639,7 +655,7 @@ extern "C" wenet_fsk *wenet_fsk_create(int Fs, int Rs, int M, int tx_f1, int tx_
     return f;
 }
 
-extern "C" void wenet_fsk_destroy(wenet_fsk *f) { delete f; }
+extern "C" void wenet_fsk_destroy(wenet_fsk *f) { if (f) { DeviceGuard dg(f->device); delete f; } }
 
 extern "C" void wenet_fsk_set_est_limits(wenet_fsk *f, int fmin, int fmax) {   // fsk.c:522-528
     if (!f) return;
@@ -672,6 +688,7 @@ static const int kBytesPerSample[4] = {2, 4, 2, 8};
 extern "C" long wenet_fsk_demod_stream(wenet_fsk *f, int fmt, const void *raw, long nsamples, int soft,
                                        void *out, long cap_frames, long *consumed, float *trace) {
     if (!f || fmt < 0 || fmt > 3 || nsamples < 0 || cap_frames < 0) return -1;
+    DeviceGuard dg(f->device);
     const WrDemodCfg &c = f->tab.cfg;
     if (consumed) *consumed = 0;
     f->stats_out.clear();
@@ -801,7 +818,7 @@ struct DecodeScratch {
     DevBuf d_in, d_out, d_llr, d_npk, d_bits, d_esn0;
 };
 std::mutex g_dec_mu;
-DecodeScratch g_dec;
+std::map<int, DecodeScratch> g_dec_per_device;                          // (scratch of the handle-less entry points, one set per device)
 
 // npk dense packets through the decode kernel; kind = WR_DEC_IN_LLR (in = float[npk*2580]) or
 // WR_DEC_IN_SD64 (in = double[npk*n])
@@ -810,6 +827,7 @@ int run_dense(int kind, const void *in, int npk, int n, int mode, int max_iter, 
     LdpcTables *t = ldpc_tables();
     if (!t) return -1;
     std::lock_guard<std::mutex> g(g_dec_mu);
+    DecodeScratch &g_dec = g_dec_per_device[current_device()];
     const size_t in_bytes = (size_t)npk * n * (kind == WR_DEC_IN_SD64 ? 8 : 4);
     if (!g_dec.d_in.reserve(in_bytes) || !g_dec.d_out.reserve((size_t)npk * sizeof(WrPacketOut)) || !g_dec.d_npk.reserve(16)) return -2;
     if (llr_host && !g_dec.d_llr.reserve((size_t)npk * n * 4)) return -2;
@@ -876,6 +894,7 @@ extern "C" void wenet_sd_to_llr(float llr[], double sd[], int n) {
 // L2 deframer handle = the symbol loop of drs232_ldpc.c:176-274 / wenet_ldpc.c:171-258
 // ================================================================================================
 struct wenet_deframer {
+    int device = current_device();
     int mode = 1, max_iter = 10, spp = 3230;
     std::vector<float> carry;            // symbols from the last resume point on
     long long carry_base = 0;            // absolute index of carry[0] in the symbol stream
@@ -893,11 +912,12 @@ extern "C" wenet_deframer *wenet_deframer_create(int framing_mode, int max_iter)
     if (!d->d_state.reserve(sizeof(WrDeframeState)) || !d->d_chan.reserve(sizeof(WrDeframeChan))) { delete d; return nullptr; }
     return d;
 }
-extern "C" void wenet_deframer_destroy(wenet_deframer *d) { delete d; }
+extern "C" void wenet_deframer_destroy(wenet_deframer *d) { if (d) { DeviceGuard dg(d->device); delete d; } }
 
 extern "C" long wenet_deframer_push(wenet_deframer *d, const float *symbols, long nsym, uint8_t *pkt_bytes,
                                     wenet_packet_info *pkt_info, long cap) {
     if (!d || nsym < 0) return -1;
+    DeviceGuard dg(d->device);
     LdpcTables *t = ldpc_tables();
     if (!t) return -1;
     if (nsym > 0) d->carry.insert(d->carry.end(), symbols, symbols + nsym);
@@ -945,12 +965,54 @@ extern "C" long wenet_deframer_push(wenet_deframer *d, const float *symbols, lon
 }
 
 // ================================================================================================
+// cf32 -> cu8 / cs16 on the device: the quantising stage of the reference's benchmarking flow
+// ================================================================================================
+// benchmarking/test_demod.py:26-43 feeds the complex-float captures benchmarking/generate_lowsnr.py:100-125 writes through `csdr convert_f_u8` /
+// `csdr convert_f_s16` into fsk_demod --cu8 / --cs16.  csdr is not part of the reference tree: SURVEY.md 8c restates convert_f_u8 as
+// (unsigned char)(x * 127.5 + 128) on the interleaved I / Q floats, convert_f_s16 as (short)(x * SHRT_MAX) -- PARITY UNPINNED for these two
+// converters (no reference test covers them).  Here: single-precision multiply, then add, each rounded (no FMA), truncation towards zero,
+// out-of-range values saturate (the C casts are undefined there).  One thread converts four floats (16 B in, 4 / 8 B out).
+namespace {
+struct WrQuantJob { const float *src; void *dst; long long nfloats; };
+__device__ __forceinline__ unsigned quant_u8(float x) {
+    const float y = __fadd_rn(__fmul_rn(x, 127.5f), 128.0f);
+    return (unsigned)(int)fminf(fmaxf(y, 0.f), 255.f);
+}
+__device__ __forceinline__ int quant_s16(float x) {
+    const float y = __fmul_rn(x, 32767.0f);
+    return (int)fminf(fmaxf(y, -32768.f), 32767.f);
+}
+template <bool S16>
+__global__ __launch_bounds__(256) void wenet_quantise_kernel(const WrQuantJob *jobs) {
+    const WrQuantJob j = jobs[blockIdx.y];
+    const long long nq = j.nfloats >> 2;
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (long long)gridDim.x * blockDim.x) {
+        const float4 v = ((const float4 *)j.src)[q];
+        if (S16) {
+            const int a = quant_s16(v.x), b = quant_s16(v.y), c = quant_s16(v.z), d = quant_s16(v.w);
+            ((uint2 *)j.dst)[q] = make_uint2((unsigned)(a & 0xffff) | ((unsigned)b << 16), (unsigned)(c & 0xffff) | ((unsigned)d << 16));
+        } else {
+            ((unsigned *)j.dst)[q] = quant_u8(v.x) | (quant_u8(v.y) << 8) | (quant_u8(v.z) << 16) | (quant_u8(v.w) << 24);
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (j.nfloats & 3)) {             // (a capture is whole I / Q pairs: at most one pair left over)
+        const long long i = (nq << 2) + threadIdx.x;
+        if (S16) ((short *)j.dst)[i] = (short)quant_s16(j.src[i]);
+        else ((unsigned char *)j.dst)[i] = (unsigned char)quant_u8(j.src[i]);
+    }
+}
+}  // namespace
+
+// ================================================================================================
 // batch receive chain
 // ================================================================================================
 struct wenet_rx {
+    int device = current_device();     // the HIP device the handle lives on (every entry point makes it current)
     DemodTables tab;
     int mode = 1, max_iter = 10, spp = 3230;
     bool want_trace = false, want_llr = false;
+    int cf32_quant = -1;                                 // WENET_FMT_CU8 / WENET_FMT_CS16: complex-float input is quantised to that format first (wenet_rx_set_cf32_quantise)
+    DevBuf d_quant, d_qjobs;
     const char *last_kernel = "";                        // demod kernel of the last enqueue
     int nchan = 0, max_pk = 0;
     std::vector<long long> sd_off, cap_frames;           // per channel: float offset into d_sd, frame capacity
@@ -1020,7 +1082,7 @@ extern "C" wenet_rx *wenet_rx_create(int Fs, int Rs, int P, int M, int framing_m
     if (!rx->chunk_events(1)) { delete rx; return nullptr; }
     return rx;
 }
-extern "C" void wenet_rx_destroy(wenet_rx *rx) { delete rx; }
+extern "C" void wenet_rx_destroy(wenet_rx *rx) { if (rx) { DeviceGuard dg(rx->device); delete rx; } }
 extern "C" int wenet_rx_packet_census(wenet_rx *rx, int ch, long long counts[8]) {
     if (!rx || rx->pending || ch < 0 || ch >= rx->nchan || (size_t)(ch + 1) * WR_CENSUS_CLASSES > rx->h_census.size()) return -1;
     for (int k = 0; k < WR_CENSUS_CLASSES; k++) counts[k] = rx->h_census[(size_t)ch * WR_CENSUS_CLASSES + k];
@@ -1029,20 +1091,39 @@ extern "C" int wenet_rx_packet_census(wenet_rx *rx, int ch, long long counts[8])
 extern "C" void wenet_rx_enable_trace(wenet_rx *rx, int on) { if (rx) { rx->want_trace = on != 0; rx->tab.cfg.stats = on ? 1 : 0; } }
 extern "C" void wenet_rx_enable_llr_dump(wenet_rx *rx, int on) { if (rx) rx->want_llr = on != 0; }
 extern "C" const char *wenet_rx_last_kernel(wenet_rx *rx) { return rx ? rx->last_kernel : ""; }
+extern "C" int wenet_rx_get_device(wenet_rx *rx) { return rx ? rx->device : -1; }
+extern "C" int wenet_rx_set_cf32_quantise(wenet_rx *rx, int to_fmt) {
+    if (!rx || (to_fmt != -1 && to_fmt != WENET_FMT_CU8 && to_fmt != WENET_FMT_CS16)) return -1;
+    rx->cf32_quant = to_fmt;
+    return 0;
+}
 
 // raw[i]: device address of capture i.  host_src != nullptr: its content still has to be copied there from host_src[i];
 // the batch is then cut into sub-batches whose uploads (copy stream) overlap the kernels of the previous sub-batch.
-static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const long long *nsamples, int fmt, void *stream_v,
+static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw_in, const long long *nsamples, int fmt_in, void *stream_v,
                       const void *const *host_src) {
-    if (!rx || nchan <= 0 || fmt < 0 || fmt > 3) return -1;
+    if (!rx || nchan <= 0 || fmt_in < 0 || fmt_in > 3) return -1;
     if (rx->pending && wenet_rx_collect(rx) < 0) return -1;            // a batch still in flight owns the buffers: finish it first
-    {   // one device per process: the code tables live on the device that was current when the library first ran
-        int dev = -1;
-        if (hipGetDevice(&dev) != hipSuccess || (g_device >= 0 && dev != g_device)) {
-            fprintf(stderr, "libwenet_rx: the current HIP device (%d) is not the one the library was initialised on (%d)\n", dev, g_device);
-            return -1;
+    DeviceGuard dg(rx->device);
+    // complex-float captures of the benchmarking flow: quantised on the device to cu8 / cs16 first (see wenet_quantise_kernel), the chain then
+    // runs on the quantised copy exactly as if `csdr convert_f_u8 | fsk_demod --cu8` had been fed
+    const bool quant = fmt_in == WENET_FMT_CF32 && rx->cf32_quant >= 0;
+    const int fmt = quant ? rx->cf32_quant : fmt_in;
+    std::vector<const void *> raw_q;
+    if (quant) {
+        const size_t bps = (size_t)kBytesPerSample[fmt];
+        std::vector<size_t> qoff(nchan + 1, 0);
+        for (int i = 0; i < nchan; i++) qoff[i + 1] = (qoff[i] + (size_t)nsamples[i] * bps + 255) & ~(size_t)255;
+        if (!rx->d_quant.reserve(qoff[nchan] + 256) || !rx->d_qjobs.reserve(sizeof(WrQuantJob) * nchan)) return -2;
+        std::vector<WrQuantJob> jobs(nchan);
+        raw_q.resize(nchan);
+        for (int i = 0; i < nchan; i++) {
+            raw_q[i] = rx->d_quant.as<char>() + qoff[i];
+            jobs[i].src = (const float *)raw_in[i]; jobs[i].dst = (void *)raw_q[i]; jobs[i].nfloats = 2 * nsamples[i];
         }
+        WR_CHECK(hipMemcpy(rx->d_qjobs.p, jobs.data(), sizeof(WrQuantJob) * nchan, hipMemcpyHostToDevice), -3);
     }
+    const void *const *raw = quant ? raw_q.data() : raw_in;
     LdpcTables *t = ldpc_tables();
     if (!t) return -1;
     const WrDemodCfg &c = rx->tab.cfg;
@@ -1148,10 +1229,10 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const lon
             if (force) { oct_caps = atoi(force) > 0 ? atoi(force) : 7; oct_nd = (c.M == 2 ? oct_caps > 7 : oct_caps > 2) ? 2 : 1; }
             else if (!rx->want_trace && c.M == 2 && n_sel > 3 * wenet_rx_device_info(1)) {
                 const int ncu = wenet_rx_device_info(1);
-                oct_caps = n_sel <= 4 * ncu ? 4 : (n_sel <= 7 * ncu ? 7 : 14);
-                // beyond seven captures per CU: ONE workgroup of fourteen captures with a chain wave and a sum wave (round 3) instead of two
-                // workgroups of seven with one duty wave each
-                if (oct_caps == 14) oct_nd = 2;
+                oct_caps = n_sel <= 4 * ncu ? 4 : (n_sel <= 7 * ncu ? 7 : (n_sel <= 8 * ncu ? 4 : 7));
+                // (round 3 measured workgroups with a chain wave AND a sum wave, WENET_RX_OCT_ND=2: fourteen captures + two duty waves per CU need
+                // 1 144 instead of 1 279 VALU instructions per frame but take 218 ms against 210 for 3584 captures -- the fourteen capture waves then
+                // move in lock-step and the sum wave competes with their transforms; two workgroups of six + two: 188 ms for 3072.  Not the default.)
             }
             // the 4-FSK / Ts 32 geometry (BASELINE config 4): 30 KB of LDS per capture = four captures per CU as two workgroups of two;
             // from two captures per CU on it beats the sequential kernel's one capture per CU (34 vs 11.5 Gsamples/s at 1024 captures)
@@ -1217,9 +1298,15 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const lon
         wenet_rx::ChunkEv &e = rx->cev[k];
         if (host_src) {
             for (int i = lo; i < hi; i++)
-                WR_CHECK(hipMemcpyAsync((void *)raw[i], host_src[i], (size_t)nsamples[i] * kBytesPerSample[fmt], hipMemcpyHostToDevice, rx->copy_stream), -3);
+                WR_CHECK(hipMemcpyAsync((void *)raw_in[i], host_src[i], (size_t)nsamples[i] * kBytesPerSample[fmt_in], hipMemcpyHostToDevice, rx->copy_stream), -3);
             WR_CHECK(hipEventRecord(e.copied, rx->copy_stream), -4);
             WR_CHECK(hipStreamWaitEvent(stream, e.copied, 0), -4);
+        }
+        if (quant) {
+            const dim3 grid(128, (unsigned)n);
+            if (fmt == WENET_FMT_CS16) hipLaunchKernelGGL(wenet_quantise_kernel<true>, grid, dim3(256), 0, stream, rx->d_qjobs.as<WrQuantJob>() + lo);
+            else hipLaunchKernelGGL(wenet_quantise_kernel<false>, grid, dim3(256), 0, stream, rx->d_qjobs.as<WrQuantJob>() + lo);
+            WR_CHECK(hipGetLastError(), -4);
         }
         WrDecodeArgs ak = a;
         ak.nchan = n;
@@ -1287,6 +1374,7 @@ extern "C" int wenet_rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw,
 
 extern "C" int wenet_rx_collect(wenet_rx *rx) {
     if (!rx || !rx->pending) return -1;
+    DeviceGuard dg(rx->device);
     const WrDemodCfg &c = rx->tab.cfg;
     const int nchan = rx->nchan;
     WR_CHECK(hipEventSynchronize(rx->cev[rx->nchunks - 1].ev[3]), -4);
@@ -1312,6 +1400,7 @@ extern "C" int wenet_rx_collect(wenet_rx *rx) {
 extern "C" int wenet_rx_process(wenet_rx *rx, int nchan, const void *const *raw, const long long *nsamples, int fmt,
                                 int device, void *stream) {
     if (!rx || nchan <= 0 || fmt < 0 || fmt > 3) return -1;
+    DeviceGuard dg(rx->device);
     if (device) {
         int rc = wenet_rx_enqueue(rx, nchan, raw, nsamples, fmt, stream);
         return rc < 0 ? rc : wenet_rx_collect(rx);
@@ -1444,6 +1533,7 @@ extern "C" float wenet_rx_last_ms(wenet_rx *rx, int what) {
 // enqueue when WENET_RX_PROFILE was set; returns the number of counters
 extern "C" int wenet_rx_debug_profile(wenet_rx *rx, int ch, long long *out12) {
     if (!rx || !rx->profile || ch < 0 || ch >= rx->nchan) return 0;
+    DeviceGuard dg(rx->device);
     if (hipMemcpy(out12, rx->d_prof.as<long long>() + (size_t)ch * 32, 32 * 8, hipMemcpyDeviceToHost) != hipSuccess) return 0;
     return 32;
 }

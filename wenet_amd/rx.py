@@ -38,6 +38,17 @@ class RxBatch:
     def last_kernel(self):
         return self._L.wenet_rx_last_kernel(self._h).decode()
 
+    def set_cf32_quantise(self, to_fmt):
+        """complex-float input ("cf32") is quantised on the GPU to "cu8" / "cs16" first (the csdr convert_f_u8 / convert_f_s16 stage of
+        benchmarking/test_demod.py); None: demodulate the floats as they are"""
+        code = -1 if to_fmt is None else FMT[to_fmt]
+        if self._L.wenet_rx_set_cf32_quantise(self._h, code) < 0:
+            raise ValueError(f"cf32 can be quantised to cu8 or cs16, not {to_fmt}")
+
+    def device(self):
+        """HIP device the handle lives on (the one that was current when it was created)"""
+        return int(self._L.wenet_rx_get_device(self._h))
+
     # ---- host buffers ------------------------------------------------------------------
     def process(self, captures, fmt):
         """captures: list of numpy arrays (raw samples in format fmt)."""
