@@ -125,7 +125,7 @@ def test_cf32_quantised_on_the_gpu_equals_host_quantiser(to_fmt):
     from wenet_amd import siggen
     from wenet_amd.rx import RxBatch
     cfg = siggen.config_v2()
-    caps = [siggen.make_capture(cfg, 2, 7.0 + k, seed=990 + k, fmt="cf32")[0] for k in range(3)]
+    caps = [siggen.make_capture(cfg, 4, 9.0 + k, seed=990 + k, fmt="cf32")[0] for k in range(3)]
     caps[1] = (caps[1] * np.float32(1.7)).astype(np.complex64)           # clips: the saturating branch
     caps.append(caps[0][:1001])                                           # odd length: the tail path of the kernel
     def host_q(c):
@@ -145,7 +145,10 @@ def test_cf32_quantised_on_the_gpu_equals_host_quantiser(to_fmt):
     for i in range(len(caps)):
         assert bits_equal(rx.soft(i), want[i][0]), i
         assert rx.valid_payloads(i) == want[i][1]
-    assert any(len(w[1]) for w in want)
+    # (full-scale s16 is 32.8 after the demodulator's division by FDMDV_SCALE = 1000, and the reference's LLRs are not amplitude-normalised
+    # (mpdecode_core.c:594): its decoder gives up on such hot input -- the oracle decodes nothing from these cs16 captures either.  cu8 decodes.)
+    assert to_fmt == "cs16" or any(len(w[1]) for w in want)
+    assert all(rx.npackets(i) > 0 for i in range(3))
     rx.set_cf32_quantise(None)                                            # off again: the floats are demodulated as they are
     rx.process(caps[:1], "cf32")
     sdf, _ = ol.oracle_demod(caps[0], "cf32", cfg.Fs, cfg.Rs, cfg.M)
