@@ -24,14 +24,11 @@ def _captures(cfg, seed0):
     return caps
 
 
-@pytest.mark.parametrize("name,group,nd", [("v2", 7, 1), ("v1", 7, 1), ("v2", 3, 1), ("v1", 15, 1), ("v2", 1, 1),
-                                           ("v2", 14, 2), ("v1", 14, 2), ("v2", 5, 2), ("v1", 1, 2)])
-def test_exact_mode_equals_oracle(name, group, nd, monkeypatch):
+@pytest.mark.parametrize("name,group", [("v2", 7), ("v1", 7), ("v2", 3), ("v1", 15), ("v2", 1)])
+def test_exact_mode_equals_oracle(name, group, monkeypatch):
     """Different lengths and SNRs, heavy clock errors (nin != N on many frames: the estimator run made ahead with nin = N is
-    repeated), an empty capture, a silent one; every capture equals the oracle in any slot and with any group size -- with one duty
-    wavefront per workgroup (chains and sums in turn) and with two (a chain wave and a sum wave, the chain pass straddling the barrier)."""
+    repeated), an empty capture, a silent one; every capture equals the oracle in any slot and with any group size."""
     monkeypatch.setenv("WENET_RX_OCT", str(group))
-    monkeypatch.setenv("WENET_RX_OCT_ND", str(nd))
     cfg = siggen.CONFIGS[name]()
     caps = _captures(cfg, 600)
     rx = RxBatch(cfg.Fs, cfg.Rs, cfg.M, framing=cfg.mode)
@@ -130,7 +127,9 @@ def test_large_batch_picks_the_kernel_by_itself():
 @pytest.mark.parametrize("group,nd", [(2, 1), (4, 2), (3, 2)])
 def test_exact_mode_4fsk_ts32_equals_oracle(group, nd, monkeypatch):
     """The large geometry of the batch kernel (BASELINE config 4: 4-FSK, Rs 57 600, Fs 1 843 200 -> Ts 32, 1024-point estimator, two
-    soft decisions per symbol), forced here: every capture equals the oracle bit for bit, slips and ragged ends included."""
+    soft decisions per symbol), forced here: every capture equals the oracle bit for bit, slips and ragged ends included -- with one duty
+    wavefront per workgroup (chains and sums in turn) and with two (a chain wave and a sum wave, the chain pass straddling the barrier: what
+    the library picks from three captures per CU on)."""
     monkeypatch.setenv("WENET_RX_OCT", str(group))
     monkeypatch.setenv("WENET_RX_OCT_ND", str(nd))
     cfg = siggen.config_4fsk()

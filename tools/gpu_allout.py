@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""How often the batch demodulator's mix stage parks ALL integrator outputs (and how often frames slip): usage gpu_allout.py [config] [captures] [seconds] [ebno]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from wenet_amd import siggen
+from wenet_amd.rx import RxBatch
+from wenet_amd.tx import Tx
+name = sys.argv[1] if len(sys.argv) > 1 else "4fsk"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+secs = float(sys.argv[3]) if len(sys.argv) > 3 else 2.0
+eb = float(sys.argv[4]) if len(sys.argv) > 4 else 8.0
+cfg = siggen.CONFIGS[name]()
+dev = torch.device("cuda", 0)
+nsym = int(secs * cfg.Rs); nsamp = nsym * cfg.Ts
+tx = Tx.from_config(cfg); spp = tx.symbols_per_packet; nfr = nsym // spp + 1
+payloads = torch.randint(0, 256, (B * nfr, 256), dtype=torch.uint8, device=dev)
+symbols = torch.empty(B * nfr * spp, dtype=torch.uint8, device=dev)
+tx.frame_packets_device(payloads.data_ptr(), B * nfr, symbols.data_ptr())
+caps = [torch.empty(2 * nsamp, dtype=torch.uint8, device=dev) for _ in range(B)]
+tx.modulate_device([symbols.data_ptr() + i * nfr * spp for i in range(B)], [nsym] * B, [c.data_ptr() for c in caps], eb, seeds=[7000 + i for i in range(B)])
+torch.cuda.synchronize()
+rx = RxBatch(cfg.Fs, cfg.Rs, cfg.M, framing=cfg.mode, max_iter=50 if cfg.M == 4 else 10)
+rx.enqueue_device([int(c.data_ptr()) for c in caps], [nsamp] * B, "cu8"); rx.collect()
+L = rx._L
+fr = sum(rx.frames(i) for i in range(B)); sl = sum(L.wenet_rx_channel_counter(rx._h, i, 0) for i in range(B)); ao = sum(L.wenet_rx_channel_counter(rx._h, i, 1) for i in range(B))
+print(f"{name} {B} captures x {secs} s at {eb} dB: kernel {rx.last_kernel()}, demod {rx.last_ms(0):.2f} ms, frames {fr}, slips {sl} ({sl / fr:.4f}), all-parked mix passes {ao} ({ao / fr:.4f} per frame)")

@@ -267,7 +267,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
     for (int b = 0; b < NSD; b++) sdl[b] = 0.f;
     float norm_rx_timing_st = 0.f, ppm = 0.f;
     long long off = 0, frames = 0;
-    int nslip = 0;
+    int nslip = 0, nallout = 0;
     bool alive = false;
     if (is_cap) {
         for (int i = lane; i < NH; i += 64) FE2[2 * NH + i] = present ? st_fft[i] : 0.f;   // (run-ahead: the frame before the launch's first = slot -1 % 3)
@@ -922,6 +922,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
                 if (alive) {
                     if (ready) {
                         dstage(off, nin, omask, true);
+                        nallout += omask == ALLOUT ? 1 : 0;
                         if (SMALL) prefetch_slot(off + nin, N);          // the next frame's samples, assuming nin = N (fetched again after a slip)
                     }
                     // estimator runs of this phase: after a slip E(k) with the true nin (tone search included), then -- always, unless it is done
@@ -1096,7 +1097,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
             hdr->frames_total += frames;
             hdr->frames_call = frames;
             hdr->slips_call = nslip;
-            hdr->uncertain_call = 0;
+            hdr->allout_call = nallout;
             hdr->consumed_call = off;
         }
     }

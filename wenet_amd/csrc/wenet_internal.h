@@ -127,7 +127,7 @@ struct WrChanHdr {
     float  ppm;                 // fsk.h:80
     int    nin;                 // fsk.h:83
     int    slips_call;          // frames of the last launch whose nin differed from N (pipelined kernels: speculation misses)
-    int    uncertain_call;      // (unused since the fast mode of round 2 was removed; kept so that the state layout stays)
+    int    allout_call;         // batch kernel: mix-stage passes of the last launch that parked ALL integrator outputs (first frames, slips, timing jumps, second passes)
     int    pad0;
     long long frames_total;     // frames demodulated since create
     long long frames_call;      // frames produced by the last launch

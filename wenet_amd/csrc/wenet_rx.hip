@@ -1226,22 +1226,29 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw_in, const 
             // measured (tools/gpu_batch_sweep.py, 10 s captures, 256 CUs, demod ms): the three-capture pipelined kernel takes 103 per round of 768
             // captures; workgroups of four captures 179 up to one per CU, 203 up to two per CU; workgroups of seven 195 up to one per CU,
             // 245..255 up to two per CU.  Hence: up to 3 captures per CU pipelined, then whichever workgroup size needs fewer per CU.
-            if (force) { oct_caps = atoi(force) > 0 ? atoi(force) : 7; oct_nd = (c.M == 2 ? oct_caps > 7 : oct_caps > 2) ? 2 : 1; }
+            if (force) { oct_caps = atoi(force) > 0 ? atoi(force) : 7; oct_nd = (c.M == 4 && oct_caps > 2) ? 2 : 1; }
             else if (!rx->want_trace && c.M == 2 && n_sel > 3 * wenet_rx_device_info(1)) {
                 const int ncu = wenet_rx_device_info(1);
                 oct_caps = n_sel <= 4 * ncu ? 4 : (n_sel <= 7 * ncu ? 7 : (n_sel <= 8 * ncu ? 4 : 7));
-                // (round 3 measured workgroups with a chain wave AND a sum wave, WENET_RX_OCT_ND=2: fourteen captures + two duty waves per CU need
+                // (round 3 measured workgroups with a chain wave AND a sum wave for these geometries: fourteen captures + two duty waves per CU need
                 // 1 144 instead of 1 279 VALU instructions per frame but take 218 ms against 210 for 3584 captures -- the fourteen capture waves then
-                // move in lock-step and the sum wave competes with their transforms; two workgroups of six + two: 188 ms for 3072.  Not the default.)
+                // move in lock-step and the sum wave competes with their transforms; two workgroups of six + two: 188 ms for 3072.  Not built for them.)
             }
             // the 4-FSK / Ts 32 geometry (BASELINE config 4): 30 KB of LDS per capture = four captures per CU as two workgroups of two;
             // from two captures per CU on it beats the sequential kernel's one capture per CU (34 vs 11.5 Gsamples/s at 1024 captures)
-            else if (!rx->want_trace && c.M == 4 && n_sel >= 2 * wenet_rx_device_info(1)) oct_caps = 2;
+            // (round 3: from three captures per CU on ONE workgroup of four captures with a chain wave and a sum wave: the 1 568-step chain and the
+            // 1 568-term sums are then shared by four captures and no longer wait for each other -- 72.7 against 83.4 ms per 1024 captures x 2 s)
+            // (... and below two captures per CU -- one stream alone included -- one capture per workgroup with a chain wave and a sum wave of its
+            // own: 35.5 x real time for one 10 s capture against 26.3 x through the sequential kernel)
+            else if (!rx->want_trace && c.M == 4) {
+                const int ncu = wenet_rx_device_info(1);
+                if (n_sel >= 3 * ncu) { oct_caps = 4; oct_nd = 2; } else if (n_sel >= 2 * ncu) oct_caps = 2; else { oct_caps = 1; oct_nd = 2; }
+            }
         }
         WrDemodCfg oct_cfg;
         bool use_oct = false;
         if (oct_caps > 0) {
-            if (getenv("WENET_RX_OCT_ND")) oct_nd = atoi(getenv("WENET_RX_OCT_ND")) == 2 ? 2 : 1;
+            if (getenv("WENET_RX_OCT_ND") && c.M == 4) oct_nd = atoi(getenv("WENET_RX_OCT_ND")) == 2 ? 2 : 1;
             oct_cfg = rx->tab.oct_cfg(oct_caps, oct_nd);
             use_oct = oct_cfg.o_ok != 0 && fmt == WENET_FMT_CU8;
         }
@@ -1416,6 +1423,12 @@ extern "C" int wenet_rx_process(wenet_rx *rx, int nchan, const void *const *raw,
 
 // results belong to the last COLLECTED batch: while an enqueue is pending (rx->nchan etc. already describe the batch in flight) every
 // getter refuses
+// development / diagnostics: what = 0 frames of the last launch with nin != N (timing slips), 1 mix-stage passes that parked all integrator outputs
+extern "C" long long wenet_rx_channel_counter(wenet_rx *rx, int ch, int what) {
+    if (!rx || rx->pending || ch < 0 || ch >= rx->nchan) return -1;
+    const WrChanHdr *h = (const WrChanHdr *)&rx->h_states[(size_t)ch * rx->tab.cfg.st_floats];
+    return what == 0 ? h->slips_call : (what == 1 ? h->allout_call : -1);
+}
 extern "C" long long wenet_rx_frames(wenet_rx *rx, int ch) {
     if (!rx || rx->pending || ch < 0 || ch >= rx->nchan || (size_t)(ch + 1) * rx->tab.cfg.st_floats > rx->h_states.size()) return -1;
     return ((const WrChanHdr *)&rx->h_states[(size_t)ch * rx->tab.cfg.st_floats])->frames_call;

@@ -26,7 +26,7 @@ EXPORTS = [
     "wenet_rx_create", "wenet_rx_destroy", "wenet_rx_process", "wenet_rx_enqueue", "wenet_rx_collect",
     "wenet_rx_frames", "wenet_rx_packets", "wenet_rx_get_packets", "wenet_rx_packet_census", "wenet_rx_get_soft",
     "wenet_rx_enable_trace", "wenet_rx_get_trace", "wenet_rx_enable_llr_dump", "wenet_rx_get_llrs",
-    "wenet_rx_last_ms", "wenet_rx_device_info", "wenet_rx_version", "wenet_rx_last_kernel", "wenet_rx_get_device", "wenet_rx_set_cf32_quantise",
+    "wenet_rx_last_ms", "wenet_rx_device_info", "wenet_rx_version", "wenet_rx_last_kernel", "wenet_rx_get_device", "wenet_rx_channel_counter", "wenet_rx_set_cf32_quantise",
     "wenet_packet_type_class", "wenet_ssdv_packet_info", "wenet_rx_get_packets_of_class", "wenet_rx_ssdv_images",
     "wenet_phi0_eval",
 ]
@@ -112,6 +112,7 @@ def load():
     L.wenet_rx_last_ms.restype = f; L.wenet_rx_last_ms.argtypes = [vp, i]
     L.wenet_rx_last_kernel.restype = C.c_char_p; L.wenet_rx_last_kernel.argtypes = [vp]
     L.wenet_rx_get_device.restype = i; L.wenet_rx_get_device.argtypes = [vp]
+    L.wenet_rx_channel_counter.restype = ll; L.wenet_rx_channel_counter.argtypes = [vp, i, i]
     L.wenet_rx_set_cf32_quantise.restype = i; L.wenet_rx_set_cf32_quantise.argtypes = [vp, i]
     L.wenet_packet_type_class.argtypes = [vp]
     L.wenet_ssdv_packet_info.argtypes = [vp, C.POINTER(SsdvInfo)]
