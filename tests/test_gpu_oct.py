@@ -124,7 +124,7 @@ def test_large_batch_picks_the_kernel_by_itself():
     rx.close()
 
 
-@pytest.mark.parametrize("group,nd", [(2, 1), (4, 2), (3, 2)])
+@pytest.mark.parametrize("group,nd", [(2, 1), (4, 2), (3, 2), (1, 2)])
 def test_exact_mode_4fsk_ts32_equals_oracle(group, nd, monkeypatch):
     """The large geometry of the batch kernel (BASELINE config 4: 4-FSK, Rs 57 600, Fs 1 843 200 -> Ts 32, 1024-point estimator, two
     soft decisions per symbol), forced here: every capture equals the oracle bit for bit, slips and ragged ends included -- with one duty
