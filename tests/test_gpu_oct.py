@@ -95,9 +95,9 @@ def test_rare_paths_of_the_run_ahead_schedule(group, monkeypatch):
 
 
 def test_large_batch_picks_the_kernel_by_itself():
-    """From six captures per CU on the library takes the one-wavefront-per-capture kernel for a device-resident batch without being told; the
-    same batch fed from HOST buffers goes through in sub-batches of at most three captures per CU, each launched with the kernel that fits its
-    own size (the pipelined ones).  Spot-check captures of both against the oracle."""
+    """From six captures per CU on the library takes the one-wavefront-per-capture kernel without being told -- for a device-resident batch in one
+    launch, for the same batch fed from HOST buffers once per uploaded time slice (the captures resume from their carried state).  Spot-check
+    captures of both against the oracle."""
     import torch
     from wenet_amd import lib
     ncu = lib.load().wenet_rx_device_info(1)
@@ -116,8 +116,8 @@ def test_large_batch_picks_the_kernel_by_itself():
         want[i] = (sd, ol.oracle_deframe(sd, cfg.mode))
         assert bits_equal(rx.soft(i), sd), i
         assert rx.npackets(i) == want[i][1]["n"] and (rx.packets(i)["bytes"] == want[i][1]["bytes"]).all()
-    rx.process(caps, "cu8")                                        # host-fed: more than three captures per CU -> several sub-batches
-    assert rx.last_kernel() in ("wenet_demod_tri_kernel", "wenet_demod_pipe_kernel")
+    rx.process(caps, "cu8")                                        # host-fed: the same kernel, launched once per uploaded time slice
+    assert rx.last_kernel() == "wenet_demod_oct_kernel"
     for i in picks:
         assert bits_equal(rx.soft(i), want[i][0]), i
         assert rx.npackets(i) == want[i][1]["n"] and (rx.packets(i)["bytes"] == want[i][1]["bytes"]).all()
@@ -157,4 +157,31 @@ def test_exact_mode_4fsk_ts32_equals_oracle(group, nd, monkeypatch):
             assert (p["bytes"] == ref["bytes"]).all() and (p["iter"] == ref["iter"]).all() and bits_equal(rx.llrs(i), ref["llr"])
         slips += int((tr[:, 4] != cfg.Ts * 48).sum())
     assert slips > 10
+    rx.close()
+
+
+@pytest.mark.parametrize("name,force", [("v2", "7"), ("v1", "4"), ("v2", None), ("v1", None)])
+def test_host_fed_time_slices_equal_one_launch(name, force, monkeypatch):
+    """A host-fed batch is uploaded and demodulated in time slices (rx_enqueue: every capture resumes from its carried state, the table entries are
+    moved on by a device kernel between the launches).  With slices forced short -- a few frames each, ragged captures, an empty and a silent one,
+    heavy clock errors -- every capture still equals the oracle bit for bit, through the batch kernel (forced) and through the pipelined ones."""
+    monkeypatch.setenv("WENET_RX_SLICE_SAMPLES", "9000")
+    if force:
+        monkeypatch.setenv("WENET_RX_OCT", force)
+    cfg = siggen.CONFIGS[name]()
+    caps = _captures(cfg, 820)
+    rx = RxBatch(cfg.Fs, cfg.Rs, cfg.M, framing=cfg.mode)
+    rx.enable_trace()
+    rx.process(caps, "cu8")
+    assert (rx.last_kernel() == "wenet_demod_oct_kernel") == bool(force)
+    for i, c in enumerate(caps):
+        if not c.size:
+            assert rx.frames(i) == 0 and rx.npackets(i) == 0
+            continue
+        sd, tr = ol.oracle_demod(c, "cu8", cfg.Fs, cfg.Rs, cfg.M, want_trace=True)
+        assert rx.frames(i) == tr.shape[0], i
+        assert bits_equal(rx.soft(i), sd), i
+        assert bits_equal(np.ascontiguousarray(rx.trace(i)[:, :7]), np.ascontiguousarray(tr[:, :7])), i
+        ref = ol.oracle_deframe(sd, cfg.mode)
+        assert rx.npackets(i) == ref["n"] and (rx.packets(i)["bytes"] == ref["bytes"]).all(), i
     rx.close()

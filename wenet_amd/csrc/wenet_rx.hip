@@ -1001,6 +1001,23 @@ __global__ __launch_bounds__(256) void wenet_quantise_kernel(const WrQuantJob *j
         else ((unsigned char *)j.dst)[i] = (unsigned char)quant_u8(j.src[i]);
     }
 }
+// Host-fed batches arrive in TIME slices (rx_enqueue): after the demodulator launch over a slice this kernel moves every capture's table entry on to
+// where that launch stopped -- the samples it consumed (whole frames; what is left over is demodulated with the next slice), the soft decisions
+// and trace rows it wrote, the frames it used of the cap -- and admits the samples of the next slice.  No host round trip between the launches.
+struct WrSliceInfo { const char *base; long long total; };
+__global__ __launch_bounds__(256) void wenet_advance_kernel(WrChan *chans, const WrSliceInfo *info, int nchan, long long next_end, int bps, int nbits) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nchan) return;
+    WrChan &c = chans[i];
+    const WrChanHdr *h = (const WrChanHdr *)c.state;
+    const long long done = ((const char *)c.raw - info[i].base) / bps + h->consumed_call;
+    const long long end = info[i].total < next_end ? info[i].total : next_end;
+    c.raw = info[i].base + done * bps;
+    c.nsamples = end > done ? end - done : 0;
+    c.sd_out += h->frames_call * nbits;
+    if (c.trace) c.trace += h->frames_call * WR_TRACE_FLOATS;
+    c.cap_frames -= h->frames_call;
+}
 }  // namespace
 
 // ================================================================================================
@@ -1012,7 +1029,8 @@ struct wenet_rx {
     int mode = 1, max_iter = 10, spp = 3230;
     bool want_trace = false, want_llr = false;
     int cf32_quant = -1;                                 // WENET_FMT_CU8 / WENET_FMT_CS16: complex-float input is quantised to that format first (wenet_rx_set_cf32_quantise)
-    DevBuf d_quant, d_qjobs;
+    DevBuf d_quant, d_qjobs, d_slices;
+    std::vector<hipEvent_t> slice_ev;                    // host-fed batches: one per time slice, recorded behind its uploads
     const char *last_kernel = "";                        // demod kernel of the last enqueue
     int nchan = 0, max_pk = 0;
     std::vector<long long> sd_off, cap_frames;           // per channel: float offset into d_sd, frame capacity
@@ -1067,6 +1085,7 @@ struct wenet_rx {
         if (res_stream) (void)hipStreamDestroy(res_stream);
         if (copied_all) (void)hipEventDestroy(copied_all);
         for (hipEvent_t ev : part_ev) (void)hipEventDestroy(ev);
+        for (hipEvent_t ev : slice_ev) (void)hipEventDestroy(ev);
         if (h_pin) (void)hipHostFree(h_pin);
     }
 };
@@ -1179,7 +1198,7 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw_in, const 
         WrDeframeChan &d = dch[i];
         memset(&d, 0, sizeof(d));
         d.sd = ch.sd_out;
-        d.nframes_src = (const long long *)((const char *)ch.state + offsetof(WrChanHdr, frames_call));
+        d.nframes_src = (const long long *)((const char *)ch.state + offsetof(WrChanHdr, frames_total));     // (the state is fresh: every frame of this batch, however many launches made them)
         d.nbits_per_frame = c.Nbits;
         d.state = rx->d_dstates.as<WrDeframeState>() + i;
         d.starts = rx->d_starts.as<long long>() + (size_t)i * max_pk;
@@ -1279,16 +1298,40 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw_in, const 
             WR_CHECK(hipStreamSynchronize(stream), -3);
         }
     }
-    rx->last_kernel = kernel_name(whole);                                // (host-fed: the last sub-batch's, set in the loop below)
+    rx->last_kernel = kernel_name(whole);
     // WENET_RX_PROFILE: 1 = instrumented pipelined kernel, 2 = instrumented one-wave sequential kernel, 3 = production
     // kernels with the per-channel stamp buffer attached (streamed sequential kernel: cycle stamps of one frame)
     const int prof = rx->profile ? (getenv("WENET_RX_PROFILE")[0] == '2' ? 2 : (getenv("WENET_RX_PROFILE")[0] == '3' ? 0 : 1)) : 0;
-    // host-fed: a first sub-batch of one capture per CU gets the kernels going early, then three per CU (= one full round of
-    // the demod kernel) per sub-batch; device-resident input: everything in one go
+    // Host-fed batches are cut in TIME, not by capture (round 3): a capture is a serial job -- any sub-batch of captures lasts a whole capture
+    // (>= 97 ms for 10 s), and the last one's kernels ran with nothing left to upload.  Instead every capture is uploaded in slices of about a
+    // million samples; the demodulator is launched over all captures after every slice and resumes from the carried state (bit-identical to one
+    // launch: the streaming contract of the state block), so that only the last slice's demodulation and the decode step follow the last byte.
     const int ncu = wenet_rx_device_info(1) > 0 ? wenet_rx_device_info(1) : 256;
     std::vector<int> bounds(1, 0);
-    if (host_src) { for (int b = ncu; b < nchan; b += 3 * ncu) bounds.push_back(b); }
     bounds.push_back(nchan);
+    long long max_ns = 0;
+    for (int i = 0; i < nchan; i++) max_ns = nsamples[i] > max_ns ? nsamples[i] : max_ns;
+    int nslices = 1;
+    if (host_src && !quant && getenv("WENET_RX_NO_SLICES") == nullptr) {
+        const long long want = getenv("WENET_RX_SLICE_SAMPLES") ? atoll(getenv("WENET_RX_SLICE_SAMPLES")) : 1000000;      // (tests force short slices)
+        nslices = (int)((max_ns + want - 1) / (want > 0 ? want : 1000000));
+        nslices = nslices < 1 ? 1 : (nslices > 32 ? 32 : nslices);
+    }
+    const long long slice_len = (max_ns + nslices - 1) / nslices;
+    if (nslices > 1) {
+        std::vector<WrSliceInfo> info(nchan);
+        for (int i = 0; i < nchan; i++) { info[i].base = (const char *)raw[i]; info[i].total = nsamples[i]; }
+        if (!rx->d_slices.reserve(sizeof(WrSliceInfo) * nchan)) return -2;
+        WR_CHECK(hipMemcpy(rx->d_slices.p, info.data(), sizeof(WrSliceInfo) * nchan, hipMemcpyHostToDevice), -3);
+        // the first launch sees the first slice only
+        for (int i = 0; i < nchan; i++) chans[i].nsamples = nsamples[i] < slice_len ? nsamples[i] : slice_len;
+        WR_CHECK(hipMemcpy(rx->d_chans.p, chans.data(), sizeof(WrChan) * nchan, hipMemcpyHostToDevice), -3);
+        while ((int)rx->slice_ev.size() < nslices) {
+            hipEvent_t ev = nullptr;
+            WR_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming), -4);
+            rx->slice_ev.push_back(ev);
+        }
+    }
     rx->nchunks = (int)bounds.size() - 1;
     if (!rx->chunk_events(rx->nchunks)) return -4;
     if (host_src && !rx->copy_stream) WR_CHECK(hipStreamCreateWithFlags(&rx->copy_stream, hipStreamNonBlocking), -4);
@@ -1303,11 +1346,23 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw_in, const 
     for (int k = 0; k < rx->nchunks; k++) {
         const int lo = bounds[k], hi = bounds[k + 1], n = hi - lo;
         wenet_rx::ChunkEv &e = rx->cev[k];
-        if (host_src) {
+        if (host_src && nslices == 1) {
             for (int i = lo; i < hi; i++)
                 WR_CHECK(hipMemcpyAsync((void *)raw_in[i], host_src[i], (size_t)nsamples[i] * kBytesPerSample[fmt_in], hipMemcpyHostToDevice, rx->copy_stream), -3);
             WR_CHECK(hipEventRecord(e.copied, rx->copy_stream), -4);
             WR_CHECK(hipStreamWaitEvent(stream, e.copied, 0), -4);
+        }
+        if (nslices > 1) {                                              // every upload is queued now, slice by slice, each slice with its event
+            const size_t bps = (size_t)kBytesPerSample[fmt_in];
+            for (int sl = 0; sl < nslices; sl++) {
+                for (int i = lo; i < hi; i++) {
+                    const long long a = std::min<long long>(nsamples[i], (long long)sl * slice_len), b = std::min<long long>(nsamples[i], (long long)(sl + 1) * slice_len);
+                    if (b > a) WR_CHECK(hipMemcpyAsync((char *)raw_in[i] + (size_t)a * bps, (const char *)host_src[i] + (size_t)a * bps, (size_t)(b - a) * bps,
+                                                       hipMemcpyHostToDevice, rx->copy_stream), -3);
+                }
+                WR_CHECK(hipEventRecord(rx->slice_ev[sl], rx->copy_stream), -4);
+            }
+            WR_CHECK(hipStreamWaitEvent(stream, rx->slice_ev[0], 0), -4);
         }
         if (quant) {
             const dim3 grid(128, (unsigned)n);
@@ -1326,10 +1381,7 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw_in, const 
         // A capture is a serial job, so the batch demodulator works in rounds of the captures a device holds (two workgroups per CU); what is
         // left over after the full rounds of a device-resident batch is launched as a batch of its own size -- sixteen captures through the
         // pipelined kernel take 96 ms, a nearly empty round of the batch demodulator 177.
-        // (a host-fed batch arrives in sub-batches of at most three captures per CU, each launched on its own: the kernel is chosen for the
-        // sub-batch's size, not the whole batch's -- its uploads, not the kernels, set the pace)
-        const DemodChoice sub = host_src ? choose_demod(n) : whole;
-        if (host_src && k == rx->nchunks - 1) rx->last_kernel = kernel_name(sub);
+        const DemodChoice sub = whole;
         const int round_caps = sub.use_oct ? (sub.oct_cfg.o_nd == 2 ? 1 : 2) * sub.oct_cfg.o_caps * ncu : 0;     // captures a device holds at once
         const int full = (sub.use_oct && !host_src && getenv("WENET_RX_OCT") == nullptr && round_caps > 0 && n > round_caps) ? (n / round_caps) * round_caps : n;
         if (sub.use_oct) WR_CHECK(wr_launch_demod_oct(&sub.oct_cfg, rx->d_chans.as<WrChan>() + lo, full, stream), -4);
@@ -1338,6 +1390,14 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw_in, const 
             DemodChoice rest = choose_demod(n - full);
             if (rest.use_oct) WR_CHECK(wr_launch_demod_oct(&rest.oct_cfg, rx->d_chans.as<WrChan>() + lo + full, n - full, stream), -4);
             else WR_CHECK(wr_launch_demod_ex(&rest.launch_cfg, rx->d_chans.as<WrChan>() + lo + full, n - full, stream, 0), -4);
+        }
+        for (int sl = 1; sl < nslices; sl++) {                          // the further slices: move the table entries on, wait for the slice, demodulate on
+            hipLaunchKernelGGL(wenet_advance_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, rx->d_chans.as<WrChan>() + lo, rx->d_slices.as<WrSliceInfo>() + lo,
+                               n, (long long)(sl + 1) * slice_len, kBytesPerSample[fmt_in], c.Nbits);
+            WR_CHECK(hipGetLastError(), -4);
+            WR_CHECK(hipStreamWaitEvent(stream, rx->slice_ev[sl], 0), -4);
+            if (sub.use_oct) WR_CHECK(wr_launch_demod_oct(&sub.oct_cfg, rx->d_chans.as<WrChan>() + lo, n, stream), -4);
+            else WR_CHECK(wr_launch_demod_ex(&sub.launch_cfg, rx->d_chans.as<WrChan>() + lo, n, stream, prof), -4);
         }
         WR_CHECK(hipEventRecord(e.ev[1], stream), -4);
         WR_CHECK(wr_launch_deframe(rx->d_dchans.as<WrDeframeChan>() + lo, n, rx->mode, stream), -4);
@@ -1431,7 +1491,7 @@ extern "C" long long wenet_rx_channel_counter(wenet_rx *rx, int ch, int what) {
 }
 extern "C" long long wenet_rx_frames(wenet_rx *rx, int ch) {
     if (!rx || rx->pending || ch < 0 || ch >= rx->nchan || (size_t)(ch + 1) * rx->tab.cfg.st_floats > rx->h_states.size()) return -1;
-    return ((const WrChanHdr *)&rx->h_states[(size_t)ch * rx->tab.cfg.st_floats])->frames_call;
+    return ((const WrChanHdr *)&rx->h_states[(size_t)ch * rx->tab.cfg.st_floats])->frames_total;
 }
 extern "C" long long wenet_rx_packets(wenet_rx *rx, int ch) {
     if (!rx || rx->pending || ch < 0 || ch >= rx->nchan || (size_t)ch >= rx->h_dstates.size()) return -1;
