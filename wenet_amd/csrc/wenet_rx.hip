@@ -1305,7 +1305,7 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw_in, const 
     // Host-fed batches are cut in TIME, not by capture (round 3): a capture is a serial job -- any sub-batch of captures lasts a whole capture
     // (>= 97 ms for 10 s), and the last one's kernels ran with nothing left to upload.  Instead every capture is uploaded in slices of about a
     // million samples; the demodulator is launched over all captures after every slice and resumes from the carried state (bit-identical to one
-    // launch: the streaming contract of the state block), so that only the last slice's demodulation and the decode step follow the last byte.
+    // launch: the streaming contract of the state block), so that only the last slice's demodulation and the decode step follow the last byte (768 captures x 10 s: 19.0 -> measured in DESIGN.md section 5).
     const int ncu = wenet_rx_device_info(1) > 0 ? wenet_rx_device_info(1) : 256;
     std::vector<int> bounds(1, 0);
     bounds.push_back(nchan);
@@ -1313,8 +1313,12 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw_in, const 
     for (int i = 0; i < nchan; i++) max_ns = nsamples[i] > max_ns ? nsamples[i] : max_ns;
     int nslices = 1;
     if (host_src && !quant && getenv("WENET_RX_NO_SLICES") == nullptr) {
-        const long long want = getenv("WENET_RX_SLICE_SAMPLES") ? atoll(getenv("WENET_RX_SLICE_SAMPLES")) : 1000000;      // (tests force short slices)
-        nslices = (int)((max_ns + want - 1) / (want > 0 ? want : 1000000));
+        // slices of ~2.5 M samples (a launch over a slice has a fixed cost of a few milliseconds: state in and out, the pipelines' fill), and no more
+        // (capture, slice) copies than the host can queue beside the transfers (~10 us each: measured, 35 840 copies cost 0.3 s)
+        const bool forced = getenv("WENET_RX_SLICE_SAMPLES") != nullptr;                                       // (tests force short slices)
+        const long long want = forced ? atoll(getenv("WENET_RX_SLICE_SAMPLES")) : 2500000;
+        nslices = (int)((max_ns + want - 1) / (want > 0 ? want : 2500000));
+        if (!forced && nslices > 8192 / nchan) nslices = 8192 / nchan;
         nslices = nslices < 1 ? 1 : (nslices > 32 ? 32 : nslices);
     }
     const long long slice_len = (max_ns + nslices - 1) / nslices;
