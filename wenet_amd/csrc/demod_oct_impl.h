@@ -236,6 +236,11 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
     constexpr int N = TS * WR_NSYM, Nmem = N + 2 * TS, nstash = 4 * TS, L = Nmem - 1, NI = (WR_NSYM + 1) * TS;    // fsk.c:135-160 with q = Ts / P = 1
     constexpr int NIq = (NI + 3) & ~3, NHB = (L + H - 1) / H;
     constexpr int NOUT = NI / TS;                                        // lanes that own integrator outputs (NI = (Nsym+1)*TS)
+    // Large slots (TS 32): a lane's row of power sums / timing products starts 128 bytes after its neighbour's -- every lane on the same LDS banks, an
+    // eight-way conflict on each 128-bit access of the mix stage (round 2: conflict ratio 4.0).  The 16-byte groups of a row are therefore stored
+    // swizzled: group g of lane l at group (g ^ (l & 7)) of the lane's eight; the ordered sum reads them back through the same map (constant
+    // indices there: free).
+    auto tp_group = [](int g) __attribute__((always_inline)) -> int { return TS == 32 ? ((g & ~7) | ((g & 7) ^ ((g >> 3) & 7))) : g; };
     constexpr int NE = NDFT / 64;                                        // estimator points per lane
     constexpr int NBF = NDFT / 256;                                      // radix-4 butterflies per lane and stage
 
@@ -572,7 +577,8 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
 #pragma unroll
                 for (int r4 = 0; r4 < TS / 4; r4++) {
                     const v4f p = {pw[FT1_LDS ? 4 * r4 : 0], pw[FT1_LDS ? 4 * r4 + 1 : 0], pw[FT1_LDS ? 4 * r4 + 2 : 0], pw[FT1_LDS ? 4 * r4 + 3 : 0]};
-                    T4[r4] = (m == 0) ? p : T4[r4] + p;
+                    const int gq = tp_group(8 * ln + r4) - 8 * ln;             // (T4 = the lane's row: eight groups)
+                    T4[gq] = (m == 0) ? p : T4[gq] + p;
                 }
             }
         }
@@ -581,11 +587,12 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
             for (int r = 0; r < TS; r += 2) {                        // fsk.c:870-871: the products; the duty wave adds them in order
                 // outputs r, r + 1 at once: (ft1[r] re(phi_ft[r]), ft1[r+1] re(phi_ft[r+1])) and the same with the imaginary parts -- the
                 // products of fsk.c:870-871, one packed multiply per row pair (the oscillator comes as two planes for this)
-                const v2f f2 = FT1_LDS ? *(const v2f *)(Trow + r) : ft1[FT1_LDS ? 0 : r / 2];
+                const int ro = FT1_LDS ? 4 * (tp_group(8 * ln + (r >> 2)) - 8 * ln) + (r & 3) : r;      // (swizzled position of output r in the lane's row)
+                const v2f f2 = FT1_LDS ? *(const v2f *)(Trow + ro) : ft1[FT1_LDS ? 0 : r / 2];
                 const v2f pre = *(oct_g_cf32x2 *)(pft_pl + TS * ln + r), pim = *(oct_g_cf32x2 *)(pft_pl + NIq + TS * ln + r);
                 const v2f tre = f2 * pre, tim = f2 * pim;
-                *(v2f *)(TPf + TS * ln + r) = tre;
-                *(v2f *)(TPf + NIq + TS * ln + r) = tim;
+                *(v2f *)(TPf + TS * ln + ro) = tre;
+                *(v2f *)(TPf + NIq + TS * ln + ro) = tim;
             }
         }
         wave_sync();
@@ -750,12 +757,12 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
         constexpr int NIc = (WR_NSYM + 1) * TS, NB = NIc / 16;
         v4f buf[3][4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { buf[0][u] = T4[u]; buf[1][u] = T4[4 + u]; }
+        for (int u = 0; u < 4; u++) { buf[0][u] = T4[tp_group(u)]; buf[1][u] = T4[tp_group(4 + u)]; }
 #pragma unroll
         for (int bk = 0; bk < NB; bk++) {
             if (bk + 2 < NB) {
 #pragma unroll
-                for (int u = 0; u < 4; u++) buf[(bk + 2) % 3][u] = T4[4 * (bk + 2) + u];
+                for (int u = 0; u < 4; u++) buf[(bk + 2) % 3][u] = T4[tp_group(4 * (bk + 2) + u)];
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
