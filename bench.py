@@ -135,7 +135,8 @@ def load_pmc_profile(kernel_name, inst, captures):
     from wenet_amd import codeid
     here = codeid.source_sha16()
     best = None
-    for pj in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_*.json"))):
+    # (profiles/: committed; gpurun_out/: the profile a profiling round has just written on the GPU box, before it is copied and committed)
+    for pj in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_*.json")) + glob.glob(os.path.join(ROOT, "gpurun_out", "r*_pmc_*.json"))):
         try:
             d = json.load(open(pj))
         except Exception:

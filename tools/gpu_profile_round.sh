@@ -1,11 +1,10 @@
 # One profiling round on the GPU box (outputs under gpurun_out/, to be copied into profiles/):
-#   bench line | rocprofv3 --kernel-trace --stats of the same command | PMC passes (FETCH_SIZE, WRITE_SIZE, SQ set; never with trace domains)
+#   rocprofv3 --kernel-trace --stats of the bench command | PMC passes (FETCH_SIZE, WRITE_SIZE, three SQ sets; never with trace domains) | the bench line, last
 # usage: gpu_profile_round.sh [captures] [tag] [extra bench args...]
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 B=${1:-3584}; TAG=${2:-r03}; shift; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out
-python bench.py --captures $B "$@" 2> $OUT/${TAG}_bench.err | tail -1 > $OUT/${TAG}_bench_b$B.json
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o k -- python $GRAFT_REPO_ROOT/bench.py --captures $B --steps 5 --warmup 1 --no-cpu-baseline --no-extras "$@" > $OUT/${TAG}_prof.log 2>&1
 cp $OUT/prof_$TAG/k_kernel_stats.csv $OUT/${TAG}_kernel_stats_b$B.csv
@@ -71,5 +70,8 @@ for k, d in acc.items():
 json.dump(out, open(f"{root}/{tag}_pmc_b{B}.json", "w"), indent=1)
 print(json.dumps({k[:40]: {x: v[x] for x in ("hbm_bytes_per_iq_sample", "valu_busy", "valu_util", "valu_packed_share", "lanes_active", "valu_insts_per_frame", "lds_bank_conflict_ratio", "wave_cycles_share") if x in v} for k, v in out["kernels"].items() if "demod" in k or "decode" in k}, indent=1))
 PY
+# the bench line LAST: it quotes traffic / valu from the PMC profile written just now (same sources: the stamp is checked)
+cd $GRAFT_REPO_ROOT
+python bench.py --captures $B "$@" 2> $OUT/${TAG}_bench.err | tail -1 > $OUT/${TAG}_bench_b$B.json
 head -12 $OUT/${TAG}_kernel_stats_b$B.csv | cut -c1-160
 tail -c 2500 $OUT/${TAG}_bench_b$B.json
