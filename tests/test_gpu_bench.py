@@ -35,7 +35,7 @@ def test_single_rank_line_has_the_contract_fields():
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["packets_match_gpu"] is True and cb["value"] > 0
     if cb["kind"] == "reference":
-        assert set(cb["legs"]) == {"a_stats100", "b_stats_off", "c_all_cores"}
+        assert {"a_stats100", "b_stats_off", "c_all_cores"} <= set(cb["legs"])          # (+ the half-occupancy leg and the best of the two on a many-core host)
     ow = d["other_workloads"]
     assert {"single_stream", "host_fed", "slipping_100ppm"} <= set(ow)
 
