@@ -5,20 +5,23 @@ extern "C" hipError_t wr_launch_demod_oct(const WrDemodCfg *cfg, const WrChan *d
     if (nchan <= 0) return hipSuccess;
     if (!cfg->o_ok) return hipErrorInvalidValue;
     const int groups = (nchan + cfg->o_caps - 1) / cfg->o_caps;
-    const int threads = (cfg->o_caps + cfg->o_nd) * 64;                // the capture waves + the duty wave(s)
+    const int threads = (cfg->o_caps + cfg->o_hlp + cfg->o_nd) * 64;   // the capture waves (+ the tone helpers of a single capture) + the duty wave(s)
     if (cfg->o_nd < 1 || cfg->o_nd > 2 || threads > 1024) return hipErrorInvalidValue;
-#define WO_LAUNCH(MM, TT, NN, DD)                                                                                                         \
+#define WO_LAUNCH(MM, TT, NN, DD, HH)                                                                                                         \
     do {                                                                                                                           \
-        hipError_t e = hipFuncSetAttribute((const void *)wenet_demod_oct_kernel<MM, TT, NN, DD>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+        hipError_t e = hipFuncSetAttribute((const void *)wenet_demod_oct_kernel<MM, TT, NN, DD, HH>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                            cfg->o_lds_bytes);                                                                      \
         if (e != hipSuccess) return e;                                                                                             \
-        hipLaunchKernelGGL((wenet_demod_oct_kernel<MM, TT, NN, DD>), dim3(groups), dim3(threads), cfg->o_lds_bytes, stream, *cfg, d_chans, nchan); \
+        hipLaunchKernelGGL((wenet_demod_oct_kernel<MM, TT, NN, DD, HH>), dim3(groups), dim3(threads), cfg->o_lds_bytes, stream, *cfg, d_chans, nchan); \
     } while (0)
     const bool duo = cfg->o_nd == 2;
     // (two duty waves pay for the large geometry -- 72.7 against 83.4 ms per 1024 captures x 2 s -- and cost the small ones 3 %: not instantiated there)
-    if (cfg->M == 2 && cfg->Ts == 10 && cfg->Ndft == 256)       { if (duo) return hipErrorInvalidValue; WO_LAUNCH(2, 10, 256, 1); }
-    else if (cfg->M == 2 && cfg->Ts == 8 && cfg->Ndft == 256)   { if (duo) return hipErrorInvalidValue; WO_LAUNCH(2, 8, 256, 1); }
-    else if (cfg->M == 4 && cfg->Ts == 32 && cfg->Ndft == 1024) { if (duo) WO_LAUNCH(4, 32, 1024, 2); else WO_LAUNCH(4, 32, 1024, 1); }
+    if (cfg->M == 2 && cfg->Ts == 10 && cfg->Ndft == 256)       { if (duo || cfg->o_hlp) return hipErrorInvalidValue; WO_LAUNCH(2, 10, 256, 1, false); }
+    else if (cfg->M == 2 && cfg->Ts == 8 && cfg->Ndft == 256)   { if (duo || cfg->o_hlp) return hipErrorInvalidValue; WO_LAUNCH(2, 8, 256, 1, false); }
+    else if (cfg->M == 4 && cfg->Ts == 32 && cfg->Ndft == 1024) {
+        if (cfg->o_hlp) { if (!duo || cfg->o_caps != 1 || cfg->o_hlp != 3) return hipErrorInvalidValue; WO_LAUNCH(4, 32, 1024, 2, true); }
+        else if (duo) WO_LAUNCH(4, 32, 1024, 2, false); else WO_LAUNCH(4, 32, 1024, 1, false);
+    }
     else return hipErrorInvalidValue;
 #undef WO_LAUNCH
     return hipGetLastError();

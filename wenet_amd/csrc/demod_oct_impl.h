@@ -43,7 +43,9 @@
 
 namespace {
 
-enum { OC_SELFMASK = 31 /* (capture 0's block only) ND == 2: sum wave -> chain wave, the captures whose next chain is started without waiting */,
+enum { OC_HSEQ = 32 /* HLP: capture wave -> tone helpers: iterations whose mix order is published */, OC_HCMD = 33 /* 1: mix a frame */, OC_HOFF = 34 /* [2] its first sample */,
+       OC_HNIN = 36, OC_HCK = 37 /* its checkpoint region */, OC_HDONE = 40 /* [M] helpers -> capture wave: iterations whose tone is mixed */,
+       OC_SELFMASK = 31 /* (capture 0's block only) ND == 2: sum wave -> chain wave, the captures whose next chain is started without waiting */,
        OC_NIN = 0, OC_ALIVE = 1,
        OC_SEQ = 2 /* frames whose nin, bins and alive flag are published: the duty wave starts a frame's chains on it */,
        OC_TC = 4 /* float re, im: timing sum */,
@@ -192,25 +194,27 @@ __device__ __forceinline__ float nco_steps_split(float own, float k1, float k2) 
 // table in LDS and fetch their samples a frame ahead; the large one reads three of the tables through the caches and loads its samples
 // where it uses them (the registers they would sit in are worth more than the microsecond in a 35 us frame).
 // ND = number of duty wavefronts: 1 (the chain, later the sums, on one wave) or 2 (a chain wave and a sum wave: see the frame loop)
-template <int M, int TS, int NDFT, int ND>
+// HLP: the mix stage of a workgroup's ONE capture runs on M wavefronts, a tone each (large geometry, one stream: DESIGN.md 4.2)
+template <int M, int TS, int NDFT, int ND, bool HLP>
 // (launch bounds: the LDS of the large geometry allows <= 10 wavefronts per CU anyway, so it may have 256 VGPRs)
 __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WAVES_PER_EU) void wenet_demod_oct_kernel(WrDemodCfg cfg, const WrChan *chans, int nchan) {
     static_assert(M == 2 || M == 4, "two or four tones");
     static_assert(NDFT == 256 || NDFT == 1024, "a power of four: radix-4 stages only");
     constexpr int H = TS / 2;                                            // checkpoint spacing = the unit of a timing slip
-    constexpr WoLayout LY = wo_layout(M, TS, NDFT);                // LDS carve-up (wenet_internal.h; the host fills cfg.o_* from the same function)
+    constexpr WoLayout LY = wo_layout(M, TS, NDFT, HLP);                // LDS carve-up (wenet_internal.h; the host fills cfg.o_* from the same function)
     constexpr bool SMALL = (NDFT == 256);                                // all tables in LDS, samples fetched a frame ahead
     constexpr unsigned ALLOUT = TS == 32 ? 0xffffffffu : (1u << TS) - 1u;
     constexpr int NSD = M == 2 ? 1 : 2;                                  // soft decisions per symbol (fsk.c:955-980)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int G = cfg.o_caps;                                            // captures (= capture waves) of this workgroup
-    const bool is_cap = wave < G, is_chain = wave == G, is_sum = wave == G + ND - 1;      // ND == 1: one duty wave, the chain and later the sums
+    constexpr int NHLP = HLP ? M - 1 : 0;                                // tone-helper waves (G == 1 then): wave 1 + t mixes tone 1 + t
+    const bool is_cap = wave < G, is_hlp = HLP && wave >= G && wave < G + NHLP, is_chain = wave == G + NHLP, is_sum = wave == G + NHLP + ND - 1;      // ND == 1: one duty wave, the chain and later the sums
     const int cap = is_cap ? wave : 0;
     const int ch = blockIdx.x * G + cap;
     const bool present = is_cap && ch < nchan;
     WrChan C = chans[ch < nchan ? ch : 0];
-    if (!present) { C.nsamples = 0; C.cap_frames = 0; C.sd_out = nullptr; C.trace = nullptr; }
+    if (!present && !(is_hlp && ch < nchan)) { C.nsamples = 0; C.cap_frames = 0; C.sd_out = nullptr; C.trace = nullptr; }   // (helpers read the capture's samples)
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
     unsigned char *smem = smem_all + cap * LY.stride;
@@ -221,6 +225,8 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
     float  *FW = (float *)(smem + LY.FW);                         // [Ndft/2]
     float2 *CK = (float2 *)(smem + LY.CK);                        // [M][o_nhb] phasor at the start of every half symbol
     int    *CT = (int *)(smem + LY.CT);
+    float  *PWf = (float *)(smem + LY.PW);                        // HLP: [M][NIq] per-tone power sums
+    v2f    *PKl = (v2f *)(smem + LY.PK);                          // HLP: [M][TS][64] integrator outputs
     const float2 *tw_t = (const float2 *)(smem_all + (G * LY.stride + LY.TW));
     const float  *hann_t = (const float *)(smem_all + (G * LY.stride + LY.HANN));
     const float2 *dphi_t = (const float2 *)(smem_all + (G * LY.stride + LY.DPHI));
@@ -287,6 +293,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
         alive = present && (long long)nin <= C.nsamples && C.cap_frames > 0;
         if (lane < M) CT[OC_FBIN + lane] = present ? hdr->f_bin[lane] : 0;           // bins of the frame before this launch
         if (lane == 0) { CT[OC_NIN] = nin; CT[OC_ALIVE] = alive ? 1 : 0; CT[OC_SEQ] = 0; }
+        if (HLP && lane < 16) CT[32 + lane] = 0;                         // (order / report words of the tone helpers)
     }
     // duty wave: lane 2 (M c + m) + part carries one component of phi_c[m] of capture c, in a register, across the frames (nco_steps_split)
     float own_s = 0.f;
@@ -502,6 +509,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
     oct_g_f32x2 *Fscr = (oct_g_f32x2 *)C.big;
     int ckpar = 0;                                                       // run-ahead schedule: checkpoint region of the frame in work
     unsigned omask = ALLOUT;                                     // outputs parked by the mix / integrate stage of the frame in work
+    int d_m_lo = 0, d_m_hi = M;                                          // tones dstage() works on (HLP: one per wavefront)
     float pv_r = 0.f, pv_i = 0.f;                                        // the previous frame's timing vector (0, 0: none)
     // D(j): mix, integrate, timing products
     // omask: which of the TS outputs per tone are parked (bit r); realign = false when the slot dwords were aligned by an earlier call
@@ -526,7 +534,8 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
             for (int k = 1; k < 3; k++) { fbase[k] = fbase[k - 1] + 4096u; asm volatile("" : "+v"(fbase[k])); }
         }
         auto put_out = [&](int m, int r, v2f f) __attribute__((always_inline)) {
-            if ((omask >> r) & 1) {                                      // (wave-uniform)
+            if (HLP) PKl[(m * TS + r) * 64 + ln] = f;                    // (one stream: every output stays in LDS)
+            else if ((omask >> r) & 1) {                                 // (wave-uniform)
                 if (!FT1_LDS) {
                     // value (m, r) sits 512 (m TS + r) bytes above the lane's first one: reached from three lane offsets 4 KB apart with the
                     // store's immediate offset (left to itself the compiler materialises -- and spills -- twenty addresses)
@@ -545,7 +554,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
             else pw[r] = a;                                              // (this tone's powers; added to the row after the tone, in one go)
         };
 #pragma unroll(FT1_LDS ? 1 : M)                                         // (large slots: one tone's code, run M times -- d[] alone is 2 TS registers)
-        for (int m = 0; m < M; m++) {
+        for (int m = HLP ? d_m_lo : 0; m < (HLP ? d_m_hi : M); m++) {
             v2f d[TS];
             const float2 dA2 = dphi_t[CT[OC_FBINP + m]], dB2 = dphi_t[CT[OC_FBIN + m]];
 #pragma unroll
@@ -571,6 +580,15 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
                 run = run + d[r];
             });
             put_out(m, 0, run);
+            if (HLP) {                                                   // this tone's powers into its own row: the capture wave joins the rows in tone order
+                if (ln < NOUT) {
+                    typedef float v4f __attribute__((ext_vector_type(4)));
+                    v4f *P4 = (v4f *)(PWf + m * NIq + TS * ln);
+#pragma unroll
+                    for (int r4 = 0; r4 < TS / 4; r4++)
+                        P4[tp_group(8 * ln + r4) - 8 * ln] = (v4f){pw[FT1_LDS ? 4 * r4 : 0], pw[FT1_LDS ? 4 * r4 + 1 : 0], pw[FT1_LDS ? 4 * r4 + 2 : 0], pw[FT1_LDS ? 4 * r4 + 3 : 0]};
+                }
+            } else
             if (FT1_LDS && ln < NOUT) {                                  // ft1 += this tone's powers (fsk.c:866), four outputs per LDS access
                 typedef float v4f __attribute__((ext_vector_type(4)));
                 v4f *T4 = (v4f *)Trow;
@@ -582,7 +600,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
                 }
             }
         }
-        if (ln < NOUT) {
+        if (!HLP && ln < NOUT) {
 #pragma unroll
             for (int r = 0; r < TS; r += 2) {                        // fsk.c:870-871: the products; the duty wave adds them in order
                 // outputs r, r + 1 at once: (ft1[r] re(phi_ft[r]), ft1[r+1] re(phi_ft[r+1])) and the same with the imaginary parts -- the
@@ -593,6 +611,25 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
                 const v2f tre = f2 * pre, tim = f2 * pim;
                 *(v2f *)(TPf + TS * ln + ro) = tre;
                 *(v2f *)(TPf + NIq + TS * ln + ro) = tim;
+            }
+        }
+        wave_sync();
+    };
+    // HLP: the per-tone power rows -> ft1 = ((p0 + p1) + p2) + p3 (fsk.c:866: tone order) and the timing products (fsk.c:870-871), by the capture wave once
+    // every helper has reported its tone
+    auto join_tones = [&]() __attribute__((always_inline)) {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const int ln = fresh_lane();
+        if (ln < NOUT) {
+#pragma unroll
+            for (int r4 = 0; r4 < TS / 4; r4++) {
+                const int g = tp_group(8 * ln + r4);                     // (the rows are swizzled like the timing rows)
+                v4f a = ((const v4f *)(PWf))[g];
+#pragma unroll
+                for (int m = 1; m < M; m++) a = a + ((const v4f *)(PWf + m * NIq))[g];
+                const v4f pre = *(const __attribute__((address_space(1))) v4f *)(pft_pl + TS * ln + 4 * r4), pim = *(const __attribute__((address_space(1))) v4f *)(pft_pl + NIq + TS * ln + 4 * r4);
+                ((v4f *)TPf)[g] = a * pre;
+                ((v4f *)(TPf + NIq))[g] = a * pim;
             }
         }
         wave_sync();
@@ -627,8 +664,13 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
             // program order -- and a vmcnt(0) here would wait for every store still on its way to L2)
 #pragma unroll
             for (int m = 0; m < M; m++) {
+                if (HLP) {
+                    t2a[m] = PKl[(m * TS + r_lo) * 64 + (t_low >= 0 ? 1 : 0) + ln];
+                    t2b[m] = PKl[(m * TS + r_hi) * 64 + (t_high >= 0 ? 1 : 0) + ln];
+                } else {
                 t2a[m] = (Fscr + ((m * TS + r_lo) * 64 + (t_low >= 0 ? 1 : 0)))[(unsigned)ln];     // (lane 63 has no symbol)
                 t2b[m] = (Fscr + ((m * TS + r_hi) * 64 + (t_high >= 0 ? 1 : 0)))[(unsigned)ln];
+                }
             }
         }
     };
@@ -923,12 +965,48 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
                 if (ND == 2 && is_chain) selfmask = __builtin_amdgcn_readfirstlane(CT0[OC_SELFMASK]);
                 WO_STAMP(3);
             }
+        } else if (is_hlp) {
+            // Tone helper (HLP, one capture per workgroup): mixes and integrates ONE tone of the frame the capture wave orders, into the capture's LDS
+            // (integrator outputs, the tone's power row), reports, and follows the workgroup's barriers.
+            const int tone = wave - G + 1;
+            int mask = (1 << G) - 1;
+            for (long long kf = 0;; kf++) {
+                while (__hip_atomic_load(&CT[OC_HSEQ], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (int)(kf + 1)) __builtin_amdgcn_s_sleep(1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (__builtin_amdgcn_readfirstlane(CT[OC_HCMD])) {
+                    const long long off_h = (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(CT[OC_HOFF + 1]) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(CT[OC_HOFF]));
+                    const int nin_h = __builtin_amdgcn_readfirstlane(CT[OC_HNIN]);
+                    ckpar = __builtin_amdgcn_readfirstlane(CT[OC_HCK]);
+                    d_m_lo = tone; d_m_hi = tone + 1;
+                    dstage(off_h, nin_h, ALLOUT, true);
+                    if (lane == 0) __hip_atomic_store(&CT[OC_HDONE + tone], (int)(kf + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                lds_barrier();
+                mask &= alive_mask();
+                if (!mask) break;
+                lds_barrier();
+            }
         } else {
             int mask = (1 << G) - 1;
             for (long long kf = 0;; kf++) {
+                if (HLP) {                                               // this iteration's order to the tone helpers (every iteration: they follow the barriers)
+                    if (lane == 0) {
+                        CT[OC_HCMD] = (alive && ready) ? 1 : 0; CT[OC_HOFF] = (int)(unsigned)off; CT[OC_HOFF + 1] = (int)(unsigned)((unsigned long long)off >> 32);
+                        CT[OC_HNIN] = nin; CT[OC_HCK] = ckpar;
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __hip_atomic_store(&CT[OC_HSEQ], (int)(kf + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
                 if (alive) {
                     if (ready) {
+                        if (HLP) { d_m_lo = 0; d_m_hi = 1; }             // (its own tone; the others' are on the helpers)
                         dstage(off, nin, omask, true);
+                        if (HLP) {
+                            for (int t = 1; t < M; t++)
+                                while (__hip_atomic_load(&CT[OC_HDONE + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (int)(kf + 1)) __builtin_amdgcn_s_sleep(1);
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            join_tones();
+                        }
                         nallout += omask == ALLOUT ? 1 : 0;
                         if (SMALL) prefetch_slot(off + nin, N);          // the next frame's samples, assuming nin = N (fetched again after a slip)
                     }
@@ -1037,7 +1115,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
                                 }
                             }
                             __builtin_amdgcn_s_setprio(0);
-                            omask = (!t_nan && near_prev && nn == N) ? window_mask(t_low, WO_EXTRA_OUT ? (t_fract < 0.5f ? -1 : 1) : 0) : ALLOUT;
+                            omask = (!HLP && !t_nan && near_prev && nn == N) ? window_mask(t_low, WO_EXTRA_OUT ? (t_fract < 0.5f ? -1 : 1) : 0) : ALLOUT;     // (HLP: every output is in LDS)
                             pv_r = t_nan ? 0.f : t_tcr; pv_i = t_nan ? 0.f : t_tci;
                             if (lane == 0) {                             // what the duty wave needs for its estimate of the next frame
                                 const bool fastok = more && ready && off1 + nn + N <= C.nsamples && frames + 2 < C.cap_frames;

@@ -70,6 +70,7 @@ struct WrDemodCfg {
     // batch kernel, one wavefront per capture (demod_oct_impl.h): o_caps captures per workgroup, each with an LDS block of
     // o_cap_stride bytes (o_off_FB .. o_off_CT inside it), the tables once behind the blocks; o_ok = geometry supported
     int o_ok, o_caps, o_cap_stride, o_lds_bytes, o_nhb, o_first_bins, o_ntw;
+    int o_hlp;                           // tone-helper wavefronts per capture (0, or M - 1 with one capture per workgroup): the mix stage on M waves
     int o_nd;                            // duty wavefronts per workgroup: 1 (chains and sums on one wave) or 2 (a chain wave and a sum wave)
     int o_off_FB, o_off_TP, o_off_FE, o_off_FW, o_off_CK, o_off_CT;
     int o_off_TW, o_off_HANN, o_off_SRC, o_off_DPHI, o_off_PFT, o_off_BACK;
@@ -91,9 +92,11 @@ struct WrDemodCfg {
 // W - 0.06 samples of the previous one (W = 1: four outputs; the 32-sample symbols of the 4-FSK geometry move by more than a sample per frame
 // at 8 dB: W = 3, eight of 32).
 constexpr int wo_park_halfwidth(int Ts) { return Ts >= 32 ? 3 : 1; }
-struct WoLayout { int FB, FW, TP, FE, CK, CT, stride, ntw, TW, HANN, DPHI, SRC, BACK, tab, nhb; };
+struct WoLayout { int FB, FW, TP, FE, CK, CT, PW, PK, stride, ntw, TW, HANN, DPHI, SRC, BACK, tab, nhb; };
 constexpr int wo_align16(int x) { return (x + 15) & ~15; }
-constexpr WoLayout wo_layout(int M, int Ts, int Ndft) {
+// hlp: the mix stage of ONE capture on M wavefronts (a tone each: the single-stream form of the large geometry): per-tone power rows and the
+// integrator outputs in LDS
+constexpr WoLayout wo_layout(int M, int Ts, int Ndft, bool hlp = false) {
     WoLayout y{};
     const bool small = Ndft == 256;
     const int NH = Ndft / 2, NI = 49 * Ts, NIq = (NI + 3) & ~3, H = Ts / 2, L = 50 * Ts - 1;
@@ -104,7 +107,11 @@ constexpr WoLayout wo_layout(int M, int Ts, int Ndft) {
     y.TP = t;  t = wo_align16(t + 2 * NIq * 4);
     y.FE = t;  t = wo_align16(t + 3 * NH * 4);
     y.CK = t;  t = wo_align16(t + 2 * M * y.nhb * 8);
-    y.CT = t;  t = wo_align16(t + 32 * 4);
+    y.CT = t;  t = wo_align16(t + (hlp ? 48 : 32) * 4);
+    if (hlp) {
+        y.PW = t;  t = wo_align16(t + M * NIq * 4);                  // [tone][output] power sums, joined in tone order by the capture wave
+        y.PK = t;  t = wo_align16(t + M * Ts * 64 * 8 + 64);         // [tone][output][lane] integrator outputs (instead of the global scratch block)
+    }
     y.stride = (t + 31) & ~31;
     y.ntw = 3 * Ndft / 4;                                                        // (the transform's largest twiddle index is 3 (Ndft/4 - 1))
     int tab = 0;

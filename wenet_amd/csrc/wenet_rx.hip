@@ -187,18 +187,21 @@ struct DemodTables {
     // configuration copy for the batch kernel with one wavefront per capture (demod_oct_impl.h), caps captures per workgroup;
     // o_ok == 0 in it if the geometry is not one it was written for (two tones, Ts 8 or 10 with P = Ts, one 256-point FFT per frame)
     // nd = duty wavefronts per workgroup (1: chains and sums on one wave; 2: a chain wave and a sum wave -- for workgroups that fill a CU)
-    WrDemodCfg oct_cfg(int caps, int nd = 1) const {
+    // hlp: one capture per workgroup with its mix stage on M wavefronts (large geometry, two duty waves)
+    WrDemodCfg oct_cfg(int caps, int nd = 1, bool hlp = false) const {
         WrDemodCfg c = cfg;
         c.o_ok = 0;
         if (nd < 1 || nd > 2) return c;
         c.o_nd = nd;
+        hlp = hlp && cfg.M == 4 && nd == 2 && caps == 1;
+        c.o_hlp = hlp ? cfg.M - 1 : 0;
         const bool small = cfg.M == 2 && (cfg.Ts == 8 || cfg.Ts == 10) && cfg.Ndft == 256;       // Wenet v1 / v2
         const bool large = cfg.M == 4 && cfg.Ts == 32 && cfg.Ndft == 1024;                        // BASELINE config 4 (4-FSK, Fs 1 843 200)
         if (cfg.big || !(small || large) || cfg.P != cfg.Ts || cfg.Nsym != WR_NSYM ||
             cfg.N < cfg.Ndft + cfg.Ts / 2 || cfg.N + cfg.Ts / 2 >= 2 * cfg.Ndft || getenv("WENET_RX_NO_OCT") != nullptr)
             return c;
         const int NH = cfg.Ndft / 2;
-        const WoLayout y = wo_layout(cfg.M, cfg.Ts, cfg.Ndft);     // (wenet_internal.h: the kernel uses the same function at compile time)
+        const WoLayout y = wo_layout(cfg.M, cfg.Ts, cfg.Ndft, hlp); // (wenet_internal.h: the kernel uses the same function at compile time)
         if (cfg.L != 50 * cfg.Ts - 1 || cfg.NI != 49 * cfg.Ts) return c;
         c.o_nhb = y.nhb;
         c.o_off_FB = y.FB; c.o_off_FW = y.FW; c.o_off_TP = y.TP; c.o_off_FE = y.FE; c.o_off_CK = y.CK; c.o_off_CT = y.CT;
@@ -1240,6 +1243,7 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw_in, const 
         // the CUs hold several captures each.  WENET_RX_OCT=<caps> forces it
         // (tests), WENET_RX_NO_OCT turns it off.  Traces with Eb/N0 accumulators and profiling stay with the pipelined kernels.
         int oct_caps = 0, oct_nd = 1;
+        bool oct_hlp = false;                                           // (one 4-FSK capture per workgroup, up to one per CU: its mix stage on four waves)
         if (fmt == WENET_FMT_CU8 && (!rx->profile || getenv("WENET_RX_PROFILE")[0] == '4')) {
             const char *force = getenv("WENET_RX_OCT");
             // measured (tools/gpu_batch_sweep.py, 10 s captures, 256 CUs, demod ms): the three-capture pipelined kernel takes 103 per round of 768
@@ -1261,14 +1265,15 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw_in, const 
             // own: 35.5 x real time for one 10 s capture against 26.3 x through the sequential kernel)
             else if (!rx->want_trace && c.M == 4) {
                 const int ncu = wenet_rx_device_info(1);
-                if (n_sel >= 3 * ncu) { oct_caps = 4; oct_nd = 2; } else if (n_sel >= 2 * ncu) oct_caps = 2; else { oct_caps = 1; oct_nd = 2; }
+                if (n_sel >= 3 * ncu) { oct_caps = 4; oct_nd = 2; } else if (n_sel >= 2 * ncu) oct_caps = 2; else { oct_caps = 1; oct_nd = 2; oct_hlp = n_sel <= ncu; }
             }
         }
         WrDemodCfg oct_cfg;
         bool use_oct = false;
         if (oct_caps > 0) {
             if (getenv("WENET_RX_OCT_ND") && c.M == 4) oct_nd = atoi(getenv("WENET_RX_OCT_ND")) == 2 ? 2 : 1;
-            oct_cfg = rx->tab.oct_cfg(oct_caps, oct_nd);
+            if (getenv("WENET_RX_OCT_HLP")) oct_hlp = atoi(getenv("WENET_RX_OCT_HLP")) != 0;
+            oct_cfg = rx->tab.oct_cfg(oct_caps, oct_nd, oct_hlp);
             use_oct = oct_cfg.o_ok != 0 && fmt == WENET_FMT_CU8;
         }
         launch_cfg.p_tsum_split = getenv("WENET_RX_TSUM_SPLIT") ? atoi(getenv("WENET_RX_TSUM_SPLIT")) : ((n_sel > wenet_rx_device_info(1)) ? 1 : 0);
