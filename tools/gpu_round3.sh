@@ -20,7 +20,10 @@ done
   WENET_RX_SLICE_SAMPLES=50000 python tools/soak.py 200 33 2>&1 | tail -2
   echo "## 4-FSK Ts 32: four captures + chain wave + sum wave per workgroup; one capture + two duty waves"
   WENET_RX_OCT=4 WENET_RX_OCT_ND=2 python tools/soak.py 120 34 4fsk 2>&1 | tail -2
-  WENET_RX_OCT=1 WENET_RX_OCT_ND=2 WENET_RX_SLICE_SAMPLES=200000 python tools/soak.py 60 35 4fsk 2>&1 | tail -2
+  WENET_RX_OCT=1 WENET_RX_OCT_ND=2 WENET_RX_OCT_HLP=0 WENET_RX_SLICE_SAMPLES=200000 python tools/soak.py 60 35 4fsk 2>&1 | tail -2
+  echo "## 4-FSK Ts 32: one capture + three tone helpers + two duty waves (the single-stream form)"
+  WENET_RX_OCT=1 WENET_RX_OCT_ND=2 WENET_RX_OCT_HLP=1 WENET_RX_SLICE_SAMPLES=300000 python tools/soak.py 80 36 4fsk 2>&1 | tail -2
+  WENET_RX_OCT=1 WENET_RX_OCT_ND=2 WENET_RX_OCT_HLP=1 WENET_RX_NO_SLICES=1 python tools/soak.py 40 37 4fsk 2>&1 | tail -2
   echo "## captures of 0..6 frames"
   WENET_RX_OCT=7 python tools/soak_short.py 2>&1 | tail -1
 } > gpurun_out/r03_soak.txt 2>&1

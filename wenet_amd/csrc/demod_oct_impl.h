@@ -44,7 +44,8 @@
 namespace {
 
 enum { OC_HSEQ = 32 /* HLP: capture wave -> tone helpers: iterations whose mix order is published */, OC_HCMD = 33 /* 1: mix a frame */, OC_HOFF = 34 /* [2] its first sample */,
-       OC_HNIN = 36, OC_HCK = 37 /* its checkpoint region */, OC_HDONE = 40 /* [M] helpers -> capture wave: iterations whose tone is mixed */,
+       OC_HNIN = 36, OC_HCK = 37 /* its checkpoint region */, OC_HDONE = 40 /* [M] helpers -> capture wave: iterations whose tone is mixed */, OC_HEOFF = 38 /* [2] first sample of the window the shared FFT transforms */,
+       OC_HFFT = 44 /* arrivals at the shared FFT's stage meetings */,
        OC_SELFMASK = 31 /* (capture 0's block only) ND == 2: sum wave -> chain wave, the captures whose next chain is started without waiting */,
        OC_NIN = 0, OC_ALIVE = 1,
        OC_SEQ = 2 /* frames whose nin, bins and alive flag are published: the duty wave starts a frame's chains on it */,
@@ -389,11 +390,26 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
         o1 = make_float2(s5.x + s4.y, s5.y - s4.x);
         o3 = make_float2(s5.x - s4.y, s5.y + s4.x);
     };
+    // (HLP: the transform of one capture spread over its M mix wavefronts -- wave w takes butterfly ln + 64 w of every stage; between the stages the
+    // waves meet at a counter in LDS, fft_meet)
+    int fft_jb_lo = 0, fft_jb_hi = NBF, fft_epoch = 0;
+    bool fft_shared = false;
+    auto fft_meet = [&](int stage) __attribute__((always_inline)) {
+        wave_sync();
+        if (HLP && fft_shared) {
+            constexpr int NSTG = NDFT == 256 ? 4 : 5;
+            const int target = (fft_epoch * NSTG + stage + 1) * M;
+            if (lane == 0) __hip_atomic_fetch_add(&CT[OC_HFFT], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            while (__hip_atomic_load(&CT[OC_HFFT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    };
     auto estimate_fft = [&](int nin_j) __attribute__((always_inline)) {
         const int fft_samps = nin_j - Ndft;                              // fsk.c:583-584 with fft_loops == 1
         const int ln = fresh_lane();
+        const int jb_lo = (HLP && fft_shared) ? fft_jb_lo : 0, jb_hi = (HLP && fft_shared) ? fft_jb_hi : NBF;
 #pragma unroll(NBF > 2 ? 1 : NBF)                                       // (large transform: one butterfly at a time -- more in flight spill)
-        for (int jb = 0; jb < NBF; jb++) {                               // first stage (m = 1) straight from the window, butterfly bf = ln + 64 jb
+        for (int jb = jb_lo; jb < jb_hi; jb++) {                         // first stage (m = 1) straight from the window, butterfly bf = ln + 64 jb
             const int bf = ln + 64 * jb;
             float2 v[4];
 #pragma unroll
@@ -412,13 +428,13 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
             F4[0] = make_float4(o0.x, o0.y, o1.x, o1.y);
             F4[1] = make_float4(o2.x, o2.y, o3.x, o3.y);
         }
-        wave_sync();
+        fft_meet(0);
         constexpr int NST = NDFT == 256 ? 4 : 5;                         // radix-4 stages
 #pragma unroll
         for (int st = 1; st < NST - 1; st++) {                           // m = 4, 16, (64): fstride = Ndft / (4 m)
             const int lgm = 2 * st, m = 1 << lgm, fs = NDFT >> (lgm + 2);
 #pragma unroll(NBF > 2 ? 1 : NBF)
-            for (int jb = 0; jb < NBF; jb++) {
+            for (int jb = jb_lo; jb < jb_hi; jb++) {
                 const int bf = ln + 64 * jb;
                 const int blk = bf >> lgm, k = bf & (m - 1);
                 float2 *F = FB + blk * m * 4 + k;
@@ -429,12 +445,12 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
                 bfly4(F[0], s0, s1, s2, o0, o1, o2, o3);
                 F[0] = o0; F[m] = o1; F[2 * m] = o2; F[3 * m] = o3;
             }
-            wave_sync();
+            fft_meet(st);
         }
         {                                                                // last stage, m = Ndft / 4, fstride 1: outputs 0 .. Ndft/2 - 1 only
             constexpr int m = NDFT / 4;
 #pragma unroll(NBF > 2 ? 1 : NBF)
-            for (int jb = 0; jb < NBF; jb++) {
+            for (int jb = jb_lo; jb < jb_hi; jb++) {
                 const int k = ln + 64 * jb;
                 float2 *F = FB + k;
                 const float2 s0 = cmul_f2(F[m], tw_t[k]);
@@ -444,8 +460,9 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
                 bfly4(F[0], s0, s1, s2, o0, o1, o2, o3);
                 F[0] = o0; F[m] = o1;
             }
-            wave_sync();
+            fft_meet(NST - 1);
         }
+        if (HLP && fft_shared) fft_epoch++;
     };
     auto estimate_pick_to = [&](int slot_in, int slot_out, int *bins_out) __attribute__((always_inline)) {
         const float *FEin = FE2 + slot_in * NH;
@@ -722,7 +739,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
     // A pass is written in two parts so that, with a chain wave of its own (ND == 2), it can straddle the workgroup barrier: part 1 = set-up, the
     // blocks around the switch to this frame's estimate and the first CH_TRIPS1 trips of eight checkpoints, part 2 = the rest.  What lives
     // across the parts (ch_*) stays in the chain wave's registers.
-    constexpr int CH_FULL = L / H, CH_TRIPS = (CH_FULL - 5) / 8, CH_TRIPS1 = ND == 2 ? CH_TRIPS * 11 / 20 : CH_TRIPS;
+    constexpr int CH_FULL = L / H, CH_TRIPS = (CH_FULL - 5) / 8, CH_TRIPS1 = ND == 2 ? CH_TRIPS * (HLP ? 14 : 11) / 20 : CH_TRIPS;      // (HLP: the mix waves' phase A also holds the shared FFT: more of the chain beside it)
     float ch_k1 = 0.f, ch_k2 = 0.f;
     float *ch_ck = nullptr;
     int ch_hb = 0;
@@ -973,13 +990,19 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
             for (long long kf = 0;; kf++) {
                 while (__hip_atomic_load(&CT[OC_HSEQ], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (int)(kf + 1)) __builtin_amdgcn_s_sleep(1);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (__builtin_amdgcn_readfirstlane(CT[OC_HCMD])) {
+                const int hcmd = __builtin_amdgcn_readfirstlane(CT[OC_HCMD]);
+                if (hcmd & 1) {
                     const long long off_h = (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(CT[OC_HOFF + 1]) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(CT[OC_HOFF]));
                     const int nin_h = __builtin_amdgcn_readfirstlane(CT[OC_HNIN]);
                     ckpar = __builtin_amdgcn_readfirstlane(CT[OC_HCK]);
                     d_m_lo = tone; d_m_hi = tone + 1;
                     dstage(off_h, nin_h, ALLOUT, true);
                     if (lane == 0) __hip_atomic_store(&CT[OC_HDONE + tone], (int)(kf + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                if (hcmd & 2) {                                          // this wave's quarter of the run-ahead FFT (every window before it taken as N samples long)
+                    est_off = (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(CT[OC_HEOFF + 1]) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(CT[OC_HEOFF]));
+                    fft_shared = true; fft_jb_lo = tone; fft_jb_hi = tone + 1;
+                    estimate_fft(N);
                 }
                 lds_barrier();
                 mask &= alive_mask();
@@ -989,10 +1012,12 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
         } else {
             int mask = (1 << G) - 1;
             for (long long kf = 0;; kf++) {
+                bool fft_in_a = false;                                   // HLP: the run-ahead FFT was done in phase A, by the four mix waves together
                 if (HLP) {                                               // this iteration's order to the tone helpers (every iteration: they follow the barriers)
                     if (lane == 0) {
-                        CT[OC_HCMD] = (alive && ready) ? 1 : 0; CT[OC_HOFF] = (int)(unsigned)off; CT[OC_HOFF + 1] = (int)(unsigned)((unsigned long long)off >> 32);
+                        CT[OC_HCMD] = (alive && ready) ? (1 | (redo_d ? 0 : 2)) : 0; CT[OC_HOFF] = (int)(unsigned)off; CT[OC_HOFF + 1] = (int)(unsigned)((unsigned long long)off >> 32);
                         CT[OC_HNIN] = nin; CT[OC_HCK] = ckpar;
+                        CT[OC_HEOFF] = (int)(unsigned)est_off; CT[OC_HEOFF + 1] = (int)(unsigned)((unsigned long long)est_off >> 32);
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         __hip_atomic_store(&CT[OC_HSEQ], (int)(kf + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
@@ -1006,6 +1031,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
                                 while (__hip_atomic_load(&CT[OC_HDONE + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (int)(kf + 1)) __builtin_amdgcn_s_sleep(1);
                             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                             join_tones();
+                            if (!redo_d) { fft_shared = true; fft_jb_lo = 0; fft_jb_hi = 1; estimate_fft(N); fft_shared = false; fft_in_a = true; }   // its quarter of the run-ahead FFT
                         }
                         nallout += omask == ALLOUT ? 1 : 0;
                         if (SMALL) prefetch_slot(off + nin, N);          // the next frame's samples, assuming nin = N (fetched again after a slip)
@@ -1026,7 +1052,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
                 if (!mask) break;
                 if (alive) {
                     const bool ran_fft = ready ? !redo_d : !en_valid;
-                    if (ND == 2 && ran_fft) estimate_fft(N);
+                    if (ND == 2 && ran_fft && !fft_in_a) estimate_fft(N);
                     if (ran_fft) {
                         int fb[M];
                         const int si = ready ? (sw + 1) % 3 : sw;
