@@ -44,9 +44,10 @@ for ch in range(0, B, int(caps)):
     n = L.wenet_rx_debug_profile(rx._h, ch, buf)
     v = list(buf)
     fr = max(v[6], 1)
-    print(f"group@{ch}: frames {v[6]}; per frame: wave 0: decide+E-ahead+wait {v[0] / fr:.0f} (busy {v[4] / fr:.0f}), mix/integ {v[1] / fr:.0f}, wait sums {v[2] / fr:.0f}"
-          f" [T1 to publish {v[3] / fr:.0f}, +T2+prefetch {(v[5] - v[3]) / fr:.0f}, +FFT ahead {(v[4] - v[5]) / fr:.0f}]"
-          f" | duty/chain wave: wait requests {v[8] / fr:.0f}, chain part 1 {v[9] / fr:.0f}, barrier 1 {v[10] / fr:.0f}, chain part 2 {v[12] / fr:.0f}, sums {v[13] / fr:.0f}, barrier 2 {v[11] / fr:.0f}"
-          f" | sum wave (ND 2): to barrier 1 {v[18] / fr:.0f}, sums + estimates {v[21] / fr:.0f}, barrier 2 {v[19] / fr:.0f} | total/frame {sum(v[8:14]) / fr:.0f}")
+    print(f"group@{ch}: frames {v[6]}; cycles per frame -- capture wave 0: phase C end -> products written (mix / integrate) {v[0] / fr:.0f}, -> barrier (FFT ahead, tone search, wait) {v[1] / fr:.0f}, "
+          f"phase C (decisions, bookkeeping) {v[2] / fr:.0f} [fine build: orders read {v[3] / fr:.0f}, +loads issued, requests {(v[4] - v[3]) / fr:.0f}, +decisions {(v[5] - v[4]) / fr:.0f}]"
+          f" | duty / chain wave: wait requests {v[8] / fr:.0f}, chain (part 1) {v[9] / fr:.0f}, wait products (ND 2: barrier 1) {v[10] / fr:.0f}, chain part 2 {v[12] / fr:.0f}, sums + estimates {v[13] / fr:.0f}, barrier 2 {v[11] / fr:.0f}"
+          f" | sum wave (ND 2): to barrier 1 {v[18] / fr:.0f}, sums + estimates {v[21] / fr:.0f}, barrier 2 {v[19] / fr:.0f} | duty total / frame {sum(v[8:14]) / fr:.0f}"
+          f" | fine build, wave 0 sections: slot fetch/align {v[24] / fr:.0f}, tones (mix + window sums) {v[25] / fr:.0f}, timing products {v[26] / fr:.0f}, next slot fetch {v[27] / fr:.0f}, FFT {v[28] / fr:.0f}, tone search {v[29] / fr:.0f}")
     if ch >= 3 * int(caps):
         break

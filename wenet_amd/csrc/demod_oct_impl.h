@@ -47,7 +47,10 @@ enum { OC_HSEQ = 32 /* HLP: capture wave -> tone helpers: iterations whose mix o
        OC_HNIN = 36, OC_HCK = 37 /* its checkpoint region */, OC_HDONE = 40 /* [M] helpers -> capture wave: iterations whose tone is mixed */, OC_HEOFF = 38 /* [2] first sample of the window the shared FFT transforms */,
        OC_HFFT = 44 /* arrivals at the shared FFT's stage meetings */,
        OC_SELFMASK = 31 /* (capture 0's block only) ND == 2: sum wave -> chain wave, the captures whose next chain is started without waiting */,
-       OC_NIN = 0, OC_ALIVE = 1,
+       OC_PRDY = 31 /* ND == 1: capture wave -> duty wave: iterations whose timing products (if the capture mixed a frame) are in their rows */,
+       OC_DUTY = 0 /* (capture 0's block only) ND == 1: duty wave -> capture waves, once per iteration when the chains are done and every capture wave has
+                      reported (OC_PRDY): (iteration + 1) << 16 | captures still alive -- the request words may be rewritten; the loop ends when none is left */,
+       OC_ALIVE = 1,
        OC_SEQ = 2 /* frames whose nin, bins and alive flag are published: the duty wave starts a frame's chains on it */,
        OC_TC = 4 /* float re, im: timing sum */,
        OC_FBIN = 8 /* [4] tone bins of this frame */, OC_FBINP = 12 /* [4] previous frame's, first-run rule applied (fsk.c:750-753) */,
@@ -293,7 +296,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
         }
         alive = present && (long long)nin <= C.nsamples && C.cap_frames > 0;
         if (lane < M) CT[OC_FBIN + lane] = present ? hdr->f_bin[lane] : 0;           // bins of the frame before this launch
-        if (lane == 0) { CT[OC_NIN] = nin; CT[OC_ALIVE] = alive ? 1 : 0; CT[OC_SEQ] = 0; }
+        if (lane == 0) { CT[OC_DUTY] = 0; CT[OC_ALIVE] = alive ? 1 : 0; CT[OC_SEQ] = 0; CT[OC_PRDY] = 0; }
         if (HLP && lane < 16) CT[32 + lane] = 0;                         // (order / report words of the tone helpers)
     }
     // duty wave: lane 2 (M c + m) + part carries one component of phi_c[m] of capture c, in a register, across the frames (nco_steps_split)
@@ -528,6 +531,15 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
     unsigned omask = ALLOUT;                                     // outputs parked by the mix / integrate stage of the frame in work
     int d_m_lo = 0, d_m_hi = M;                                          // tones dstage() works on (HLP: one per wavefront)
     float pv_r = 0.f, pv_i = 0.f;                                        // the previous frame's timing vector (0, 0: none)
+#ifdef WR_PROF_FINE                                                      // (make PROF=1 EXTRA=-DWR_PROF_FINE: every stamp drains the wave's LDS / scalar-memory queue -- the finer, the slower)
+    long long pf[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tf = 0;                  // fine stamps of capture wave 0 (sections of phases A and B)
+    const bool pfn = C.prof != nullptr && lane == 0 && wave == 0 && is_cap;
+#define WO_FINE0() do { if (pfn) tf = (long long)__builtin_readcyclecounter(); } while (0)
+#define WO_FINE(k) do { if (pfn) { const long long t1f = (long long)__builtin_readcyclecounter(); pf[k] += t1f - tf; tf = t1f; } } while (0)
+#else
+#define WO_FINE0() do { } while (0)
+#define WO_FINE(k) do { } while (0)
+#endif
     // D(j): mix, integrate, timing products
     // omask: which of the TS outputs per tone are parked (bit r); realign = false when the slot dwords were aligned by an earlier call
     auto dstage = [&](long long off_j, int nin_j, unsigned omask_j, bool realign) __attribute__((always_inline)) {
@@ -543,6 +555,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
 #pragma unroll
             for (int u = 0; u < TS; u++) xs[SMALL ? 0 : u] = slot_sample(u);
         }
+        WO_FINE(0);
         float *Trow = TPf + TS * ln;
         unsigned fbase[3];                                               // byte offsets of the lane's values from the scratch block, 4 KB apart
         if (!FT1_LDS) {
@@ -617,6 +630,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
                 }
             }
         }
+        WO_FINE(1);
         if (!HLP && ln < NOUT) {
 #pragma unroll
             for (int r = 0; r < TS; r += 2) {                        // fsk.c:870-871: the products; the duty wave adds them in order
@@ -631,6 +645,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
             }
         }
         wave_sync();
+        WO_FINE(2);
     };
     // HLP: the per-tone power rows -> ft1 = ((p0 + p1) + p2) + p3 (fsk.c:866: tone order) and the timing products (fsk.c:870-871), by the capture wave once
     // every helper has reported its tone
@@ -671,7 +686,10 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
         return (unsigned)((pat | (pat >> TS)) & ALLOUT);
     };
     v2f t2a[M], t2b[M];                                                  // the parked outputs the frame's symbols are resampled from
-    auto tstage2_load = [&]() __attribute__((always_inline)) {
+    auto tstage2_load = [&](const oct_g_f32x2 *Fscr, int t_low, int t_high, bool t_nan) __attribute__((always_inline)) {
+#ifdef WO_DBG_NODEC                                                      // (timing experiments only: no decisions at all)
+        return;
+#endif
         if (!t_nan) {
             const int ln = fresh_lane();
             // symbol `lane` is resampled between f_int[.][(lane+1)*P + low_sample] and [.. + high_sample]: for an offset o >= 0
@@ -691,7 +709,10 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
             }
         }
     };
-    auto tstage2_finish = [&](long long fr) __attribute__((always_inline)) {
+    auto tstage2_finish = [&](long long fr, float t_fract, bool t_nan) __attribute__((always_inline)) {
+#ifdef WO_DBG_NODEC
+        return;
+#endif
         if (!t_nan) {
             const float fract = t_fract, omf = 1 - fract;
             float tmax[M];
@@ -720,6 +741,8 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
             if (NSD == 1) ((oct_g_f32 *)C.sd_out + fr * WR_NSYM)[(unsigned)lane] = sdl[0];
             else ((oct_g_f32x2 *)C.sd_out + fr * WR_NSYM)[(unsigned)lane] = (v2f){sdl[0], sdl[NSD - 1]};
         }
+    };
+    auto trace_write = [&](long long fr) __attribute__((always_inline)) {
         if (C.trace && lane == 0) {
             float *tr = C.trace + fr * WR_TRACE_FLOATS;
 #pragma unroll
@@ -864,13 +887,18 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
         //            are compared with the result, and the chain is requested again if they differ (at launch start there is no guess: always)
         //   en_valid the next frame's estimator run is done already (the iteration after such a second request)
         //   redo_d   (ready) the parked integrator outputs did not cover the resampling points: mix the frame again, parking everything
+        // (G <= 15 captures per workgroup: OC_DUTY carries their alive mask in sixteen bits)
         if (is_chain) __builtin_amdgcn_s_setprio(2);
 #ifdef WR_WITH_PROF
         const bool pp = C.prof != nullptr && lane == 0 && (wave == 0 || is_chain || is_sum);
         long long *pr = C.prof + (is_chain ? 8 : (is_sum ? 16 : 0));     // (ND == 2: wave 0 | chain wave | sum wave)
         long long pt[6] = {0, 0, 0, 0, 0, 0}, t0 = pp ? (long long)__builtin_readcyclecounter() : 0;
 #define WO_STAMP(k) do { if (pp) { const long long t1 = (long long)__builtin_readcyclecounter(); pt[k] += t1 - t0; t0 = t1; } } while (0)
+#ifdef WR_PROF_FINE
 #define WO_SUB(k) do { if (pp) { const long long t1 = (long long)__builtin_readcyclecounter(); pt[k] += t1 - t0; } } while (0)   /* since the last WO_STAMP */
+#else
+#define WO_SUB(k) do { } while (0)
+#endif
 #else
 #define WO_STAMP(k) do { } while (0)
 #define WO_SUB(k) do { } while (0)
@@ -891,7 +919,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
         auto request = [&](int kind, int nin_c, const int *bc, const int *pv, int region, bool more, long long seq) __attribute__((always_inline)) {
             if (lane == 0) {
                 const bool first = pv[0] < cfg.o_first_bins;
-                CT[OC_REQ] = kind; CT[OC_CNIN] = nin_c; CT[OC_CREG] = region; CT[OC_ALIVE] = more ? 1 : 0; CT[OC_NIN] = nin_c;
+                CT[OC_REQ] = kind; CT[OC_CNIN] = nin_c; CT[OC_CREG] = region; CT[OC_ALIVE] = more ? 1 : 0;
 #pragma unroll
                 for (int m = 0; m < M; m++) { CT[OC_CBC + m] = bc[m]; CT[OC_CBP + m] = first ? bc[m] : pv[m]; }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -933,18 +961,32 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
                     if (m2) { chain_part1(m2); ran |= m2; if (ND == 1) chain_part2(); }
                     WO_STAMP(1);
                 }
-                lds_barrier();                                           // timing products of the frames in work; (ND == 1) checkpoints of the requested chains
-                WO_STAMP(2);
-                if (ND == 2 && is_chain) chain_part2();                  // (its checkpoints are read after the second barrier)
-                WO_STAMP(4);
-                mask &= alive_mask();
-                if (!mask) break;
+                if (ND == 2) {
+                    lds_barrier();                                       // timing products of the frames in work
+                    WO_STAMP(2);
+                    if (is_chain) chain_part2();                         // (its checkpoints are read after the second barrier)
+                    WO_STAMP(4);
+                    mask &= alive_mask();
+                    if (!mask) break;
+                } else {
+                    // ND == 1: no barrier here.  The capture waves go on with the run-ahead FFT and the tone search as soon as their timing products are
+                    // written; this wave, done with the chains, takes the sums up as soon as every capture has said so (a word per capture, like the
+                    // requests) -- the sums run beside the transforms instead of after them.
+                    // Every capture wave reports every iteration; once all have, their last phase C is over: who is still alive is known, and this
+                    // wave has read the request words -- both said in one word (the waves read the mask after the barrier, all the same value).
+                    for (int c = 0; c < G; c++)
+                        while (__hip_atomic_load((int *)&CT0[c * ctw + OC_PRDY], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (int)(kf + 1)) __builtin_amdgcn_s_sleep(1);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    mask &= alive_mask();
+                    if (lane == 0) __hip_atomic_store((int *)&CT0[OC_DUTY], (int)((((unsigned)kf + 1u) << 16) | (unsigned)mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    WO_STAMP(2);
+                }
                 // The sums, and straight away the timing estimate of every capture (one lane each: atan2f, the double division, nin -- once
                 // per workgroup instead of once per capture wave).  If nin stays N and the capture said beforehand that it then has another
                 // frame and that its parked outputs are sure to cover the resampling points (all parked, or the timing vector near the
                 // previous one), its next request can only be the speculative chain it wrote down in phase B: the chain is started
                 // without waiting for the capture wave.
-                if (is_sum) {
+                if (is_sum && (ND == 2 || mask)) {
                     const float acc = tsum(mask);
                     const float oth = __shfl_xor(acc, 1, 64);
                     bool self = false;
@@ -978,9 +1020,10 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
                     if (ND == 2 && lane == 0) ((int *)smem_all)[LY.CT / 4 + OC_SELFMASK] = selfmask;
                 }
                 WO_STAMP(5);
-                lds_barrier();                                           // timing sums
+                lds_barrier();                                           // timing sums; (ND == 1) checkpoints of the requested chains
                 if (ND == 2 && is_chain) selfmask = __builtin_amdgcn_readfirstlane(CT0[OC_SELFMASK]);
                 WO_STAMP(3);
+                if (ND == 1 && !mask) break;                             // (every wave reads the same mask after this barrier)
             }
         } else if (is_hlp) {
             // Tone helper (HLP, one capture per workgroup): mixes and integrates ONE tone of the frame the capture wave orders, into the capture's LDS
@@ -1025,6 +1068,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
                 if (alive) {
                     if (ready) {
                         if (HLP) { d_m_lo = 0; d_m_hi = 1; }             // (its own tone; the others' are on the helpers)
+                        WO_FINE0();
                         dstage(off, nin, omask, true);
                         if (HLP) {
                             for (int t = 1; t < M; t++)
@@ -1035,7 +1079,17 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
                         }
                         nallout += omask == ALLOUT ? 1 : 0;
                         if (SMALL) prefetch_slot(off + nin, N);          // the next frame's samples, assuming nin = N (fetched again after a slip)
+                        WO_FINE(3);
                     }
+                }
+                if (ND == 1) {                                           // the frame's timing products are in their rows (every iteration, mixed or not: the duty wave waits for the word)
+                    if (lane == 0) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __hip_atomic_store(&CT[OC_PRDY], (int)(kf + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    WO_STAMP(0);
+                }
+                if (alive) {
                     // estimator runs of this phase: after a slip E(k) with the true nin (tone search included), then -- always, unless it is done
                     // already -- the FFT of the newest frame the schedule looks at, assuming it (and the frames before it) have nin = N
                     // (ND == 2: that FFT runs in phase B, beside the sum wave's ordered sums -- the chain no longer has to be covered by phase A)
@@ -1045,11 +1099,15 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
                         if (e == 0) { estimate_pick_to((sw + 2) % 3, sw, b_w); prefetch_est(off + nin); }
                         // (the samples of the run after it are fetched at the end of phase B)
                     }
+                    WO_FINE(4);
                 }
-                lds_barrier();
-                WO_STAMP(0);
-                mask &= alive_mask();
-                if (!mask) break;
+                if (ND == 2) {
+                    lds_barrier();
+                    WO_STAMP(0);
+                    mask &= alive_mask();
+                    if (!mask) break;
+                }
+                WO_FINE0();
                 if (alive) {
                     const bool ran_fft = ready ? !redo_d : !en_valid;
                     if (ND == 2 && ran_fft && !fft_in_a) estimate_fft(N);
@@ -1059,6 +1117,9 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
                         estimate_pick_to(si, (si + 1) % 3, fb);
 #pragma unroll
                         for (int m = 0; m < M; m++) { if (ready) b_nn[m] = fb[m]; else b_n[m] = fb[m]; }
+                        if (ND == 1 && ready) {                          // (the duty wave has read this iteration's request words: it says so once per iteration)
+                            while (((unsigned)__hip_atomic_load((int *)&CT0[OC_DUTY], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 16) != (((unsigned)kf + 1u) & 0xffffu)) __builtin_amdgcn_s_sleep(1);
+                        }
                         if (ready && lane == 0) {                        // the request of the next iteration if nin stays N (see the duty wave's loop)
                             const bool first = b_n[0] < cfg.o_first_bins;
                             CT[OC_REQ] = OC_REQ_SPEC; CT[OC_CNIN] = N; CT[OC_CREG] = ckpar;
@@ -1069,9 +1130,14 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
                     // the samples of the estimator run after the one just done (a capture that mixes frames fetches them at the end of phase C:
                     // a load in flight there would make the wait for the parked outputs a wait for HBM)
                     if (ran_fft && !ready) prefetch_est(off + nin + N);
+                    WO_FINE(5);
                 }
                 lds_barrier();
                 WO_STAMP(1);
+                if (ND == 1) {                                           // (the duty wave's word of this iteration: the captures still alive)
+                    mask = __builtin_amdgcn_readfirstlane(CT0[OC_DUTY]) & 0xffff;
+                    if (!mask) break;
+                }
                 if (alive) {
                     if (ready) {
 #pragma unroll
@@ -1121,7 +1187,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
                                 }
                             }
                             WO_SUB(3);
-                            tstage2_load();                             // the frame's resampling points (parked in this iteration's phase A: L2)
+                            tstage2_load(Fscr, t_low, t_high, t_nan);   // the frame's resampling points (parked in this iteration's phase A: L2)
                             const long long off1 = off + nin;
                             const bool more = self || (off1 + nn <= C.nsamples && frames + 1 < C.cap_frames);
                             if (!more) request(OC_REQ_DEAD, nn, b_w, b_pv, ckpar, false, kf + 2);
@@ -1150,7 +1216,8 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
                             }
                             if (more && nn != N) { if (SMALL) prefetch_slot(off1, nn); prefetch_est(off1); }
                             WO_SUB(4);
-                            tstage2_finish(frames);
+                            tstage2_finish(frames, t_fract, t_nan);
+                            trace_write(frames);
                             WO_SUB(5);
                             nslip += (nn != N) ? 1 : 0;
                             off = off1; nin = nn; frames++;
@@ -1185,9 +1252,14 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
         }
 #ifdef WR_WITH_PROF
         if (pp) { for (int k = 0; k < 6; k++) pr[k] = pt[k]; if (!is_chain) pr[6] = frames; }
+#ifdef WR_PROF_FINE
+        if (pfn) { for (int k = 0; k < 8; k++) C.prof[24 + k] = pf[k]; }
+#endif
 #endif
 #undef WO_STAMP
 #undef WO_SUB
+#undef WO_FINE
+#undef WO_FINE0
     }
 
     // ================================ save carried state =======================================
