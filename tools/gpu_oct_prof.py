@@ -49,5 +49,9 @@ for ch in range(0, B, int(caps)):
           f" | duty / chain wave: wait requests {v[8] / fr:.0f}, chain (part 1) {v[9] / fr:.0f}, wait products (ND 2: barrier 1) {v[10] / fr:.0f}, chain part 2 {v[12] / fr:.0f}, sums + estimates {v[13] / fr:.0f}, barrier 2 {v[11] / fr:.0f}"
           f" | sum wave (ND 2): to barrier 1 {v[18] / fr:.0f}, sums + estimates {v[21] / fr:.0f}, barrier 2 {v[19] / fr:.0f} | duty total / frame {sum(v[8:14]) / fr:.0f}"
           f" | fine build, wave 0 sections: slot fetch/align {v[24] / fr:.0f}, tones (mix + window sums) {v[25] / fr:.0f}, timing products {v[26] / fr:.0f}, next slot fetch {v[27] / fr:.0f}, FFT {v[28] / fr:.0f}, tone search {v[29] / fr:.0f}")
+    for w in range(1, int(caps)):                                  # the other capture waves of the group: the same three stamps
+        if ch + w < B and L.wenet_rx_debug_profile(rx._h, ch + w, buf):
+            u = list(buf); fw = max(u[6], 1)
+            print(f"    capture wave {w}: mix / integrate {u[0] / fw:.0f}, FFT + tone search + wait {u[1] / fw:.0f}, phase C {u[2] / fw:.0f}")
     if ch >= 3 * int(caps):
         break

@@ -858,10 +858,19 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
         return acc;
     };
 
+    // (lane c looks at capture c's word: one LDS round trip for the workgroup's captures, not one per capture)
     auto alive_mask = [&]() __attribute__((always_inline)) {
-        int mk = 0;
-        for (int c = 0; c < G; c++) mk |= (__builtin_amdgcn_readfirstlane(CT0[c * ctw + OC_ALIVE]) ? 1 : 0) << c;
-        return mk;
+        const int ln = fresh_lane();
+        const int v = CT0[(ln < G ? ln : 0) * ctw + OC_ALIVE];
+        return (int)__ballot(ln < G && v != 0);
+    };
+    // wait until word `w` of every capture in `mk` has reached `target` (sequence words written by the capture waves)
+    auto wait_words = [&](int w, int target, int mk) __attribute__((always_inline)) {
+        const int ln = fresh_lane();
+        int *wp = (int *)&CT0[(ln < G ? ln : 0) * ctw + w];
+        const bool need = ln < G && ((mk >> ln) & 1);
+        while (__ballot(need && __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) != 0ull) __builtin_amdgcn_s_sleep(1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
 
     // ================================ frame loop ===============================================
@@ -890,7 +899,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
         // (G <= 15 captures per workgroup: OC_DUTY carries their alive mask in sixteen bits)
         if (is_chain) __builtin_amdgcn_s_setprio(2);
 #ifdef WR_WITH_PROF
-        const bool pp = C.prof != nullptr && lane == 0 && (wave == 0 || is_chain || is_sum);
+        const bool pp = C.prof != nullptr && lane == 0 && (present || is_chain || is_sum);       // (every capture wave into its own capture's block)
         long long *pr = C.prof + (is_chain ? 8 : (is_sum ? 16 : 0));     // (ND == 2: wave 0 | chain wave | sum wave)
         long long pt[6] = {0, 0, 0, 0, 0, 0}, t0 = pp ? (long long)__builtin_readcyclecounter() : 0;
 #define WO_STAMP(k) do { if (pp) { const long long t1 = (long long)__builtin_readcyclecounter(); pt[k] += t1 - t0; t0 = t1; } } while (0)
@@ -943,10 +952,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
             int selfmask = 0;                                            // captures whose next chain is the speculative one they wrote down beforehand
             for (long long kf = 0;; kf++) {
                 if (is_chain) {
-                    for (int c = 0; c < G; c++)
-                        if (((mask & ~selfmask) >> c) & 1)
-                            while (__hip_atomic_load((int *)&CT0[c * ctw + OC_SEQ], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (int)(kf + 1)) __builtin_amdgcn_s_sleep(1);
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    wait_words(OC_SEQ, (int)(kf + 1), mask & ~selfmask);
                     WO_STAMP(0);
                     constexpr int LPC = 2 * M;                           // chain lanes per capture
                     const int cc = lane / LPC;
@@ -974,9 +980,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
                     // requests) -- the sums run beside the transforms instead of after them.
                     // Every capture wave reports every iteration; once all have, their last phase C is over: who is still alive is known, and this
                     // wave has read the request words -- both said in one word (the waves read the mask after the barrier, all the same value).
-                    for (int c = 0; c < G; c++)
-                        while (__hip_atomic_load((int *)&CT0[c * ctw + OC_PRDY], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (int)(kf + 1)) __builtin_amdgcn_s_sleep(1);
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    wait_words(OC_PRDY, (int)(kf + 1), (1 << G) - 1);
                     mask &= alive_mask();
                     if (lane == 0) __hip_atomic_store((int *)&CT0[OC_DUTY], (int)((((unsigned)kf + 1u) << 16) | (unsigned)mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     WO_STAMP(2);
@@ -1088,6 +1092,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
                         __hip_atomic_store(&CT[OC_PRDY], (int)(kf + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                     WO_STAMP(0);
+                    __builtin_amdgcn_s_setprio(0);
                 }
                 if (alive) {
                     // estimator runs of this phase: after a slip E(k) with the true nin (tone search included), then -- always, unless it is done
@@ -1143,15 +1148,18 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
 #pragma unroll
                         for (int m = 0; m < M; m++) t_bins[m] = b_w[m];
                         __builtin_amdgcn_s_setprio(1);
-                        const int ordw = __builtin_amdgcn_readfirstlane(CT[OC_ORD]);
+                        // (the order word and the five values behind it: three LDS reads in flight together, one round trip)
+                        int ordw_v = CT[OC_ORD];
+                        float2 tc2 = *(const float2 *)((const float *)CT + OC_TC);
+                        float4 o4 = *(const float4 *)((const float *)CT + OC_O_NRT);
+                        asm volatile("" : "+v"(ordw_v), "+v"(tc2.x), "+v"(tc2.y), "+v"(o4.x), "+v"(o4.y), "+v"(o4.z));
+                        const int ordw = __builtin_amdgcn_readfirstlane(ordw_v);
                         const bool ordered = (ordw & 1) != 0;            // the duty wave formed the timing estimate
                         const bool self = (ordw & 2) != 0;               // ... and has started the next chain already: nin stays N, nothing to check
                         int nn = N;
                         bool did_1b = false, near_prev = false;
                         float o_nrt = 0.f;
                         if (ordered) {
-                            const float2 tc2 = *(const float2 *)((const float *)CT + OC_TC);             // (two LDS reads for the five values)
-                            const float4 o4 = *(const float4 *)((const float *)CT + OC_O_NRT);
                             t_tcr = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(tc2.x)));
                             t_tci = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(tc2.y)));
                             o_nrt = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(o4.x)));
@@ -1206,7 +1214,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
                                     ready = false; redo_e = true; en_valid = false;
                                 }
                             }
-                            __builtin_amdgcn_s_setprio(0);
+                            if (ND == 2) __builtin_amdgcn_s_setprio(0);     // (ND == 1: raised until the products are written -- everything up to there is on the workgroup's critical path, the transform after it is not)
                             omask = (!HLP && !t_nan && near_prev && nn == N) ? window_mask(t_low, WO_EXTRA_OUT ? (t_fract < 0.5f ? -1 : 1) : 0) : ALLOUT;     // (HLP: every output is in LDS)
                             pv_r = t_nan ? 0.f : t_tcr; pv_i = t_nan ? 0.f : t_tci;
                             if (lane == 0) {                             // what the duty wave needs for its estimate of the next frame
@@ -1224,7 +1232,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
                             alive = more;
                             if (alive && ready) prefetch_est(off + nin + N);
                         }
-                        __builtin_amdgcn_s_setprio(0);
+                        if (ND == 2) __builtin_amdgcn_s_setprio(0);
                     } else {
                         bool same = true;
                         if (redo_e) {
