@@ -1011,7 +1011,14 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
                                 const float rxt = nrt * cfg.P_f;
                                 const int low = (int)floorf(rxt), high = (int)ceilf(rxt);
                                 const int nnc = at > cfg.o_at_hi ? 2 : (at < cfg.o_at_lo ? 0 : 1);               // fsk.c:900-907
-                                self = (fl & 1) && nnc == 1 && ((fl & 2) || near);
+                                // (small slots: the capture's parking mask rides in the flags, so the cover test of a frame whose timing moved is made
+                                // here too -- the capture wave's own test, same bits -- and only slips and real misses wait for the capture wave)
+                                bool covered = false;
+                                if (TS <= 16) {
+                                    const unsigned om = (unsigned)fl >> 8;
+                                    covered = ((om >> (low >= 0 ? low : TS + low)) & (om >> (high >= 0 ? high : TS + high)) & 1u) != 0;
+                                }
+                                self = (fl & 1) && nnc == 1 && ((fl & 2) || near || covered);
                                 ord = 1 | (self ? 2 : 0) | (near ? 4 : 0) | (nnc << 4) | ((low + 64) << 8) | ((high + 64) << 16);
                                 ((float *)CTc)[OC_O_NRT] = nrt; ((float *)CTc)[OC_O_FRACT] = rxt - (float)low; ((float *)CTc)[OC_O_RXT] = rxt;
                             }
@@ -1219,7 +1226,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
                             pv_r = t_nan ? 0.f : t_tcr; pv_i = t_nan ? 0.f : t_tci;
                             if (lane == 0) {                             // what the duty wave needs for its estimate of the next frame
                                 const bool fastok = more && ready && off1 + nn + N <= C.nsamples && frames + 2 < C.cap_frames;
-                                CT[OC_FLAGS] = (fastok ? 1 : 0) | (omask == ALLOUT ? 2 : 0) | (more && ready ? 4 : 0);
+                                CT[OC_FLAGS] = (fastok ? 1 : 0) | (omask == ALLOUT ? 2 : 0) | (more && ready ? 4 : 0) | (TS <= 16 ? (int)(omask << 8) : 0);
                                 ((float *)CT)[OC_PV] = pv_r; ((float *)CT)[OC_PV + 1] = pv_i;
                             }
                             if (more && nn != N) { if (SMALL) prefetch_slot(off1, nn); prefetch_est(off1); }
@@ -1243,7 +1250,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
                             ready = true; redo_e = false; en_valid = false;
                             if (lane == 0) {
                                 const bool fastok = off + nin + N <= C.nsamples && frames + 1 < C.cap_frames;
-                                CT[OC_FLAGS] = (fastok ? 1 : 0) | (omask == ALLOUT ? 2 : 0) | 4;
+                                CT[OC_FLAGS] = (fastok ? 1 : 0) | (omask == ALLOUT ? 2 : 0) | 4 | (TS <= 16 ? (int)(omask << 8) : 0);
                                 ((float *)CT)[OC_PV] = pv_r; ((float *)CT)[OC_PV + 1] = pv_i;
                             }
                             request(OC_REQ_SPEC, N, b_n, b_w, ckpar ^ 1, true, kf + 2);
