@@ -332,7 +332,11 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
         if (off_j + Ndft <= nsamp_u) {                                // the whole transform window is inside the capture: no index clamping
             oct_g_ci8 *pb = (oct_g_ci8 *)(raw16 + off_j);
 #pragma unroll
-            for (int j = 0; j < NE; j++) epre[j] = *(oct_g_u16 *)(pb + 2u * (unsigned)src_t[4 * (ln + 64 * (j >> 2)) + (j & 3)]);
+            for (int j4 = 0; j4 < NE / 4; j4++) {
+                const int4 s4 = *(const int4 *)(src_t + 4 * (ln + 64 * j4));                       // (the four source indices of a butterfly: one 128-bit read)
+                epre[4 * j4] = *(oct_g_u16 *)(pb + 2u * (unsigned)s4.x); epre[4 * j4 + 1] = *(oct_g_u16 *)(pb + 2u * (unsigned)s4.y);
+                epre[4 * j4 + 2] = *(oct_g_u16 *)(pb + 2u * (unsigned)s4.z); epre[4 * j4 + 3] = *(oct_g_u16 *)(pb + 2u * (unsigned)s4.w);
+            }
         } else {                                                         // (a run ahead of the capture's end: its result is never used)
 #pragma unroll
             for (int j = 0; j < NE; j++) { long long a = off_j + src_t[4 * (ln + 64 * (j >> 2)) + (j & 3)]; epre[j] = raw16[a < last_smp ? a : last_smp]; }
@@ -393,6 +397,9 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
         o1 = make_float2(s5.x + s4.y, s5.y - s4.x);
         o3 = make_float2(s5.x - s4.y, s5.y + s4.x);
     };
+    auto lds_batch7 = [](float2 &a, float2 &b, float2 &c, float2 &d, float2 &e, float2 &f, float2 &g) __attribute__((always_inline)) {
+        asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(b.x), "+v"(b.y), "+v"(c.x), "+v"(c.y), "+v"(d.x), "+v"(d.y), "+v"(e.x), "+v"(e.y), "+v"(f.x), "+v"(f.y), "+v"(g.x), "+v"(g.y));
+    };
     // (HLP: the transform of one capture spread over its M mix wavefronts -- wave w takes butterfly ln + 64 w of every stage; between the stages the
     // waves meet at a counter in LDS, fft_meet)
     int fft_jb_lo = 0, fft_jb_hi = NBF, fft_epoch = 0;
@@ -414,16 +421,19 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
 #pragma unroll(NBF > 2 ? 1 : NBF)                                       // (large transform: one butterfly at a time -- more in flight spill)
         for (int jb = jb_lo; jb < jb_hi; jb++) {                         // first stage (m = 1) straight from the window, butterfly bf = ln + 64 jb
             const int bf = ln + 64 * jb;
+            // fsk.c:587-603: half-Hann window, zero padding.  Branch-free, the table reads batched: the four source indices are one 128-bit read, the
+            // four window values are in flight together (an index in the padding reads entry 0 and the product is replaced by the zero)
             float2 v[4];
+            const int4 id4 = *(const int4 *)(src_t + 4 * bf);
+            const int idx[4] = {id4.x, id4.y, id4.z, id4.w};
+            float h[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) {                                // fsk.c:587-603: half-Hann window, zero padding
-                const int idx = src_t[4 * bf + i];
-                v[i] = make_float2(0.f, 0.f);
-                if (idx < fft_samps) {
-                    const float h = hann_t[idx];
-                    const float2 x = cvt(SMALL ? epre[SMALL ? 4 * jb + i : 0] : (unsigned)raw16[est_off + idx < last_smp ? est_off + idx : last_smp]);
-                    v[i] = make_float2(h * x.x, h * x.y);
-                }
+            for (int i = 0; i < 4; i++) h[i] = hann_t[idx[i] < fft_samps ? idx[i] : 0];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float2 x = cvt(SMALL ? epre[SMALL ? 4 * jb + i : 0] : (unsigned)raw16[est_off + idx[i] < last_smp ? est_off + idx[i] : last_smp]);
+                const bool in = idx[i] < fft_samps;
+                v[i] = make_float2(in ? h[i] * x.x : 0.f, in ? h[i] * x.y : 0.f);
             }
             float2 o0, o1, o2, o3;
             bfly4(v[0], v[1], v[2], v[3], o0, o1, o2, o3);
@@ -441,11 +451,13 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
                 const int bf = ln + 64 * jb;
                 const int blk = bf >> lgm, k = bf & (m - 1);
                 float2 *F = FB + blk * m * 4 + k;
-                const float2 s0 = cmul_f2(F[m], tw_t[k * fs]);
-                const float2 s1 = cmul_f2(F[2 * m], tw_t[k * fs * 2]);
-                const float2 s2 = cmul_f2(F[3 * m], tw_t[k * fs * 3]);
+                float2 f0 = F[0], f1 = F[m], f2 = F[2 * m], f3 = F[3 * m], w1 = tw_t[k * fs], w2 = tw_t[k * fs * 2], w3 = tw_t[k * fs * 3];
+                lds_batch7(f0, f1, f2, f3, w1, w2, w3);                  // (the butterfly's seven LDS reads in flight together: one round trip, not three)
+                const float2 s0 = cmul_f2(f1, w1);
+                const float2 s1 = cmul_f2(f2, w2);
+                const float2 s2 = cmul_f2(f3, w3);
                 float2 o0, o1, o2, o3;
-                bfly4(F[0], s0, s1, s2, o0, o1, o2, o3);
+                bfly4(f0, s0, s1, s2, o0, o1, o2, o3);
                 F[0] = o0; F[m] = o1; F[2 * m] = o2; F[3 * m] = o3;
             }
             fft_meet(st);
@@ -456,11 +468,13 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
             for (int jb = jb_lo; jb < jb_hi; jb++) {
                 const int k = ln + 64 * jb;
                 float2 *F = FB + k;
-                const float2 s0 = cmul_f2(F[m], tw_t[k]);
-                const float2 s1 = cmul_f2(F[2 * m], tw_t[2 * k]);
-                const float2 s2 = cmul_f2(F[3 * m], tw_t[3 * k]);
+                float2 f0 = F[0], f1 = F[m], f2 = F[2 * m], f3 = F[3 * m], w1 = tw_t[k], w2 = tw_t[2 * k], w3 = tw_t[3 * k];
+                lds_batch7(f0, f1, f2, f3, w1, w2, w3);
+                const float2 s0 = cmul_f2(f1, w1);
+                const float2 s1 = cmul_f2(f2, w2);
+                const float2 s2 = cmul_f2(f3, w3);
                 float2 o0, o1, o2, o3;
-                bfly4(F[0], s0, s1, s2, o0, o1, o2, o3);
+                bfly4(f0, s0, s1, s2, o0, o1, o2, o3);
                 F[0] = o0; F[m] = o1;
             }
             fft_meet(NST - 1);
