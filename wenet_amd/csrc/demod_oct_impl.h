@@ -860,9 +860,15 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
 #pragma unroll
                 for (int u = 0; u < 4; u++) buf[(bk + 2) % 3][u] = T4[tp_group(4 * (bk + 2) + u)];
             }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                acc = acc + buf[bk % 3][u].x; acc = acc + buf[bk % 3][u].y; acc = acc + buf[bk % 3][u].z; acc = acc + buf[bk % 3][u].w;
+            {                                                            // (the batch's sixteen adds as one statement: ONE wait for its four reads, not one per read -- every s_waitcnt is an issue slot of this wave)
+                const v4f q0 = buf[bk % 3][0], q1 = buf[bk % 3][1], q2 = buf[bk % 3][2], q3 = buf[bk % 3][3];
+                asm volatile("v_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %2\n\tv_add_f32 %0, %0, %3\n\tv_add_f32 %0, %0, %4\n\t"
+                             "v_add_f32 %0, %0, %5\n\tv_add_f32 %0, %0, %6\n\tv_add_f32 %0, %0, %7\n\tv_add_f32 %0, %0, %8\n\t"
+                             "v_add_f32 %0, %0, %9\n\tv_add_f32 %0, %0, %10\n\tv_add_f32 %0, %0, %11\n\tv_add_f32 %0, %0, %12\n\t"
+                             "v_add_f32 %0, %0, %13\n\tv_add_f32 %0, %0, %14\n\tv_add_f32 %0, %0, %15\n\tv_add_f32 %0, %0, %16"
+                             : "+v"(acc)
+                             : "v"(q0.x), "v"(q0.y), "v"(q0.z), "v"(q0.w), "v"(q1.x), "v"(q1.y), "v"(q1.z), "v"(q1.w),
+                               "v"(q2.x), "v"(q2.y), "v"(q2.z), "v"(q2.w), "v"(q3.x), "v"(q3.y), "v"(q3.z), "v"(q3.w));
             }
             asm volatile("" : "+v"(acc));                                // (keeps the batches in order)
         }
