@@ -487,14 +487,20 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
         const int ln = fresh_lane();
         constexpr int NPL = NH / 64;                                     // spectrum points per lane: bins ln, ln + 64, ...
         float e[NPL];
+        float2 vq[NPL];
+        float feq[NPL];
+#pragma unroll
+        for (int kk = 0; kk < NPL; kk++) { vq[kk] = FB[ln + 64 * kk]; feq[kk] = FEin[ln + 64 * kk]; }     // (all the lane's LDS reads in flight together)
+#pragma unroll
+        for (int kk = 0; kk < NPL; kk++) asm volatile("" : "+v"(vq[kk].x), "+v"(vq[kk].y), "+v"(feq[kk]));
 #pragma unroll
         for (int kk = 0; kk < NPL; kk++) {                               // fsk.c:612-628
             const int i = ln + 64 * kk;
-            const float2 v = FB[i];
+            const float2 v = vq[kk];
             float mag = (v.x * v.x) + (v.y * v.y);
             if (i < cfg.f_min) mag = 0.f;
             if (cfg.f_max - 1 >= 0 && i >= cfg.f_max - 1) mag = 0.f;
-            e[kk] = (FEin[i] * cfg.one_minus_tc) + (sqrtf(mag) * cfg.tc);
+            e[kk] = (feq[kk] * cfg.one_minus_tc) + (sqrtf(mag) * cfg.tc);
             FEout[i] = e[kk];
         }
         int fbin[M];

@@ -42,18 +42,26 @@ WG_HD float wg_atanf(float x) {
         if (hx > 0) return atanhi3 + atanlo3;
         return -atanhi3 - atanlo3;
     }
-    if (ix < 0x3ee00000) {                       // |x| < 0.4375
-        if (ix < 0x31000000) return x;           // |x| < 2^-29
-        id = -1;
-    } else {
-        x = wg_u2f((uint32_t)ix);                // fabsf
-        if (ix < 0x3f980000) {                   // |x| < 1.1875
-            if (ix < 0x3f300000) { id = 0; x = (2.0f * x - one) / (2.0f + x); hi = atanhi0; lo = atanlo0; }
-            else                 { id = 1; x = (x - one) / (x + one);         hi = atanhi1; lo = atanlo1; }
-        } else {
-            if (ix < 0x401c0000) { id = 2; x = (x - 1.5f) / (one + 1.5f * x); hi = atanhi2; lo = atanlo2; }
-            else                 { id = 3; x = -1.0f / x;                     hi = atanhi3; lo = atanlo3; }
-        }
+    // The five argument intervals without divergent branches (the lanes of a wavefront -- one capture each in the batch demodulator -- fall into
+    // different ones): the quotient's operands are selected, ONE division serves all (an interval without a reduction divides 0 by 1 and keeps x).
+    // Every lane still performs exactly the operations of its own interval, in fdlibm's order.
+    if (ix < 0x31000000) return x;               // |x| < 2^-29
+    const float ax = wg_u2f((uint32_t)ix);       // fabsf
+    float num = 0.0f, den = one;
+    id = -1;
+    if (ix >= 0x3ee00000) {                      // |x| >= 0.4375
+        const float n0 = 2.0f * ax - one, d0 = 2.0f + ax;            // id 0: |x| < 0.6875
+        const float n1 = ax - one, d1 = ax + one;                    // id 1: |x| < 1.1875
+        const float n2 = ax - 1.5f, d2 = one + 1.5f * ax;            // id 2: |x| < 2.4375
+        id = ix < 0x3f300000 ? 0 : (ix < 0x3f980000 ? 1 : (ix < 0x401c0000 ? 2 : 3));
+        num = id == 0 ? n0 : (id == 1 ? n1 : (id == 2 ? n2 : -1.0f));
+        den = id == 0 ? d0 : (id == 1 ? d1 : (id == 2 ? d2 : ax));
+        hi = id == 0 ? atanhi0 : (id == 1 ? atanhi1 : (id == 2 ? atanhi2 : atanhi3));
+        lo = id == 0 ? atanlo0 : (id == 1 ? atanlo1 : (id == 2 ? atanlo2 : atanlo3));
+    }
+    {
+        const float q = num / den;
+        x = id < 0 ? x : q;
     }
     z = x * x;
     w = z * z;
