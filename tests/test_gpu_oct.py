@@ -124,8 +124,8 @@ def test_large_batch_picks_the_kernel_by_itself():
     rx.close()
 
 
-@pytest.mark.parametrize("group,nd,hlp", [(2, 1, 0), (4, 2, 0), (3, 2, 0), (1, 2, 0), (1, 2, 1)])
-def test_exact_mode_4fsk_ts32_equals_oracle(group, nd, hlp, monkeypatch):
+@pytest.mark.parametrize("group,nd,hlp,slices", [(2, 1, 0, 0), (4, 2, 0, 0), (3, 2, 0, 0), (1, 2, 0, 0), (1, 2, 1, 0), (1, 2, 1, 1), (4, 2, 0, 1), (2, 1, 0, 1)])
+def test_exact_mode_4fsk_ts32_equals_oracle(group, nd, hlp, slices, monkeypatch):
     """The large geometry of the batch kernel (BASELINE config 4: 4-FSK, Rs 57 600, Fs 1 843 200 -> Ts 32, 1024-point estimator, two
     soft decisions per symbol), forced here: every capture equals the oracle bit for bit, slips and ragged ends included -- with one duty
     wavefront per workgroup (chains and sums in turn) and with two (a chain wave and a sum wave, the chain pass straddling the barrier: what
@@ -133,6 +133,8 @@ def test_exact_mode_4fsk_ts32_equals_oracle(group, nd, hlp, monkeypatch):
     monkeypatch.setenv("WENET_RX_OCT", str(group))
     monkeypatch.setenv("WENET_RX_OCT_ND", str(nd))
     monkeypatch.setenv("WENET_RX_OCT_HLP", str(hlp))                 # 1: the capture's mix stage on four wavefronts, a tone each (the single-stream form)
+    if slices:                                                       # uploaded and demodulated in short time slices: every launch resumes from the carried state
+        monkeypatch.setenv("WENET_RX_SLICE_SAMPLES", "25000")        # (the tone helpers read the capture's carried samples in a launch's first frame)
     cfg = siggen.config_4fsk()
     spec = ((4, 8.0, 0.0), (2, 12.0, 150.0), (3, 6.5, -300.0), (1, 20.0, 0.0), (2, 9.0, 2000.0), (2, 7.0, -2500.0))
     caps = [siggen.make_capture(cfg, n, eb, seed=740 + i, ppm=ppm)[0] for i, (n, eb, ppm) in enumerate(spec)]

@@ -28,6 +28,11 @@ done
   WENET_RX_OCT=7 python tools/soak_short.py 2>&1 | tail -1
 } > gpurun_out/r03_soak.txt 2>&1
 python tools/host_feed.py 768 10 > gpurun_out/r03_host_feed.txt 2>&1; python tools/host_feed.py 256 10 >> gpurun_out/r03_host_feed.txt 2>&1; python tools/host_feed.py 3584 10 >> gpurun_out/r03_host_feed.txt 2>&1
+{ echo "# cycle stamps of the batch demodulator (instrumented build, tools/prof_build.sh; ~10 % slower than the product), per frame"
+  echo "## 3584 captures x 2 s, seven captures + one duty wave per workgroup, two workgroups per CU"; WENET_RX_LIB=tools/prof_build/libwenet_rx.so python tools/gpu_oct_prof.py 3584 2 7 v2 2>&1 | grep -v amdgpu.ids | head -9
+  echo "## 1792 captures: one workgroup per CU"; WENET_RX_LIB=tools/prof_build/libwenet_rx.so python tools/gpu_oct_prof.py 1792 2 7 v2 2>&1 | grep -v amdgpu.ids | head -2
+  echo "## product build, the same two"; python tools/gpu_oct_prof.py 3584 2 7 v2 2>&1 | grep kernel; python tools/gpu_oct_prof.py 1792 2 7 v2 2>&1 | grep kernel
+} > gpurun_out/r03_oct_stamps.txt 2>&1
 python tools/gpu_allout.py v2 3584 2 8 > gpurun_out/r03_allout.txt 2>&1; python tools/gpu_allout.py 4fsk 1024 2 8 >> gpurun_out/r03_allout.txt 2>&1
 python - <<'PY'
 import json, glob

@@ -358,7 +358,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
             // zeros of a reset: exact inverse of the conversion) below 0, the capture's last sample repeated beyond it (never used)
             auto samp = [&](long long a) __attribute__((always_inline)) -> unsigned {
                 if (a < 0) {
-                    const float2 v = present ? st_old[nstash + a] : make_float2(0.f, 0.f);
+                    const float2 v = (present || (is_hlp && ch < nchan)) ? st_old[nstash + a] : make_float2(0.f, 0.f);     // (a tone helper reads its capture's carried samples too)
                     return (unsigned)(int)(v.x * 128.0f + 127.0f) | ((unsigned)(int)(v.y * 128.0f + 127.0f) << 8);
                 }
                 return raw16[a < last_smp ? a : last_smp];
