@@ -923,6 +923,11 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
         //   en_valid the next frame's estimator run is done already (the iteration after such a second request)
         //   redo_d   (ready) the parked integrator outputs did not cover the resampling points: mix the frame again, parking everything
         // (G <= 15 captures per workgroup: OC_DUTY carries their alive mask in sixteen bits)
+        // Priorities.  One duty wave (ND == 1): its chain + sums are nearly as long as the frame -- it runs above the capture waves, which are raised
+        // themselves from the barrier until their products are written.  Two duty waves (the Ts-32 forms): the capture wave's own frame (decisions, mix
+        // stage, transform) is the workgroup's serial path and both duty waves have slack -- the capture (and tone-helper) waves run above them
+        // (config 4, 1024 captures x 2 s: 66.5 -> 60.2 ms; the single-stream form with its tone helpers is better off with the duty waves above: 74 against 79-83 ms per 4 s).
+        if (ND == 2 && !HLP) { if (is_chain || is_sum) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2); } else
         if (is_chain) __builtin_amdgcn_s_setprio(2);
 #ifdef WR_WITH_PROF
         const bool pp = C.prof != nullptr && lane == 0 && (present || is_chain || is_sum);       // (every capture wave into its own capture's block)
@@ -972,7 +977,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
         // chain nor the sums wait for the other: the workgroup's iteration is no longer chain + sums but max(chain, capture work) -- and two
         // duty waves serve fourteen captures (one workgroup per CU), half the narrow-stage instructions per capture.
         if (is_chain || is_sum) {
-            if (is_sum) __builtin_amdgcn_s_setprio(2);
+            if (is_sum && !(ND == 2 && !HLP)) __builtin_amdgcn_s_setprio(2);
             float own_m1 = own_s;                                        // the phasors before the last chain that was run
             int mask = (1 << G) - 1;
             int selfmask = 0;                                            // captures whose next chain is the speculative one they wrote down beforehand
@@ -1180,7 +1185,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
                     if (ready) {
 #pragma unroll
                         for (int m = 0; m < M; m++) t_bins[m] = b_w[m];
-                        __builtin_amdgcn_s_setprio(1);
+                        if (!(ND == 2 && !HLP)) __builtin_amdgcn_s_setprio(1);
                         // (the order word and the five values behind it: three LDS reads in flight together, one round trip)
                         int ordw_v = CT[OC_ORD];
                         float2 tc2 = *(const float2 *)((const float *)CT + OC_TC);
@@ -1247,7 +1252,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
                                     ready = false; redo_e = true; en_valid = false;
                                 }
                             }
-                            if (ND == 2) __builtin_amdgcn_s_setprio(0);     // (ND == 1: raised until the products are written -- everything up to there is on the workgroup's critical path, the transform after it is not)
+                            if (ND == 2 && HLP) __builtin_amdgcn_s_setprio(0);     // (ND == 1: raised until the products are written -- everything up to there is on the workgroup's critical path, the transform after it is not)
                             omask = (!HLP && !t_nan && near_prev && nn == N) ? window_mask(t_low, WO_EXTRA_OUT ? (t_fract < 0.5f ? -1 : 1) : 0) : ALLOUT;     // (HLP: every output is in LDS)
                             pv_r = t_nan ? 0.f : t_tcr; pv_i = t_nan ? 0.f : t_tci;
                             if (lane == 0) {                             // what the duty wave needs for its estimate of the next frame
@@ -1265,7 +1270,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
                             alive = more;
                             if (alive && ready) prefetch_est(off + nin + N);
                         }
-                        if (ND == 2) __builtin_amdgcn_s_setprio(0);
+                        if (ND == 2 && HLP) __builtin_amdgcn_s_setprio(0);
                     } else {
                         bool same = true;
                         if (redo_e) {
