@@ -1265,7 +1265,12 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw_in, const 
             // own: 35.5 x real time for one 10 s capture against 26.3 x through the sequential kernel)
             else if (!rx->want_trace && c.M == 4) {
                 const int ncu = wenet_rx_device_info(1);
-                if (n_sel >= 3 * ncu) { oct_caps = 4; oct_nd = 2; } else if (n_sel >= 2 * ncu) oct_caps = 2; else { oct_caps = 1; oct_nd = 2; oct_hlp = n_sel <= ncu; }
+                // (round 3, capture waves above the duty waves: the fewest captures per workgroup that put the batch on the CUs at once, always with a chain
+                // wave and a sum wave -- 1024 captures x 2 s: four per workgroup 60.2 ms; 700: three 56.8 (two + one duty wave: 72.7); 512 and 300: two 54.5
+                // (300 as one capture per workgroup without helpers: 89); up to one capture per CU the single-stream form with its tone helpers)
+                oct_nd = 2;
+                oct_caps = n_sel <= ncu ? 1 : (n_sel <= 2 * ncu ? 2 : (n_sel <= 3 * ncu ? 3 : 4));
+                oct_hlp = oct_caps == 1;
             }
         }
         WrDemodCfg oct_cfg;
