@@ -11,9 +11,10 @@
 //     duty wave     NCO chains of the captures (lanes 2 (M c + m), +1 = re, im of tone m of capture c), a checkpoint every Ts/2
 //                   steps; the ordered timing sums of the captures (lanes 2c, 2c+1 = re, im); their timing estimates (lane 2c)
 //
-// Exact mode runs the run-ahead schedule described at the frame loop: the chain of frame k+1 under the mix stage of frame k, two
-// workgroup barriers per frame.  Two such workgroups share a CU (80 KB of LDS each at G = 7), so one group's narrow phases run
-// under the other's wide ones.
+// The run-ahead schedule is described at the frame loop: the chain of frame k+1 under the mix stage of frame k, the ordered sums of frame k
+// beside the capture waves' estimator FFT, one workgroup barrier per frame (round 3).  Two such workgroups share a CU (80 KB of LDS each at
+// G = 7), so one group's narrow phases run under the other's wide ones.  The Ts-32 geometry (4-FSK) runs with two duty waves (a chain wave and
+// a sum wave), and a single stream of it with three tone helpers beside the capture wave (HLP).
 //
 // Data movement: no sample ring.  A capture wave reads its frame straight from HBM -- lane l owns the Ts samples of symbol
 // slot l (buffer positions Ts*l .. Ts*l+Ts-1 of the reference's Nmem-sample window), loaded one frame ahead -- mixes them with
@@ -906,14 +907,17 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
     {
         // ---- the run-ahead schedule (exact mode) ---------------------------------------------------------------
         // A capture's frames form one dependency chain: NCO chain(k) -> mix / integrate(k) -> ordered timing sum(k) -> nin(k+1) ->
-        // chain(k+1).  Run in that order (the loop below this one) the duty wave idles through the wide stage and the capture waves
+        // chain(k+1).  Run in that order (the plain schedule of early round 2) the duty wave idles through the wide stage and the capture waves
         // through the chain.  Here the duty wave runs chain(k+1) DURING mix / integrate(k), assuming nin(k+1) = N -- true for all but the
-        // frames with a timing slip -- so an iteration is two phases and two workgroup barriers:
-        //     A   capture waves: mix / integrate(k), then the FFT of E(k+2)      | duty wave: chain(k+1), speculative, into the other checkpoint region
-        //     B   capture waves: tone search of E(k+2), decisions / outputs(k-1) | duty wave: ordered timing sums(k)
-        //     C   (no barrier) capture waves: nin(k+1) from the sums, bookkeeping, next request to the duty wave (LDS sequence word)
-        // The estimator therefore runs two frames ahead (three spectra in a ring), the decisions one frame behind (two blocks of parked
-        // integrator outputs).  A capture whose nin(k+1) != N spends ONE iteration without a frame: the duty wave chains frame k+1 again
+        // frames with a timing slip.  An iteration (one duty wave, ND == 1: ONE workgroup barrier, at its end):
+        //     C   capture waves: nin(k) / timing(k-1) from the duty wave's order words, decisions / outputs(k-1), bookkeeping, next request to the
+        //         duty wave (an LDS sequence word; none if the duty wave said it starts the next chain by itself)
+        //     A   capture waves: mix / integrate(k) -> "products written" word (OC_PRDY)   | duty wave: chain(k+1), speculative, into the other checkpoint region
+        //     B   capture waves: FFT of E(k+2), tone search, the speculative request       | duty wave, once every capture's word is there: ordered timing sums(k),
+        //                                                                                  |   timing estimates -> order words; OC_DUTY: requests read, captures alive
+        //     barrier
+        // (Two duty waves, ND == 2 -- the Ts-32 forms: a barrier between A and B as well, the FFT after it, the chain pass straddling it.)
+        // The estimator therefore runs two frames ahead (three spectra in a ring).  A capture whose nin(k+1) != N spends ONE iteration without a frame: the duty wave chains frame k+1 again
         // with the true nin (from the state before the speculative chain, with the tone bins the run-ahead estimator found -- a guess that
         // is checked) while the capture wave repeats E(k+1) and E(k+2) on the shifted windows; the other captures of the workgroup are not
         // held up.  Everything a frame computes is computed by the same statements in the same order as in the plain schedule.

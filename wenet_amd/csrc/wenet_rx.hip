@@ -1257,12 +1257,10 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw_in, const 
                 // 1 144 instead of 1 279 VALU instructions per frame but take 218 ms against 210 for 3584 captures -- the fourteen capture waves then
                 // move in lock-step and the sum wave competes with their transforms; two workgroups of six + two: 188 ms for 3072.  Not built for them.)
             }
-            // the 4-FSK / Ts 32 geometry (BASELINE config 4): 30 KB of LDS per capture = four captures per CU as two workgroups of two;
-            // from two captures per CU on it beats the sequential kernel's one capture per CU (34 vs 11.5 Gsamples/s at 1024 captures)
-            // (round 3: from three captures per CU on ONE workgroup of four captures with a chain wave and a sum wave: the 1 568-step chain and the
-            // 1 568-term sums are then shared by four captures and no longer wait for each other -- 72.7 against 83.4 ms per 1024 captures x 2 s)
-            // (... and below two captures per CU -- one stream alone included -- one capture per workgroup with a chain wave and a sum wave of its
-            // own: 35.5 x real time for one 10 s capture against 26.3 x through the sequential kernel)
+            // The 4-FSK / Ts 32 geometry (BASELINE config 4), 32.6 KB of LDS per capture: up to four captures per CU.  Round 2 ran two workgroups of two
+            // captures + one duty wave (34 against the sequential kernel's 11.5 G samples/s at 1024 captures); round 3 ONE workgroup with a chain wave and a
+            // sum wave -- the 1 568-step chain and the 1 568-term sums shared by its captures and running beside each other -- and the capture waves above
+            // both in priority; a single stream (up to one capture per CU) with three tone helpers: 54.7 x real time against 26.3 x.
             else if (!rx->want_trace && c.M == 4) {
                 const int ncu = wenet_rx_device_info(1);
                 // (round 3, capture waves above the duty waves: the fewest captures per workgroup that put the batch on the CUs at once, always with a chain
