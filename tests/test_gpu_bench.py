@@ -67,3 +67,18 @@ def test_fixed_capture_set_sharded_round_robin_over_two_ranks():
     nsamp = d["config"]["samples_per_capture"]
     assert abs(d["value"] - 9 * nsamp * 2 / (d["ms_per_step"] * 2e-3) / 1e6) < 1e-3 * d["value"]
     assert "sweep" in d["config"]["workload"] and d["packets_valid_per_step_rank0"] > 0
+
+
+def test_config5_shape_eight_ranks_on_one_gpu_over_gloo():
+    """BASELINE config 5 as the driver's 8-GPU run will launch it -- 128 channels dealt round-robin to eight ranks, sixteen each -- with the eight
+    ranks sharing the one GPU of the test box (gloo): rendezvous, sharding, the barrier + max-over-ranks timing and rank 0's line with n_gpus 8."""
+    env = dict(os.environ, WENET_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", "29523",
+           os.path.join(ROOT, "bench.py"), "--gpus", "8", "--total-captures", "128", "--seconds", "1", "--steps", "2", "--warmup", "1"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _line(r.stdout)
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["config"]["captures_per_gpu"] == 16 and d["cpu_baseline"] is None
+    nsamp = d["config"]["samples_per_capture"]
+    assert abs(d["value"] - 128 * nsamp * 2 / (d["ms_per_step"] * 2e-3) / 1e6) < 1e-3 * d["value"]
+    assert d["packets_valid_per_step_rank0"] > 0
