@@ -419,7 +419,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
         const int fft_samps = nin_j - Ndft;                              // fsk.c:583-584 with fft_loops == 1
         const int ln = fresh_lane();
         const int jb_lo = (HLP && fft_shared) ? fft_jb_lo : 0, jb_hi = (HLP && fft_shared) ? fft_jb_hi : NBF;
-#pragma unroll(NBF > 2 ? 1 : NBF)                                       // (large transform: one butterfly at a time -- more in flight spill)
+#pragma unroll(NBF > 2 ? 1 : NBF)
         for (int jb = jb_lo; jb < jb_hi; jb++) {                         // first stage (m = 1) straight from the window, butterfly bf = ln + 64 jb
             const int bf = ln + 64 * jb;
             // fsk.c:587-603: half-Hann window, zero padding.  Branch-free, the table reads batched: the four source indices are one 128-bit read, the
@@ -568,18 +568,23 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
         const int nold = Nmem - nin_j;
         if (realign) { if (!SMALL) prefetch_slot(off_j, nin_j); slot_align(off_j, nin_j); }
         const int ln = fresh_lane(), slot = ln < NBLK ? ln : NBLK - 1;
-        constexpr bool FT1_LDS = TS > 10;                                // the per-output power sums: registers, or (large slots) the products' re row
+        // the per-output power sums: in registers -- or, for the tone helpers of the single-stream form (one tone per wavefront), per-tone rows in LDS.
+        // (Round 3, Ts 32: rounds 1-2 kept the sums in the capture's product row and the slot's 32 converted samples in registers for all four tones;
+        // converting per tone from the raw dwords frees 64 registers, 32 of which hold the sums: no LDS read-modify-write per tone -- config 4 -4 %.)
+        constexpr bool FT1_LDS = TS > 10 && HLP;
+        constexpr bool XS_ONCE = !SMALL && HLP;                          // the slot's samples converted once (a helper mixes one tone) or per tone from the raw dwords
+        constexpr bool SLOT_SMALL = TS <= 16;
         v2f ft1[FT1_LDS ? 1 : TS / 2];                                   // (pairs: outputs r, r + 1 -- the operands of the packed timing products)
         float pw[FT1_LDS ? TS : 1];
-        v2f xs[SMALL ? 1 : TS];                                          // large geometry (256 VGPRs): the slot's samples converted once for all tones
-        if (!SMALL) {
+        v2f xs[XS_ONCE ? TS : 1];
+        if (XS_ONCE) {
 #pragma unroll
-            for (int u = 0; u < TS; u++) xs[SMALL ? 0 : u] = slot_sample(u);
+            for (int u = 0; u < TS; u++) xs[XS_ONCE ? u : 0] = slot_sample(u);
         }
         WO_FINE(0);
         float *Trow = TPf + TS * ln;
         unsigned fbase[3];                                               // byte offsets of the lane's values from the scratch block, 4 KB apart
-        if (!FT1_LDS) {
+        if (SLOT_SMALL) {
             fbase[0] = (unsigned)ln * 8u;
 #pragma unroll
             for (int k = 1; k < 3; k++) { fbase[k] = fbase[k - 1] + 4096u; asm volatile("" : "+v"(fbase[k])); }
@@ -587,7 +592,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
         auto put_out = [&](int m, int r, v2f f) __attribute__((always_inline)) {
             if (HLP) PKl[(m * TS + r) * 64 + ln] = f;                    // (one stream: every output stays in LDS)
             else if ((omask >> r) & 1) {                                 // (wave-uniform)
-                if (!FT1_LDS) {
+                if (SLOT_SMALL) {
                     // value (m, r) sits 512 (m TS + r) bytes above the lane's first one: reached from three lane offsets 4 KB apart with the
                     // store's immediate offset (left to itself the compiler materialises -- and spills -- twenty addresses)
                     const int byte = (m * TS + r) * 512;
@@ -604,7 +609,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
             if (!FT1_LDS) ft1[FT1_LDS ? 0 : r / 2][r & 1] = (m == 0) ? a : ft1[FT1_LDS ? 0 : r / 2][r & 1] + a;
             else pw[r] = a;                                              // (this tone's powers; added to the row after the tone, in one go)
         };
-#pragma unroll(FT1_LDS ? 1 : M)                                         // (large slots: one tone's code, run M times -- d[] alone is 2 TS registers)
+#pragma unroll(SLOT_SMALL ? M : 1)                                      // (large slots: one tone's code, run M times -- d[] alone is 2 TS registers)
         for (int m = HLP ? d_m_lo : 0; m < (HLP ? d_m_hi : M); m++) {
             v2f d[TS];
             const float2 dA2 = dphi_t[CT[OC_FBINP + m]], dB2 = dphi_t[CT[OC_FBIN + m]];
@@ -617,7 +622,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
                 const v2f dd = {segA ? dA2.x : dB2.x, segA ? dA2.y : dB2.y};
 #pragma unroll
                 for (int u = 0; u < H; u++) {
-                    d[hh * H + u] = cmul_conj_pk(SMALL ? slot_sample(hh * H + u) : xs[SMALL ? 0 : hh * H + u], phi);   // fsk.c:796 / :822
+                    d[hh * H + u] = cmul_conj_pk(XS_ONCE ? xs[XS_ONCE ? hh * H + u : 0] : slot_sample(hh * H + u), phi);   // fsk.c:796 / :822
                     if (u < H - 1) phi = cmul_pk(phi, dd);                                     // fsk.c:798 / :824 (replayed from the checkpoint)
                 }
             }
@@ -657,7 +662,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
             for (int r = 0; r < TS; r += 2) {                        // fsk.c:870-871: the products; the duty wave adds them in order
                 // outputs r, r + 1 at once: (ft1[r] re(phi_ft[r]), ft1[r+1] re(phi_ft[r+1])) and the same with the imaginary parts -- the
                 // products of fsk.c:870-871, one packed multiply per row pair (the oscillator comes as two planes for this)
-                const int ro = FT1_LDS ? 4 * (tp_group(8 * ln + (r >> 2)) - 8 * ln) + (r & 3) : r;      // (swizzled position of output r in the lane's row)
+                const int ro = TS == 32 ? 4 * (tp_group(8 * ln + (r >> 2)) - 8 * ln) + (r & 3) : r;      // (swizzled position of output r in the lane's row)
                 const v2f f2 = FT1_LDS ? *(const v2f *)(Trow + ro) : ft1[FT1_LDS ? 0 : r / 2];
                 const v2f pre = *(oct_g_cf32x2 *)(pft_pl + TS * ln + r), pim = *(oct_g_cf32x2 *)(pft_pl + NIq + TS * ln + r);
                 const v2f tre = f2 * pre, tim = f2 * pim;
