@@ -124,12 +124,12 @@ def test_large_batch_picks_the_kernel_by_itself():
     rx.close()
 
 
-@pytest.mark.parametrize("group,nd,hlp,slices", [(2, 1, 0, 0), (4, 2, 0, 0), (3, 2, 0, 0), (1, 2, 0, 0), (1, 2, 1, 0), (1, 2, 1, 1), (4, 2, 0, 1), (2, 1, 0, 1)])
+@pytest.mark.parametrize("group,nd,hlp,slices", [(2, 1, 0, 0), (4, 2, 0, 0), (3, 2, 0, 0), (2, 2, 0, 0), (1, 2, 0, 0), (1, 2, 1, 0), (1, 2, 1, 1), (4, 2, 0, 1), (3, 2, 0, 1), (2, 2, 0, 1), (2, 1, 0, 1)])
 def test_exact_mode_4fsk_ts32_equals_oracle(group, nd, hlp, slices, monkeypatch):
     """The large geometry of the batch kernel (BASELINE config 4: 4-FSK, Rs 57 600, Fs 1 843 200 -> Ts 32, 1024-point estimator, two
     soft decisions per symbol), forced here: every capture equals the oracle bit for bit, slips and ragged ends included -- with one duty
     wavefront per workgroup (chains and sums in turn) and with two (a chain wave and a sum wave, the chain pass straddling the barrier: what
-    the library picks from three captures per CU on)."""
+    the library picks for every batch size since round 3: one to four captures per workgroup)."""
     monkeypatch.setenv("WENET_RX_OCT", str(group))
     monkeypatch.setenv("WENET_RX_OCT_ND", str(nd))
     monkeypatch.setenv("WENET_RX_OCT_HLP", str(hlp))                 # 1: the capture's mix stage on four wavefronts, a tone each (the single-stream form)
