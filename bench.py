@@ -285,8 +285,9 @@ def main():
         roof = {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
                 "algorithmic_bytes_per_launch": round(ALGO_BYTES_PER_SAMPLE * B * nsamp), "avg_launch_ms": round(k_ms[0], 3),
-                "limiter": "VALU instruction issue, not HBM: the order-dependent float recurrences of the reference (NCO chain, slot-ordered "
-                           "integrator, timing sum) are replayed exactly; see `valu`"}
+                "limiter": "not HBM and not issue slots: the order-dependent float recurrences of the reference (NCO chain, slot-ordered integrator, "
+                           "timing sum) are replayed exactly, and a workgroup's frame is as long as its two serial instruction streams -- the duty "
+                           "wave's chain + ordered sums, the slowest capture wave's mix stage + transform (DESIGN.md 4.1); see `valu`, `ceilings`"}
         if prof is not None:
             roof["traffic"] = round(prof["hbm_bytes_per_iq_sample"] * B * nsamp)
             roof["traffic_source"] = (f"{prof['file']}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH_SIZE x2 on gfx950) of {kernel_name} "
