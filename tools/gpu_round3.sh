@@ -27,6 +27,8 @@ done
   echo "## captures of 0..6 frames"
   WENET_RX_OCT=7 python tools/soak_short.py 2>&1 | tail -1
 } > gpurun_out/r03_soak.txt 2>&1
+python tools/sweep.py --config v2 --n 3584 --bins 17 --check-cpu 6 > gpurun_out/r03_config3_sweep3584_v2.md 2>&1
+for c in v1 v2; do python tools/robustness.py --config $c > gpurun_out/r03_robustness_$c.md 2>&1; done
 python tools/host_feed.py 768 10 > gpurun_out/r03_host_feed.txt 2>&1; python tools/host_feed.py 256 10 >> gpurun_out/r03_host_feed.txt 2>&1; python tools/host_feed.py 3584 10 >> gpurun_out/r03_host_feed.txt 2>&1
 { echo "# cycle stamps of the batch demodulator (instrumented build, tools/prof_build.sh; ~10 % slower than the product), per frame"
   echo "## 3584 captures x 2 s, seven captures + one duty wave per workgroup, two workgroups per CU"; WENET_RX_LIB=tools/prof_build/libwenet_rx.so python tools/gpu_oct_prof.py 3584 2 7 v2 2>&1 | grep -v amdgpu.ids | head -9
