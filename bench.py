@@ -134,6 +134,9 @@ def load_pmc_profile(kernel_name, inst, captures):
     sources this process runs (wenet_amd/codeid.py, stamped by tools/gpu_profile_round.sh)."""
     from wenet_amd import codeid
     here = codeid.source_sha16()
+    if codeid.library_source_id() != here:             # the loaded libwenet_rx.so was built from OTHER sources (stale build): no profile speaks for it
+        print(f"bench.py: libwenet_rx.so was built from sources {codeid.library_source_id()}, the tree holds {here}: rebuild (make -C wenet_amd/csrc)", file=sys.stderr)
+        return None
     best = None
     # (profiles/: committed; gpurun_out/: the profile a profiling round has just written on the GPU box, before it is copied and committed)
     for pj in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_*.json")) + glob.glob(os.path.join(ROOT, "gpurun_out", "r*_pmc_*.json"))):
@@ -167,10 +170,15 @@ def main():
     ap.add_argument("--max-iter", type=int, default=10, help="LDPC MAX_ITER (10 in the reference CLIs; BASELINE config 4 asks for 50)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the other_workloads block (slipping signal, host-fed, one capture)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="drive --gpus N devices from ONE process: N handles (one per device) on N host threads, no torch.distributed (SURVEY.md 7-8's "
+                         "'one host thread + stream set per GPU'); devices are shared modulo the device count when the box has fewer")
     ap.add_argument("--no-single-stream", action="store_true", help="(kept for the profiling scripts: implies nothing else is launched after the timed steps)")
     args = ap.parse_args()
     if args.no_single_stream:
         args.no_extras = True
+
+    import threading
 
     import torch
     from wenet_amd import siggen
@@ -180,96 +188,186 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    dist_note = None
     if world > 1:
+        if args.single_process:
+            raise SystemExit("--single-process drives every GPU from ONE process: do not launch it under torch.distributed.run")
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("WENET_BENCH_BACKEND", "nccl")          # "gloo" lets two ranks share one GPU in tests
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1)))
+            # RCCL carries only the timing barrier / max / gather of this bench (no collective on the data path): if it cannot be brought up
+            # the measurement is still valid over gloo -- fall back and say so in the line instead of losing the run
+            try:
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1)))
+                probe = torch.zeros(1, device=torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1)))
+                dist.all_reduce(probe)                                   # (the communicator is built lazily: make it fail HERE if it is going to)
+                torch.cuda.synchronize()
+            except Exception as e:
+                dist_note = f"nccl (RCCL) initialisation failed on rank {rank}: {str(e)[:160]}; timing collectives over gloo instead"
+                print("bench.py: " + dist_note, file=sys.stderr)
+                try:
+                    if dist.is_initialized():
+                        dist.destroy_process_group()
+                except Exception:
+                    pass
+                if os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "").lower() != "true":       # (launched by hand: rank 0 hosted the store of the failed group
+                    os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)    #  and may still hold the port; under torch.distributed.run the agent hosts it)
+                dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend=backend)
     ndev = max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(local_rank % ndev)
-    dev = torch.device("cuda", local_rank % ndev)
-
     cfg = siggen.CONFIGS[args.config]()
     nsym = int(args.seconds * cfg.Rs)
     nsamp = nsym * cfg.Ts
-    # which captures this rank owns: its own --captures (weak scaling: per-GPU work fixed), or its round-robin share of --total-captures
-    if args.total_captures > 0:
-        from wenet_amd.shard import shard_indices
-        mine = shard_indices(args.total_captures, rank, world)           # global capture indices of this rank
-        n_all = args.total_captures
-    else:
-        mine = [rank * args.captures + i for i in range(args.captures)]
-        n_all = world * args.captures
-    B = len(mine)
-    if B == 0:
-        raise SystemExit(f"rank {rank}: no capture to process (--total-captures {args.total_captures} over {world} ranks)")
-    ebnos = [4.0 + 8.0 * g / max(n_all - 1, 1) for g in mine] if args.sweep else [args.ebno] * B
-    # synthetic captures, born in HBM: random payloads -> frames -> M-FSK + AWGN by the library's own generator
-    # kernels (include/wenet_tx.h; format pinned in tests/test_gpu_tx.py).  torch only owns the memory.
-    from wenet_amd.tx import Tx
-    tx = Tx.from_config(cfg)
-    spp = tx.symbols_per_packet
-    nfr = nsym // spp + 1
-    g = torch.Generator(device=dev)
-    g.manual_seed(2001 + 1000 * rank)
-    payloads = torch.randint(0, 256, (B * nfr, 256), dtype=torch.uint8, device=dev, generator=g)
-    symbols = torch.empty(B * nfr * spp, dtype=torch.uint8, device=dev)
-    tx.frame_packets_device(payloads.data_ptr(), B * nfr, symbols.data_ptr())
-    caps = [torch.empty(2 * nsamp, dtype=torch.uint8, device=dev) for _ in range(B)]
-    sym_ptrs = [symbols.data_ptr() + i * nfr * spp for i in range(B)]
-    seeds = [7000 + g for g in mine] if args.total_captures > 0 else [7000 + i + 100000 * rank for i in range(B)]
+    # one process, N GPUs ("one host thread + stream set per device"): N workers, each on its own device with its own handle
+    # (wenet_rx handles are per device, include/wenet_rx.h), driven by N host threads -- ctypes releases the GIL inside the library calls.
+    # On a box with fewer GPUs than workers the devices are shared (index mod device count), as the multi-rank tests do.
+    nwork = args.gpus if args.single_process else 1
+    jobs = nwork if args.single_process else world                      # "ranks" of the job, for sharding and the line
 
-    def modulate(ppm):
-        torch.cuda.synchronize()
-        tg = time.perf_counter()
-        tx.modulate_device(sym_ptrs, [nsym] * B, [c.data_ptr() for c in caps], ebnos, ppm=(ppm if ppm else None), seeds=seeds)
-        torch.cuda.synchronize()
-        return time.perf_counter() - tg
+    class Worker:
+        """one rank's share of the job on one device: synthetic captures born in HBM, the handle, the step"""
 
-    datagen_s = modulate(args.ppm)
-    ptrs = [int(c.data_ptr()) for c in caps]
-    ns = [nsamp] * B
+        def __init__(self, r):
+            self.r = r
+            self.dev = torch.device("cuda", (r if args.single_process else local_rank) % ndev)
+            torch.cuda.set_device(self.dev)                              # (per host thread)
+            # which captures this rank owns: its own --captures (weak scaling: per-GPU work fixed), or its round-robin share of --total-captures
+            if args.total_captures > 0:
+                from wenet_amd.shard import shard_indices
+                self.mine = shard_indices(args.total_captures, r, jobs)  # global capture indices of this rank
+            else:
+                self.mine = [r * args.captures + i for i in range(args.captures)]
+            B = self.B = len(self.mine)
+            if B == 0:
+                raise SystemExit(f"rank {r}: no capture to process (--total-captures {args.total_captures} over {jobs} ranks)")
+            n_all_ = args.total_captures if args.total_captures > 0 else jobs * args.captures
+            self.ebnos = [4.0 + 8.0 * g / max(n_all_ - 1, 1) for g in self.mine] if args.sweep else [args.ebno] * B
+            # synthetic captures, born in HBM: random payloads -> frames -> M-FSK + AWGN by the library's own generator
+            # kernels (include/wenet_tx.h; format pinned in tests/test_gpu_tx.py).  torch only owns the memory.
+            from wenet_amd.tx import Tx
+            self.tx = Tx.from_config(cfg)
+            spp = self.tx.symbols_per_packet
+            nfr = nsym // spp + 1
+            g = torch.Generator(device=self.dev)
+            g.manual_seed(2001 + 1000 * r)
+            payloads = torch.randint(0, 256, (B * nfr, 256), dtype=torch.uint8, device=self.dev, generator=g)
+            self.symbols = torch.empty(B * nfr * spp, dtype=torch.uint8, device=self.dev)
+            self.tx.frame_packets_device(payloads.data_ptr(), B * nfr, self.symbols.data_ptr())
+            self.caps = [torch.empty(2 * nsamp, dtype=torch.uint8, device=self.dev) for _ in range(B)]
+            self.sym_ptrs = [self.symbols.data_ptr() + i * nfr * spp for i in range(B)]
+            self.seeds = [7000 + g for g in self.mine] if args.total_captures > 0 else [7000 + i + 100000 * r for i in range(B)]
+            self.datagen_s = self.modulate(args.ppm)
+            self.ptrs = [int(c.data_ptr()) for c in self.caps]
+            self.ns = [nsamp] * B
+            self.rx = RxBatch(cfg.Fs, cfg.Rs, cfg.M, framing=cfg.mode, max_iter=args.max_iter)
 
-    rx = RxBatch(cfg.Fs, cfg.Rs, cfg.M, framing=cfg.mode, max_iter=args.max_iter)
+        def modulate(self, ppm):
+            torch.cuda.synchronize()
+            tg = time.perf_counter()
+            self.tx.modulate_device(self.sym_ptrs, [nsym] * self.B, [c.data_ptr() for c in self.caps], self.ebnos, ppm=(ppm if ppm else None), seeds=self.seeds)
+            torch.cuda.synchronize()
+            return time.perf_counter() - tg
 
-    def step(r=rx, p=ptrs, n=ns):
-        r.enqueue_device(p, n, "cu8")
-        r.collect()
+        def step(self, r=None, p=None, n=None):
+            r = r or self.rx
+            r.enqueue_device(p if p is not None else self.ptrs, n if n is not None else self.ns, "cu8")
+            r.collect()
+
+        def timed(self, nsteps, r=None, p=None, n=None):
+            """nsteps passes; returns (seconds, mean kernel ms [demod, deframe, decode, total])"""
+            r = r or self.rx
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            k = np.zeros(4)
+            for _ in range(nsteps):
+                self.step(r, p, n)
+                k += [r.last_ms(i) for i in range(4)]
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0, k / max(nsteps, 1)
 
     def sync():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
 
-    def timed(nsteps, r=rx, p=ptrs, n=ns):
-        """nsteps passes; returns (seconds, mean kernel ms [demod, deframe, decode, total])"""
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        k = np.zeros(4)
-        for _ in range(nsteps):
-            step(r, p, n)
-            k += [r.last_ms(i) for i in range(4)]
-        torch.cuda.synchronize()
-        return time.perf_counter() - t0, k / max(nsteps, 1)
+    if args.single_process:
+        # N host threads, one per worker: set-up, warm-up, a thread barrier, K timed steps each, a barrier; the job's time is the slowest thread's
+        workers = [None] * nwork
+        dts = [0.0] * nwork
+        kms = [None] * nwork
+        errs = []
+        bar = threading.Barrier(nwork)
 
-    for _ in range(args.warmup):
-        step()
-    sync()
-    t0 = time.perf_counter()
-    k_ms = np.zeros(4)
-    for _ in range(args.steps):
-        step()
-        k_ms += [rx.last_ms(i) for i in range(4)]
-    sync()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    k_ms /= max(args.steps, 1)
+        def run(i):
+            try:
+                w = workers[i] = Worker(i)
+                for _ in range(args.warmup):
+                    w.step()
+                torch.cuda.synchronize()
+                bar.wait()
+                t0 = time.perf_counter()
+                k = np.zeros(4)
+                for _ in range(args.steps):
+                    w.step()
+                    k += [w.rx.last_ms(j) for j in range(4)]
+                torch.cuda.synchronize()
+                dts[i] = time.perf_counter() - t0
+                kms[i] = k / max(args.steps, 1)
+                bar.wait()
+            except BaseException as e:                                  # (a failed worker must not leave the others at the barrier)
+                errs.append((i, repr(e)))
+                bar.abort()
+
+        th = [threading.Thread(target=run, args=(i,)) for i in range(nwork)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if errs:
+            raise SystemExit(f"--single-process worker(s) failed: {errs}")
+        W = workers[0]
+        torch.cuda.set_device(W.dev)
+        dt = max(dts)
+        k_ms = kms[0]
+        per_rank_ms = [round(x / args.steps * 1e3, 3) for x in dts]
+        valid = [sum(int(w.rx.packets(c)["crc_ok"].sum()) for c in range(w.B)) for w in workers]
+        npk_valid_total = sum(valid)
+        world_line = nwork
+    else:
+        W = Worker(rank)
+        for _ in range(args.warmup):
+            W.step()
+        sync()
+        t0 = time.perf_counter()
+        k_ms = np.zeros(4)
+        for _ in range(args.steps):
+            W.step()
+            k_ms += [W.rx.last_ms(i) for i in range(4)]
+        sync()
+        dt_own = dt = time.perf_counter() - t0
+        k_ms /= max(args.steps, 1)
+        per_rank_ms = [round(dt / args.steps * 1e3, 3)]
+        npk_valid_total = sum(int(W.rx.packets(c)["crc_ok"].sum()) for c in range(W.B))
+        if dist is not None:
+            on = W.dev if dist.get_backend() == "nccl" else "cpu"
+            t = torch.tensor([dt], dtype=torch.float64, device=on)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+            # every rank's own time and CRC-valid packets (a straggler, or a rank that decoded nothing, must show in the line)
+            mine_t = torch.tensor([dt_own, float(npk_valid_total)], dtype=torch.float64, device=on)
+            allr = [torch.zeros_like(mine_t) for _ in range(world)]
+            dist.all_gather(allr, mine_t)
+            per_rank_ms = [round(float(x[0]) / args.steps * 1e3, 3) for x in allr]
+            tot = torch.tensor([float(npk_valid_total)], dtype=torch.float64, device=on)
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            npk_valid_total = int(tot.item())
+        world_line = world
+    rx, B, caps, ptrs, ns = W.rx, W.B, W.caps, W.ptrs, W.ns
+    step, timed, modulate = W.step, W.timed, W.modulate
+    datagen_s = W.datagen_s
+    n_all = args.total_captures if args.total_captures > 0 else jobs * args.captures
 
     npk_valid = sum(int(rx.packets(c)["crc_ok"].sum()) for c in range(B))
     npk_all = sum(rx.npackets(c) for c in range(B))
@@ -307,26 +405,32 @@ def main():
                                     "note": "valu = the measured rate / calibrated VALU utilisation: the rate at which THIS kernel's instruction stream would saturate the SIMDs"}
         line = {
             "metric": "IQ Msamples/s demod+LDPC-decoded", "value": round(value, 3), "unit": "Msamples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world_line, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong" if args.total_captures > 0 else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "mode": "exact (bit-identical to the reference pipe)",
             "datagen": {"by": "wenet_tx_modulate (GPU)", "ms": round(datagen_s * 1e3, 1),
                         "gsamples_per_s": round(B * nsamp / datagen_s / 1e9, 2)},
             "config": {"workload": f"{cfg.name} {cfg.M}-FSK Rs={cfg.Rs} Fs={cfg.Fs} cu8 Eb/N0={'4..12 dB sweep' if args.sweep else str(args.ebno) + 'dB'} "
-                                   + (f"{args.seconds:g}s x {n_all} captures in all, capture i on rank i mod {world} (BASELINE config {3 if args.sweep else 5} shape)"
+                                   + (f"{args.seconds:g}s x {n_all} captures in all, capture i on rank i mod {world_line} (BASELINE config {3 if args.sweep else 5} shape)"
                                       if args.total_captures > 0 else
                                       f"{args.seconds:g}s x {B} independent captures per GPU (BASELINE config {4 if cfg.M == 4 else 2} shape, batched)")
                                    + (f", {args.ppm:g} ppm symbol-clock error" if args.ppm else ""),
                        "captures_per_gpu": B, "samples_per_capture": nsamp, "framing": cfg.mode, "ldpc_max_iter": args.max_iter},
             "x_realtime_aggregate": round(value * 1e6 / cfg.Fs, 1),
-            "packets_per_s": round(world * npk_valid * args.steps / dt, 1),
+            "packets_per_s": round(npk_valid_total * args.steps / dt, 1),
             "packets_valid_per_step_rank0": npk_valid, "packets_found_per_step_rank0": npk_all,
+            "packets_valid_total": npk_valid_total,                   # all ranks (all-reduced): a rank that decoded nothing shows here
+            "per_rank_ms": per_rank_ms,                               # every rank's own ms per step (gathered); ms_per_step is their maximum
+            "launch": ("single process, one host thread + handle per device" if args.single_process else
+                       (f"{world} ranks, torch.distributed backend {dist.get_backend()}" if dist is not None else "one rank")),
             "kernel_ms": {"demod": round(k_ms[0], 3), "deframe": round(k_ms[1], 3), "decode": round(k_ms[2], 3),
                           "gpu_total": round(k_ms[3], 3)},
             "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if dist_note:
+            line["dist_note"] = dist_note
+        if world_line == 1 and not args.no_cpu_baseline:
             ncpu = max(1, min(B, (os.cpu_count() or 2) // 2))              # leg (c) fills the host: one two-process pipe per pair of logical CPUs
             caps_host = [caps[i].cpu().numpy() for i in range(ncpu)]
             if args.max_iter == 10:
@@ -344,7 +448,7 @@ def main():
                                                         f"the timed GPU steps decode with MAX_ITER {args.max_iter}")
         else:
             line["cpu_baseline"] = None
-        if world == 1 and not args.no_extras:
+        if world_line == 1 and not args.no_extras:
             other = {}
             # one capture alone (BASELINE config 2 taken literally: the '>= 50x real time on one stream' target)
             single = RxBatch(cfg.Fs, cfg.Rs, cfg.M, framing=cfg.mode, max_iter=args.max_iter)

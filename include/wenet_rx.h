@@ -220,6 +220,9 @@ float wenet_rx_last_ms(wenet_rx *rx, int what);
  * GPU, a single process may equally keep one handle (and one host thread) per GPU. */
 int wenet_rx_device_info(int what);
 const char *wenet_rx_version(void);
+/* identity of the kernel sources this library was built from (16 hex digits; wenet_amd/codeid.py computes the same hash over the source files:
+ * a measurement is attributed to the sources only when the two agree, i.e. the library is not a stale build) */
+const char *wenet_rx_source_id(void);
 
 /* self-test: phi0 (src/phi0.c:13-218) exactly as the decode kernel evaluates it on the device (keyed LDS tables), y[i] = phi0(x[i]) for n
  * host floats.  0 on success.  (The library also checks the tables on the host against the reference form when it builds them.) */

@@ -82,3 +82,33 @@ def test_config5_shape_eight_ranks_on_one_gpu_over_gloo():
     nsamp = d["config"]["samples_per_capture"]
     assert abs(d["value"] - 128 * nsamp * 2 / (d["ms_per_step"] * 2e-3) / 1e6) < 1e-3 * d["value"]
     assert d["packets_valid_per_step_rank0"] > 0
+
+
+def test_two_ranks_default_backend_falls_back_when_rccl_cannot_start():
+    """The driver's multi-GPU run takes bench.py's default backend (nccl = RCCL).  Two ranks on ONE GPU is a set-up RCCL refuses (or, where it
+    accepts it, runs): either way the run must finish and print its line -- over RCCL, or over gloo with `dist_note` saying so -- with every rank's
+    own time and the all-reduced packet count in it."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WENET_BENCH_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29527",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--captures", "16", "--seconds", "1", "--steps", "2", "--warmup", "1"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _line(r.stdout)
+    assert d["n_gpus"] == 2 and len(d["per_rank_ms"]) == 2 and all(x > 0 for x in d["per_rank_ms"])
+    assert abs(max(d["per_rank_ms"]) - d["ms_per_step"]) < 0.05 * d["ms_per_step"]
+    assert d["packets_valid_total"] >= 2 * d["packets_valid_per_step_rank0"] - 2          # both ranks decoded (same workload shape, different seeds)
+    assert ("gloo" in d["launch"]) == ("dist_note" in d)
+
+
+def test_single_process_two_handles_on_two_host_threads():
+    """`--single-process --gpus 2`: two handles driven by two host threads of one process (one per device; the same device twice on a one-GPU box) --
+    the bench-shaped caller of the per-device contexts (tests/test_gpu_units.py::test_two_handles_one_process_two_devices)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--single-process", "--gpus", "2", "--captures", "16", "--seconds", "1",
+                        "--steps", "2", "--warmup", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _line(r.stdout)
+    assert d["n_gpus"] == 2 and len(d["per_rank_ms"]) == 2 and "single process" in d["launch"] and d["cpu_baseline"] is None
+    nsamp = d["config"]["samples_per_capture"]
+    assert abs(d["value"] - 2 * 16 * nsamp * 2 / (d["ms_per_step"] * 2e-3) / 1e6) < 1e-3 * d["value"]
+    assert d["packets_valid_total"] > d["packets_valid_per_step_rank0"] > 0

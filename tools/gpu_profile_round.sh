@@ -27,6 +27,8 @@ if "--config" in sys.argv: cfg = sys.argv[sys.argv.index("--config") + 1]
 Fs = {"v2": 960000, "v1": 921416, "4fsk": 1843200}[cfg]
 N = {"v2": 480, "v1": 384, "4fsk": 1536}[cfg]
 NS = B * int(secs * Fs)
+if codeid.library_source_id() != codeid.source_sha16():
+    sys.exit(f"libwenet_rx.so was built from {codeid.library_source_id()}, the tree holds {codeid.source_sha16()}: a profile of a stale build is not written")
 acc = {}
 for f in glob.glob(f"{root}/pmc_{tag}_*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
@@ -42,7 +44,7 @@ out = {"note": "rocprofv3 --pmc, one pass per counter set (FETCH_SIZE | WRITE_SI
                     "cycles of a saturated SIMD from profiles/r03_valu_calibration.json (tools/ubench/pmc_cal.hip); packed = SQ_INSTS_VALU_FLOPS_FP32 - ADD_F32 - MUL_F32 - "
                     "2 FMA_F32 (a packed add / multiply counts two flops and one instruction there).  It cannot exceed 1.  The round-2 figure valu_busy (every instruction "
                     "taken as 4 cycles) is kept beside it for comparison.",
-       "source_sha16": codeid.source_sha16(), "library_sha16": codeid.library_sha16(),
+       "source_sha16": codeid.source_sha16(), "library_sha16": codeid.library_sha16(), "library_source_id": codeid.library_source_id(),
        "captures": B, "samples_in_launch": NS, "kernels": {}}
 for k, d in acc.items():
     e = dict(d)

@@ -28,6 +28,14 @@ def source_sha16():
     return h.hexdigest()[:16]
 
 
+def library_source_id():
+    """source_sha16() of the sources libwenet_rx.so was BUILT from (the Makefile compiles it in: wenet_rx_source_id()).  A profile or a bench
+    line may speak for the current sources only if this equals source_sha16() -- otherwise the library is a stale build."""
+    from . import lib
+    L = lib.load()
+    return L.wenet_rx_source_id().decode()
+
+
 def library_sha16():
     p = os.path.join(ROOT, "wenet_amd", "libwenet_rx.so")
     return hashlib.sha256(open(p, "rb").read()).hexdigest()[:16] if os.path.exists(p) else None
@@ -42,3 +50,7 @@ def hipcc_version():
     except Exception:
         pass
     return "unknown"
+
+
+if __name__ == "__main__":
+    print(source_sha16())

@@ -21,6 +21,7 @@
 
 #include "../../include/wenet_rx.h"
 #include "wenet_internal.h"
+#include "srcid.h"
 
 #pragma clang fp contract(off)
 
@@ -1007,12 +1008,14 @@ __global__ __launch_bounds__(256) void wenet_quantise_kernel(const WrQuantJob *j
 // Host-fed batches arrive in TIME slices (rx_enqueue): after the demodulator launch over a slice this kernel moves every capture's table entry on to
 // where that launch stopped -- the samples it consumed (whole frames; what is left over is demodulated with the next slice), the soft decisions
 // and trace rows it wrote, the frames it used of the cap -- and admits the samples of the next slice.  No host round trip between the launches.
-struct WrSliceInfo { const char *base; long long total; };
-__global__ __launch_bounds__(256) void wenet_advance_kernel(WrChan *chans, const WrSliceInfo *info, int nchan, long long next_end, int bps, int nbits) {
+struct WrSliceInfo { const char *base; long long total; int slips_acc, allout_acc; };     // + the slip / park-all counts of the launches before the last one
+__global__ __launch_bounds__(256) void wenet_advance_kernel(WrChan *chans, WrSliceInfo *info, int nchan, long long next_end, int bps, int nbits) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nchan) return;
     WrChan &c = chans[i];
     const WrChanHdr *h = (const WrChanHdr *)c.state;
+    info[i].slips_acc += h->slips_call;                               // (every launch overwrites its per-launch counters: keep the batch's totals)
+    info[i].allout_acc += h->allout_call;
     const long long done = ((const char *)c.raw - info[i].base) / bps + h->consumed_call;
     const long long end = info[i].total < next_end ? info[i].total : next_end;
     c.raw = info[i].base + done * bps;
@@ -1073,6 +1076,7 @@ struct wenet_rx {
         return part_ev[i];
     }
     bool pending = false;
+    bool sliced = false;                    // the batch in flight / last collected was demodulated in time slices (counters accumulate in d_slices)
     bool chunk_events(int n) {
         while ((int)cev.size() < n) {
             ChunkEv c;
@@ -1330,9 +1334,10 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw_in, const 
         nslices = nslices < 1 ? 1 : (nslices > 32 ? 32 : nslices);
     }
     const long long slice_len = (max_ns + nslices - 1) / nslices;
+    rx->sliced = nslices > 1;
     if (nslices > 1) {
         std::vector<WrSliceInfo> info(nchan);
-        for (int i = 0; i < nchan; i++) { info[i].base = (const char *)raw[i]; info[i].total = nsamples[i]; }
+        for (int i = 0; i < nchan; i++) { info[i].base = (const char *)raw[i]; info[i].total = nsamples[i]; info[i].slips_acc = 0; info[i].allout_acc = 0; }
         if (!rx->d_slices.reserve(sizeof(WrSliceInfo) * nchan)) return -2;
         WR_CHECK(hipMemcpy(rx->d_slices.p, info.data(), sizeof(WrSliceInfo) * nchan, hipMemcpyHostToDevice), -3);
         // the first launch sees the first slice only
@@ -1364,16 +1369,21 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw_in, const 
             WR_CHECK(hipEventRecord(e.copied, rx->copy_stream), -4);
             WR_CHECK(hipStreamWaitEvent(stream, e.copied, 0), -4);
         }
-        if (nslices > 1) {                                              // every upload is queued now, slice by slice, each slice with its event
+        // host-fed time slices: the uploads of slice sl are queued right before the launch that consumes it (below) -- hipMemcpyAsync from PAGEABLE
+        // memory blocks the calling thread until the runtime has staged the bytes, so queueing every upload first (round 3) let only callers with
+        // pinned buffers overlap transfers and kernels
+        auto queue_slice = [&](int sl) -> int {
             const size_t bps = (size_t)kBytesPerSample[fmt_in];
-            for (int sl = 0; sl < nslices; sl++) {
-                for (int i = lo; i < hi; i++) {
-                    const long long a = std::min<long long>(nsamples[i], (long long)sl * slice_len), b = std::min<long long>(nsamples[i], (long long)(sl + 1) * slice_len);
-                    if (b > a) WR_CHECK(hipMemcpyAsync((char *)raw_in[i] + (size_t)a * bps, (const char *)host_src[i] + (size_t)a * bps, (size_t)(b - a) * bps,
-                                                       hipMemcpyHostToDevice, rx->copy_stream), -3);
-                }
-                WR_CHECK(hipEventRecord(rx->slice_ev[sl], rx->copy_stream), -4);
+            for (int i = lo; i < hi; i++) {
+                const long long a = std::min<long long>(nsamples[i], (long long)sl * slice_len), b = std::min<long long>(nsamples[i], (long long)(sl + 1) * slice_len);
+                if (b > a) WR_CHECK(hipMemcpyAsync((char *)raw_in[i] + (size_t)a * bps, (const char *)host_src[i] + (size_t)a * bps, (size_t)(b - a) * bps,
+                                                   hipMemcpyHostToDevice, rx->copy_stream), -3);
             }
+            WR_CHECK(hipEventRecord(rx->slice_ev[sl], rx->copy_stream), -4);
+            return 0;
+        };
+        if (nslices > 1) {
+            if (int rc = queue_slice(0)) return rc;
             WR_CHECK(hipStreamWaitEvent(stream, rx->slice_ev[0], 0), -4);
         }
         if (quant) {
@@ -1403,7 +1413,8 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw_in, const 
             if (rest.use_oct) WR_CHECK(wr_launch_demod_oct(&rest.oct_cfg, rx->d_chans.as<WrChan>() + lo + full, n - full, stream), -4);
             else WR_CHECK(wr_launch_demod_ex(&rest.launch_cfg, rx->d_chans.as<WrChan>() + lo + full, n - full, stream, 0), -4);
         }
-        for (int sl = 1; sl < nslices; sl++) {                          // the further slices: move the table entries on, wait for the slice, demodulate on
+        for (int sl = 1; sl < nslices; sl++) {                          // the further slices: upload, move the table entries on, wait for the slice, demodulate on
+            if (int rc = queue_slice(sl)) return rc;
             hipLaunchKernelGGL(wenet_advance_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, rx->d_chans.as<WrChan>() + lo, rx->d_slices.as<WrSliceInfo>() + lo,
                                n, (long long)(sl + 1) * slice_len, kBytesPerSample[fmt_in], c.Nbits);
             WR_CHECK(hipGetLastError(), -4);
@@ -1460,11 +1471,19 @@ extern "C" int wenet_rx_collect(wenet_rx *rx) {
     rx->h_dstates.resize(nchan);
     WR_CHECK(hipMemcpy(rx->h_states.data(), rx->d_states.p, (size_t)c.st_floats * 4 * nchan, hipMemcpyDeviceToHost), -3);
     WR_CHECK(hipMemcpy(rx->h_dstates.data(), rx->d_dstates.p, sizeof(WrDeframeState) * nchan, hipMemcpyDeviceToHost), -3);
+    if (rx->sliced) {   // host-fed time slices: every launch overwrote the per-launch counters -- add what the launches before the last one counted
+        std::vector<WrSliceInfo> info(nchan);
+        WR_CHECK(hipMemcpy(info.data(), rx->d_slices.p, sizeof(WrSliceInfo) * nchan, hipMemcpyDeviceToHost), -3);
+        for (int i = 0; i < nchan; i++) {
+            WrChanHdr *h = (WrChanHdr *)&rx->h_states[(size_t)i * c.st_floats];
+            h->slips_call += info[i].slips_acc; h->allout_call += info[i].allout_acc;
+        }
+    }
     {   // share of frames with a timing slip in this batch: the next launch of this handle picks its batch kernel by it
         long long fr = 0, sl = 0;
         for (int i = 0; i < nchan; i++) {
             const WrChanHdr *h = (const WrChanHdr *)&rx->h_states[(size_t)i * c.st_floats];
-            fr += h->frames_call; sl += h->slips_call;
+            fr += h->frames_total; sl += h->slips_call;             // (fresh state per batch: frames_total = the batch's frames, however many launches made them)
         }
         rx->slip_rate = fr > 0 ? (double)sl / (double)fr : 0.0;
     }
@@ -1580,6 +1599,7 @@ extern "C" long long wenet_rx_get_soft(wenet_rx *rx, int ch, float *sd, long lon
     if (fr < 0) return fr;
     long long n = fr * rx->tab.cfg.Nbits;
     if (n > cap) n = cap;
+    DeviceGuard dg(rx->device);
     if (n > 0) WR_CHECK(hipMemcpy(sd, rx->d_sd.as<float>() + rx->sd_off[ch], (size_t)n * 4, hipMemcpyDeviceToHost), -3);
     return n;
 }
@@ -1587,6 +1607,7 @@ extern "C" long long wenet_rx_get_trace(wenet_rx *rx, int ch, float *trace, long
     long long fr = wenet_rx_frames(rx, ch);
     if (fr < 0 || !rx->want_trace) return -1;
     if (fr > cap_frames) fr = cap_frames;
+    DeviceGuard dg(rx->device);
     if (fr > 0) WR_CHECK(hipMemcpy(trace, rx->d_trace.as<float>() + (rx->sd_off[ch] / rx->tab.cfg.Nbits) * WR_TRACE_FLOATS,
                                     (size_t)fr * WR_TRACE_FLOATS * 4, hipMemcpyDeviceToHost), -3);
     return fr;
@@ -1595,6 +1616,7 @@ extern "C" long long wenet_rx_get_llrs(wenet_rx *rx, int ch, float *llr, long lo
     long long n = wenet_rx_packets(rx, ch);
     if (n < 0 || !rx->want_llr) return -1;
     if (n > cap_packets) n = cap_packets;
+    DeviceGuard dg(rx->device);
     if (n > 0) WR_CHECK(hipMemcpy(llr, rx->d_llr.as<float>() + (size_t)ch * rx->max_pk * WR_NCODE, (size_t)n * WR_NCODE * 4, hipMemcpyDeviceToHost), -3);
     return n;
 }
@@ -1648,4 +1670,5 @@ extern "C" int wenet_phi0_eval(const float *x, float *y, long n) {
     WR_CHECK(hipMemcpy(y, dy.p, (size_t)n * 4, hipMemcpyDeviceToHost), -3);
     return 0;
 }
-extern "C" const char *wenet_rx_version(void) { return "wenet_rx 0.1 (gfx950)"; }
+extern "C" const char *wenet_rx_version(void) { return "wenet_rx 0.4 (gfx950)"; }
+extern "C" const char *wenet_rx_source_id(void) { return WR_SOURCE_ID; }

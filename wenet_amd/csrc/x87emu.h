@@ -14,7 +14,7 @@
 #pragma once
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define WX_HD __host__ __device__ __forceinline__
 #else
 #define WX_HD static inline
