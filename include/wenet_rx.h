@@ -160,6 +160,21 @@ int wenet_rx_process(wenet_rx *rx, int nchan, const void *const *raw, const long
 int wenet_rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const long long *nsamples,
                      int fmt, void *stream);
 int wenet_rx_collect(wenet_rx *rx);
+/* ---- live channels (own design): nchan streams fed in ticks, everything a tick leaves undone carried on the GPU ----
+ * Per channel the semantics of the reference's two loops: src/fsk_demod.c:270-413 (read fsk_nin() samples, demodulate, write the soft decisions;
+ * struct FSK carried) and the symbol loop of src/wenet_ldpc.c:171-258 / src/drs232_ldpc.c:176-274 (unique-word window and a packet in collection
+ * carried across reads).  wenet_rx_push appends chunk[c] (nsamples[c] samples of format fmt, HOST memory; 0 samples and a NULL pointer are fine)
+ * to channel c, demodulates every whole modem frame the channel now holds, searches the new soft decisions for unique words and decodes every
+ * packet that COMPLETED in this tick -- one demodulator, one deframer and one decoder launch for all channels.  The first push on an idle handle
+ * opens nchan channels with fresh modem and deframer state; later pushes must name the same nchan and fmt.  Returns the number of packets
+ * completed in this tick over all channels (>= 0), < 0 on error.  After a push the result getters below describe THIS TICK: wenet_rx_packets /
+ * wenet_rx_get_packets / _of_class / census / wenet_rx_get_llrs = the packets completed in it (start_symbol = position in the channel's whole
+ * soft-decision stream), wenet_rx_get_soft / wenet_rx_get_trace = the frames demodulated in it, wenet_rx_frames = frames since the channel opened.
+ * The concatenation of all ticks' outputs equals one run of the reference pipe over the concatenated samples, bit for bit, however the
+ * stream was cut.  wenet_rx_flush ends the streams (EOF of the pipes: a partial frame and a packet still in collection are dropped, as the
+ * reference drops them) and leaves the handle idle; wenet_rx_process / wenet_rx_enqueue on a handle with open channels end them too. */
+long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *chunk, const long long *nsamples, int fmt);
+int wenet_rx_flush(wenet_rx *rx);
 /* results of the last process/collect */
 long long wenet_rx_frames(wenet_rx *rx, int ch);            /* modem frames demodulated */
 long long wenet_rx_packets(wenet_rx *rx, int ch);           /* packets completed (valid or not) */

@@ -1,0 +1,140 @@
+"""GPU: live channels (wenet_rx_push / wenet_rx_flush) -- N streams fed in ragged ticks with everything carried on the GPU must equal, per channel
+and bit for bit, ONE run of the oracle over the concatenated samples: soft decisions, packet bytes, iteration counts, CRC flags, LLRs and the
+packets' positions in the symbol stream.  (BASELINE config 5 taken as written: 128 CONCURRENT channels; per channel the loops of
+src/fsk_demod.c:270-413 and src/wenet_ldpc.c:171-258 / src/drs232_ldpc.c:176-274.)"""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from conftest import bits_equal
+from wenet_amd import siggen
+from wenet_amd.fsk import BYTES_PER_SAMPLE
+from wenet_amd.rx import RxBatch
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_live(cfg, caps, fmt, cuts, want_llr=False, max_iter=10):
+    """push every channel's capture in the ticks `cuts[ch]` gives (sample counts per tick, 0 allowed); returns per channel the concatenated results"""
+    n = len(caps)
+    bps = BYTES_PER_SAMPLE[fmt]
+    rx = RxBatch(cfg.Fs, cfg.Rs, cfg.M, framing=cfg.mode, max_iter=max_iter)
+    if want_llr:
+        rx.enable_llr_dump()
+    raw = [ol.raw_bytes(c) for c in caps]
+    pos = [0] * n
+    out = [dict(sd=[], bytes=[], iter=[], ok=[], start=[], llr=[]) for _ in range(n)]
+    nt = max(len(c) for c in cuts)
+    reported = 0
+    for t in range(nt):
+        chunks = []
+        for ch in range(n):
+            k = cuts[ch][t] if t < len(cuts[ch]) else 0
+            chunks.append(raw[ch][pos[ch] * bps:(pos[ch] + k) * bps])
+            pos[ch] += k
+        got = rx.push(chunks, fmt)
+        tick_pk = 0
+        for ch in range(n):
+            out[ch]["sd"].append(rx.soft(ch).copy())
+            p = rx.packets(ch)
+            tick_pk += p["n"]
+            if p["n"]:
+                out[ch]["bytes"].append(p["bytes"].copy()); out[ch]["iter"].append(p["iter"]); out[ch]["ok"].append(p["crc_ok"]); out[ch]["start"].append(p["start"])
+                if want_llr:
+                    out[ch]["llr"].append(rx.llrs(ch).copy())
+        assert got == tick_pk
+        reported += got
+    for ch in range(n):
+        assert pos[ch] * bps == raw[ch].size, "the cuts must cover the capture"
+    frames = [rx.frames(ch) for ch in range(n)]
+    rx.flush()
+    rx.close()
+    return out, frames, reported
+
+
+def _check(cfg, caps, fmt, out, frames, want_llr=False, max_iter=10):
+    total = 0
+    for ch, raw in enumerate(caps):
+        sd, _ = ol.oracle_demod(raw, fmt, cfg.Fs, cfg.Rs, cfg.M)
+        ref = ol.oracle_deframe(sd, cfg.mode, max_iter=max_iter, want_llr=want_llr)
+        got_sd = np.concatenate(out[ch]["sd"]) if out[ch]["sd"] else np.zeros(0, np.float32)
+        assert bits_equal(got_sd, sd), f"channel {ch}: soft decisions"
+        assert frames[ch] * (48 if cfg.M == 2 else 96) == sd.size
+        nb = sum(len(b) for b in out[ch]["bytes"])
+        assert nb == ref["n"], f"channel {ch}: {nb} packets, oracle {ref['n']}"
+        if nb:
+            assert (np.concatenate(out[ch]["bytes"]) == ref["bytes"]).all(), ch
+            assert (np.concatenate(out[ch]["iter"]) == ref["iter"]).all(), ch
+            assert (np.concatenate(out[ch]["ok"]) == ref["crc_ok"]).all(), ch
+            assert (np.concatenate(out[ch]["start"]) == ref["start"]).all(), ch
+            if want_llr:
+                assert bits_equal(np.concatenate(out[ch]["llr"]), ref["llr"]), ch
+        total += nb
+    return total
+
+
+def _ragged_cuts(rng, nsamp, mean):
+    cuts, left = [], nsamp
+    while left > 0:
+        k = int(rng.integers(0, 2 * mean))
+        if rng.random() < 0.1:
+            k = 0                                                         # a tick in which nothing arrived for this channel
+        k = min(k, left)
+        cuts.append(k)
+        left -= k
+    return cuts
+
+
+def test_128_channels_in_ragged_ticks_equal_the_oracle_one_shot():
+    cfg = siggen.config_v2()
+    rng = np.random.default_rng(77)
+    made = [siggen.make_capture(cfg, int(rng.integers(5, 9)), 8.0, seed=7700 + ch, ppm=float(rng.choice([0.0, 60.0, -90.0]))) for ch in range(128)]
+    caps = [m[0] for m in made]
+    cuts = [_ragged_cuts(rng, c.size // 2, 30000) for c in caps]            # ~31 ms ticks on average, anything from 0 to 62 ms
+    out, frames, reported = _run_live(cfg, caps, "cu8", cuts, want_llr=True)
+    total = _check(cfg, caps, "cu8", out, frames, want_llr=True)
+    assert reported == total and total > 0.7 * sum(len(m[1]) for m in made) - 128
+
+
+@pytest.mark.parametrize("name,fmt,mean", [("v1", "cu8", 9000), ("v2", "cs16", 1500), ("v2", "cf32", 50000), ("4fsk", "cu8", 40000)])
+def test_live_formats_framings_and_tiny_ticks(name, fmt, mean):
+    """ticks much shorter than a modem frame (several pushes per frame, many with no frame at all), every input format, both framings, 4-FSK"""
+    cfg = siggen.CONFIGS[name]()
+    rng = np.random.default_rng(abs(hash((name, fmt))) % 1000)
+    nch = 5
+    caps = [siggen.make_capture(cfg, 3, 9.0, seed=900 + ch, fmt=fmt, ppm=(150.0 if ch == 1 else 0.0))[0] for ch in range(nch)]
+    bps = BYTES_PER_SAMPLE[fmt]
+    cuts = [_ragged_cuts(rng, ol.raw_bytes(c).size // bps, mean) for c in caps]
+    out, frames, _ = _run_live(cfg, caps, fmt, cuts)
+    assert _check(cfg, caps, fmt, out, frames) > 0
+
+
+def test_live_many_channels_through_the_batch_demodulator(monkeypatch):
+    """enough channels that the per-tick launch takes the batch demodulator (one wavefront per capture) with carried state"""
+    monkeypatch.setenv("WENET_RX_OCT", "7")
+    cfg = siggen.config_v2()
+    rng = np.random.default_rng(5)
+    caps = [siggen.make_capture(cfg, 3, 8.5, seed=300 + ch, ppm=(200.0 if ch % 5 == 0 else 0.0))[0] for ch in range(23)]
+    cuts = [_ragged_cuts(rng, c.size // 2, 25000) for c in caps]
+    out, frames, _ = _run_live(cfg, caps, "cu8", cuts)
+    assert _check(cfg, caps, "cu8", out, frames) > 0
+
+
+def test_push_rejects_a_changed_channel_set_and_flush_reopens():
+    cfg = siggen.config_v2()
+    raw, _ = siggen.make_capture(cfg, 2, 12.0, seed=3)
+    rx = RxBatch(cfg.Fs, cfg.Rs, cfg.M, framing=cfg.mode)
+    rx.push([raw[:40000], raw[:40000]], "cu8")
+    with pytest.raises(RuntimeError):
+        rx.push([raw[:40000]], "cu8")                                       # one channel where two are open
+    with pytest.raises(RuntimeError):
+        rx.push([raw[:40000], raw[:40000]], "cs16")                         # another sample format
+    rx.flush()
+    got = rx.push([raw], "cu8")                                            # a fresh stream: the whole capture in one tick = the batch result
+    sd, _ = ol.oracle_demod(raw, "cu8", cfg.Fs, cfg.Rs, cfg.M)
+    ref = ol.oracle_deframe(sd, cfg.mode)
+    assert got == ref["n"] and bits_equal(rx.soft(0), sd) and (rx.packets(0)["bytes"] == ref["bytes"]).all()
+    # a batch on the same handle ends the live streams and still works
+    rx.process([raw], "cu8")
+    assert bits_equal(rx.soft(0), sd)
+    rx.close()

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(64) void wenet_deframe_kernel(const WrDeframeChan *
     if (ch >= nchan) return;
     const int lane = threadIdx.x;
     const WrDeframeChan C = chans[ch];
-    const long long n = C.nframes_src ? (*C.nframes_src) * (long long)C.nbits_per_frame : C.nsym;
+    const long long n = C.nframes_src ? C.nsym + (*C.nframes_src) * (long long)C.nbits_per_frame : C.nsym;      // (live channels: carried symbols + this tick's frames)
 
     // unique words, oldest bit first (drs232_ldpc.c:77-86: 0xAB 0xCD 0xEF 0x01 with RS232 start/stop
     // bits, LSB first; wenet_ldpc.c:77-82: the same bytes MSB first)

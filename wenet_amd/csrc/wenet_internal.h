@@ -169,8 +169,8 @@ struct WrDeframeState {
 
 struct WrDeframeChan {
     const float *sd;
-    long long    nsym;          // symbols available (ignored if nsym_src != null)
-    const long long *nframes_src;  // if non-null: nsym = *nframes_src * nbits_per_frame
+    long long    nsym;          // symbols available; with nframes_src: the symbols carried in front of this launch's frames (0 for a batch)
+    const long long *nframes_src;  // if non-null: symbols available = nsym + *nframes_src * nbits_per_frame
     int          nbits_per_frame;
     int          pad;
     WrDeframeState *state;

@@ -1075,6 +1075,12 @@ struct wenet_rx {
         }
         return part_ev[i];
     }
+    // ---- live channels (wenet_rx_push): state, unconsumed samples and undecided symbols carried from tick to tick ----
+    int live_n = 0, live_fmt = -1;
+    long long live_ticks = 0;
+    long long live_in_stride = 0, live_sd_stride = 0;   // bytes / floats between the channels' blocks in d_live_in / d_sd
+    std::vector<long long> live_carry_smp, live_carry_sym, live_sym_base, live_new_sym;   // host mirror, per channel
+    DevBuf d_live_in, d_live_meta;
     bool pending = false;
     bool sliced = false;                    // the batch in flight / last collected was demodulated in time slices (counters accumulate in d_slices)
     bool chunk_events(int n) {
@@ -1124,6 +1130,72 @@ extern "C" int wenet_rx_set_cf32_quantise(wenet_rx *rx, int to_fmt) {
     return 0;
 }
 
+// Which demodulator kernel for n_sel captures launched together (the whole batch; or, below, the full rounds and the remainder of a
+// device-resident batch separately):
+struct DemodChoice { bool use_oct; WrDemodCfg oct_cfg, launch_cfg; };
+static DemodChoice choose_demod(wenet_rx *rx, int n_sel, int fmt) {
+    const WrDemodCfg &c = rx->tab.cfg;
+    // every capture starts from reset state; with cu8 input the three-per-CU raw-ring variant applies
+    // ... when a third capture per CU is worth having; up to two per CU the float-ring variant (96 registers, no spills)
+    // is 7 % faster per frame.  WENET_RX_FORCE_RAW=1 selects the raw ring regardless (tests).
+    const bool want_raw = (fmt == WENET_FMT_CU8) && (n_sel > 2 * wenet_rx_device_info(1) || getenv("WENET_RX_FORCE_RAW") != nullptr);
+    // three captures per workgroup (one shared NCO-chain wave, demod_tri_impl.h) for big cu8 batches; WENET_RX_TRI=1 forces it on
+    // any cu8 batch (tests), WENET_RX_NO_TRI turns it off
+    // ... unless the previous batch of this handle slipped on more than 5 % of its frames (symbol-clock error: the timing estimate
+    // ping-pongs at its thresholds): a slip stalls all three captures of a workgroup, and the one-capture kernel wins
+    // (tools/gpu_slip_batch.py: 100 ppm = 11 % slips: 34.5 vs 30.5 ms)
+    const bool slippy = rx->slip_rate > 0.05 && getenv("WENET_RX_TRI") == nullptr;
+    const bool want_tri = (fmt == WENET_FMT_CU8) && (!rx->profile || getenv("WENET_RX_PROFILE")[0] == '3') &&
+                          (getenv("WENET_RX_TRI") != nullptr || (2 * n_sel >= 3 * wenet_rx_device_info(1) && !slippy));   // from 1.5 captures per CU on it wins (measured 384..3072)
+    WrDemodCfg launch_cfg = want_tri ? rx->tab.tri_cfg() : (want_raw ? rx->tab.raw_cfg() : rx->tab.cfg);
+    if (want_tri && !launch_cfg.p_tri) launch_cfg = want_raw ? rx->tab.raw_cfg() : rx->tab.cfg;     // geometry does not fit three blocks
+    // Batches (round 2): one wavefront per capture, `caps` captures per workgroup sharing an NCO-chain and a timing-sum wavefront
+    // (demod_oct_impl.h).  A capture advances one frame per ~20 k cycles there (the pipelined kernels: 11.5 k), so it takes over once
+    // the CUs hold several captures each.  WENET_RX_OCT=<caps> forces it
+    // (tests), WENET_RX_NO_OCT turns it off.  Traces with Eb/N0 accumulators and profiling stay with the pipelined kernels.
+    int oct_caps = 0, oct_nd = 1;
+    bool oct_hlp = false;                                           // (one 4-FSK capture per workgroup, up to one per CU: its mix stage on four waves)
+    if (fmt == WENET_FMT_CU8 && (!rx->profile || getenv("WENET_RX_PROFILE")[0] == '4')) {
+        const char *force = getenv("WENET_RX_OCT");
+        // measured (tools/gpu_batch_sweep.py, 10 s captures, 256 CUs, demod ms): the three-capture pipelined kernel takes 103 per round of 768
+        // captures; workgroups of four captures 179 up to one per CU, 203 up to two per CU; workgroups of seven 195 up to one per CU,
+        // 245..255 up to two per CU.  Hence: up to 3 captures per CU pipelined, then whichever workgroup size needs fewer per CU.
+        if (force) { oct_caps = atoi(force) > 0 ? atoi(force) : 7; oct_nd = (c.M == 4 && oct_caps > 2) ? 2 : 1; }
+        else if (!rx->want_trace && c.M == 2 && n_sel > 3 * wenet_rx_device_info(1)) {
+            const int ncu = wenet_rx_device_info(1);
+            oct_caps = n_sel <= 4 * ncu ? 4 : (n_sel <= 7 * ncu ? 7 : (n_sel <= 8 * ncu ? 4 : 7));
+            // (round 3 measured workgroups with a chain wave AND a sum wave for these geometries: fourteen captures + two duty waves per CU need
+            // 1 144 instead of 1 279 VALU instructions per frame but take 218 ms against 210 for 3584 captures -- the fourteen capture waves then
+            // move in lock-step and the sum wave competes with their transforms; two workgroups of six + two: 188 ms for 3072.  Not built for them.)
+        }
+        // The 4-FSK / Ts 32 geometry (BASELINE config 4), 32.6 KB of LDS per capture: up to four captures per CU.  Round 2 ran two workgroups of two
+        // captures + one duty wave (34 against the sequential kernel's 11.5 G samples/s at 1024 captures); round 3 ONE workgroup with a chain wave and a
+        // sum wave -- the 1 568-step chain and the 1 568-term sums shared by its captures and running beside each other -- and the capture waves above
+        // both in priority; a single stream (up to one capture per CU) with three tone helpers: 54.7 x real time against 26.3 x.
+        else if (!rx->want_trace && c.M == 4) {
+            const int ncu = wenet_rx_device_info(1);
+            // (round 3, capture waves above the duty waves: the fewest captures per workgroup that put the batch on the CUs at once, always with a chain
+            // wave and a sum wave -- 1024 captures x 2 s: four per workgroup 60.2 ms; 700: three 56.8 (two + one duty wave: 72.7); 512 and 300: two 54.5
+            // (300 as one capture per workgroup without helpers: 89); up to one capture per CU the single-stream form with its tone helpers)
+            oct_nd = 2;
+            oct_caps = n_sel <= ncu ? 1 : (n_sel <= 2 * ncu ? 2 : (n_sel <= 3 * ncu ? 3 : 4));
+            oct_hlp = oct_caps == 1;
+        }
+    }
+    WrDemodCfg oct_cfg;
+    bool use_oct = false;
+    if (oct_caps > 0) {
+        if (getenv("WENET_RX_OCT_ND") && c.M == 4) oct_nd = atoi(getenv("WENET_RX_OCT_ND")) == 2 ? 2 : 1;
+        if (getenv("WENET_RX_OCT_HLP")) oct_hlp = atoi(getenv("WENET_RX_OCT_HLP")) != 0;
+        oct_cfg = rx->tab.oct_cfg(oct_caps, oct_nd, oct_hlp);
+        use_oct = oct_cfg.o_ok != 0 && fmt == WENET_FMT_CU8;
+    }
+    launch_cfg.p_tsum_split = getenv("WENET_RX_TSUM_SPLIT") ? atoi(getenv("WENET_RX_TSUM_SPLIT")) : ((n_sel > wenet_rx_device_info(1)) ? 1 : 0);
+    if (launch_cfg.p_tri) launch_cfg.p_tsum_split = 1;              // (the batch form throughout)
+    DemodChoice dc; dc.use_oct = use_oct; dc.oct_cfg = oct_cfg; dc.launch_cfg = launch_cfg;
+    return dc;
+}
+
 // raw[i]: device address of capture i.  host_src != nullptr: its content still has to be copied there from host_src[i];
 // the batch is then cut into sub-batches whose uploads (copy stream) overlap the kernels of the previous sub-batch.
 static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw_in, const long long *nsamples, int fmt_in, void *stream_v,
@@ -1131,6 +1203,7 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw_in, const 
     if (!rx || nchan <= 0 || fmt_in < 0 || fmt_in > 3) return -1;
     if (rx->pending && wenet_rx_collect(rx) < 0) return -1;            // a batch still in flight owns the buffers: finish it first
     DeviceGuard dg(rx->device);
+    rx->live_n = 0; rx->live_fmt = -1; rx->live_ticks = 0;             // (a batch ends live streams of this handle: the buffers are shared)
     // complex-float captures of the benchmarking flow: quantised on the device to cu8 / cs16 first (see wenet_quantise_kernel), the chain then
     // runs on the quantised copy exactly as if `csdr convert_f_u8 | fsk_demod --cu8` had been fed
     const bool quant = fmt_in == WENET_FMT_CF32 && rx->cf32_quant >= 0;
@@ -1224,71 +1297,7 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw_in, const 
     a.census = rx->d_census.as<unsigned>();
     a.llr_out = rx->want_llr ? rx->d_llr.as<float>() : nullptr;
     fill_decode_tables(a, t);
-    // Which demodulator kernel for n_sel captures launched together (the whole batch; or, below, the full rounds and the remainder of a
-    // device-resident batch separately):
-    struct DemodChoice { bool use_oct; WrDemodCfg oct_cfg, launch_cfg; };
-    auto choose_demod = [&](int n_sel) -> DemodChoice {
-        // every capture starts from reset state; with cu8 input the three-per-CU raw-ring variant applies
-        // ... when a third capture per CU is worth having; up to two per CU the float-ring variant (96 registers, no spills)
-        // is 7 % faster per frame.  WENET_RX_FORCE_RAW=1 selects the raw ring regardless (tests).
-        const bool want_raw = (fmt == WENET_FMT_CU8) && (n_sel > 2 * wenet_rx_device_info(1) || getenv("WENET_RX_FORCE_RAW") != nullptr);
-        // three captures per workgroup (one shared NCO-chain wave, demod_tri_impl.h) for big cu8 batches; WENET_RX_TRI=1 forces it on
-        // any cu8 batch (tests), WENET_RX_NO_TRI turns it off
-        // ... unless the previous batch of this handle slipped on more than 5 % of its frames (symbol-clock error: the timing estimate
-        // ping-pongs at its thresholds): a slip stalls all three captures of a workgroup, and the one-capture kernel wins
-        // (tools/gpu_slip_batch.py: 100 ppm = 11 % slips: 34.5 vs 30.5 ms)
-        const bool slippy = rx->slip_rate > 0.05 && getenv("WENET_RX_TRI") == nullptr;
-        const bool want_tri = (fmt == WENET_FMT_CU8) && (!rx->profile || getenv("WENET_RX_PROFILE")[0] == '3') &&
-                              (getenv("WENET_RX_TRI") != nullptr || (2 * n_sel >= 3 * wenet_rx_device_info(1) && !slippy));   // from 1.5 captures per CU on it wins (measured 384..3072)
-        WrDemodCfg launch_cfg = want_tri ? rx->tab.tri_cfg() : (want_raw ? rx->tab.raw_cfg() : rx->tab.cfg);
-        if (want_tri && !launch_cfg.p_tri) launch_cfg = want_raw ? rx->tab.raw_cfg() : rx->tab.cfg;     // geometry does not fit three blocks
-        // Batches (round 2): one wavefront per capture, `caps` captures per workgroup sharing an NCO-chain and a timing-sum wavefront
-        // (demod_oct_impl.h).  A capture advances one frame per ~20 k cycles there (the pipelined kernels: 11.5 k), so it takes over once
-        // the CUs hold several captures each.  WENET_RX_OCT=<caps> forces it
-        // (tests), WENET_RX_NO_OCT turns it off.  Traces with Eb/N0 accumulators and profiling stay with the pipelined kernels.
-        int oct_caps = 0, oct_nd = 1;
-        bool oct_hlp = false;                                           // (one 4-FSK capture per workgroup, up to one per CU: its mix stage on four waves)
-        if (fmt == WENET_FMT_CU8 && (!rx->profile || getenv("WENET_RX_PROFILE")[0] == '4')) {
-            const char *force = getenv("WENET_RX_OCT");
-            // measured (tools/gpu_batch_sweep.py, 10 s captures, 256 CUs, demod ms): the three-capture pipelined kernel takes 103 per round of 768
-            // captures; workgroups of four captures 179 up to one per CU, 203 up to two per CU; workgroups of seven 195 up to one per CU,
-            // 245..255 up to two per CU.  Hence: up to 3 captures per CU pipelined, then whichever workgroup size needs fewer per CU.
-            if (force) { oct_caps = atoi(force) > 0 ? atoi(force) : 7; oct_nd = (c.M == 4 && oct_caps > 2) ? 2 : 1; }
-            else if (!rx->want_trace && c.M == 2 && n_sel > 3 * wenet_rx_device_info(1)) {
-                const int ncu = wenet_rx_device_info(1);
-                oct_caps = n_sel <= 4 * ncu ? 4 : (n_sel <= 7 * ncu ? 7 : (n_sel <= 8 * ncu ? 4 : 7));
-                // (round 3 measured workgroups with a chain wave AND a sum wave for these geometries: fourteen captures + two duty waves per CU need
-                // 1 144 instead of 1 279 VALU instructions per frame but take 218 ms against 210 for 3584 captures -- the fourteen capture waves then
-                // move in lock-step and the sum wave competes with their transforms; two workgroups of six + two: 188 ms for 3072.  Not built for them.)
-            }
-            // The 4-FSK / Ts 32 geometry (BASELINE config 4), 32.6 KB of LDS per capture: up to four captures per CU.  Round 2 ran two workgroups of two
-            // captures + one duty wave (34 against the sequential kernel's 11.5 G samples/s at 1024 captures); round 3 ONE workgroup with a chain wave and a
-            // sum wave -- the 1 568-step chain and the 1 568-term sums shared by its captures and running beside each other -- and the capture waves above
-            // both in priority; a single stream (up to one capture per CU) with three tone helpers: 54.7 x real time against 26.3 x.
-            else if (!rx->want_trace && c.M == 4) {
-                const int ncu = wenet_rx_device_info(1);
-                // (round 3, capture waves above the duty waves: the fewest captures per workgroup that put the batch on the CUs at once, always with a chain
-                // wave and a sum wave -- 1024 captures x 2 s: four per workgroup 60.2 ms; 700: three 56.8 (two + one duty wave: 72.7); 512 and 300: two 54.5
-                // (300 as one capture per workgroup without helpers: 89); up to one capture per CU the single-stream form with its tone helpers)
-                oct_nd = 2;
-                oct_caps = n_sel <= ncu ? 1 : (n_sel <= 2 * ncu ? 2 : (n_sel <= 3 * ncu ? 3 : 4));
-                oct_hlp = oct_caps == 1;
-            }
-        }
-        WrDemodCfg oct_cfg;
-        bool use_oct = false;
-        if (oct_caps > 0) {
-            if (getenv("WENET_RX_OCT_ND") && c.M == 4) oct_nd = atoi(getenv("WENET_RX_OCT_ND")) == 2 ? 2 : 1;
-            if (getenv("WENET_RX_OCT_HLP")) oct_hlp = atoi(getenv("WENET_RX_OCT_HLP")) != 0;
-            oct_cfg = rx->tab.oct_cfg(oct_caps, oct_nd, oct_hlp);
-            use_oct = oct_cfg.o_ok != 0 && fmt == WENET_FMT_CU8;
-        }
-        launch_cfg.p_tsum_split = getenv("WENET_RX_TSUM_SPLIT") ? atoi(getenv("WENET_RX_TSUM_SPLIT")) : ((n_sel > wenet_rx_device_info(1)) ? 1 : 0);
-        if (launch_cfg.p_tri) launch_cfg.p_tsum_split = 1;              // (the batch form throughout)
-        DemodChoice dc; dc.use_oct = use_oct; dc.oct_cfg = oct_cfg; dc.launch_cfg = launch_cfg;
-        return dc;
-    };
-    const DemodChoice whole = choose_demod(nchan);
+    const DemodChoice whole = choose_demod(rx, nchan, fmt);
     const bool use_oct = whole.use_oct;
     auto kernel_name = [](const DemodChoice &d) -> const char * {
         return d.use_oct ? "wenet_demod_oct_kernel"
@@ -1409,7 +1418,7 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw_in, const 
         if (sub.use_oct) WR_CHECK(wr_launch_demod_oct(&sub.oct_cfg, rx->d_chans.as<WrChan>() + lo, full, stream), -4);
         else WR_CHECK(wr_launch_demod_ex(&sub.launch_cfg, rx->d_chans.as<WrChan>() + lo, n, stream, prof), -4);
         if (full < n) {
-            DemodChoice rest = choose_demod(n - full);
+            DemodChoice rest = choose_demod(rx, n - full, fmt);
             if (rest.use_oct) WR_CHECK(wr_launch_demod_oct(&rest.oct_cfg, rx->d_chans.as<WrChan>() + lo + full, n - full, stream), -4);
             else WR_CHECK(wr_launch_demod_ex(&rest.launch_cfg, rx->d_chans.as<WrChan>() + lo + full, n - full, stream, 0), -4);
         }
@@ -1456,6 +1465,243 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw_in, const 
     WR_CHECK(hipEventRecord(rx->copied_all, rx->res_stream), -4);
     rx->pending = true;
     return 0;
+}
+
+
+// ================================================================================================
+// live channels: N streams pushed in ticks, state carried, one set of launches per tick
+// ================================================================================================
+// Per channel the semantics of the reference's two loops: src/fsk_demod.c:270-413 (read nin samples, demodulate, write the soft decisions, carry
+// struct FSK) and src/wenet_ldpc.c:171-258 / src/drs232_ldpc.c:176-274 (the unique-word window and a packet in collection carried across reads).
+// What a tick leaves undone stays on the DEVICE: the samples behind the last whole frame (< nin of them) at the front of the channel's input block,
+// the soft decisions from the deframer's resume point on at the front of its symbol block (moved there by wenet_live_compact_kernel at the start
+// of the next tick, from the counts the kernels left in the state blocks -- no host round trip), the modem state block and the deframer state.
+namespace {
+struct WrLiveMeta { long long carry_smp, carry_sym; };                  // what the compaction left in front of the channel's blocks
+// one workgroup per channel: samples [consumed, have) -> front of the input block, symbols [resume, nsym) -> front of the symbol block
+// (the spans may overlap their destinations by a few elements: every pass reads into registers, meets, then writes)
+__global__ __launch_bounds__(256) void wenet_live_compact_kernel(char *in_base, long long in_stride, float *sd_base, long long sd_stride,
+                                                                 const float *states, int st_floats, const WrDeframeState *dst, WrLiveMeta *meta,
+                                                                 const long long *new_smp, int bps, int nbits) {
+    const int ch = blockIdx.x, tid = threadIdx.x;
+    const WrChanHdr *h = (const WrChanHdr *)(states + (size_t)ch * st_floats);
+    const long long have = meta[ch].carry_smp + new_smp[ch], used = h->consumed_call;
+    const long long nsym = meta[ch].carry_sym + h->frames_call * nbits, res = dst[ch].resume;
+    {
+        char *b = in_base + (size_t)ch * in_stride;
+        const long long nb = (have - used) * bps, from = used * bps;
+        for (long long o = 0; o < nb && from > 0; o += 256 * 4) {
+            const long long i = o + tid * 4;
+            unsigned v = 0;
+            if (i < nb) v = *(const unsigned *)(b + from + i);          // (2 | 4 | 8 bytes per sample, blocks 256-byte aligned: whole dwords... or a 2-byte tail)
+            __syncthreads();
+            if (i + 4 <= nb) *(unsigned *)(b + i) = v;
+            else if (i < nb) *(unsigned short *)(b + i) = (unsigned short)v;
+            __syncthreads();
+        }
+    }
+    {
+        float *b = sd_base + (size_t)ch * sd_stride;
+        const long long n = nsym - res;
+        for (long long o = 0; o < n && res > 0; o += 256) {
+            const long long i = o + tid;
+            float v = 0.f;
+            if (i < n) v = b[res + i];
+            __syncthreads();
+            if (i < n) b[i] = v;
+            __syncthreads();
+        }
+    }
+    if (tid == 0) { meta[ch].carry_smp = have - used; meta[ch].carry_sym = nsym - res; }
+}
+}  // namespace
+
+static void live_close(wenet_rx *rx) { rx->live_n = 0; rx->live_fmt = -1; rx->live_ticks = 0; }
+
+extern "C" int wenet_rx_flush(wenet_rx *rx) {
+    if (!rx) return -1;
+    live_close(rx);                                                     // (EOF of the reference pipes: a partial frame and a packet in collection are dropped)
+    return 0;
+}
+
+extern "C" long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *chunk, const long long *nsamples, int fmt) {
+    if (!rx || nchan <= 0 || fmt < 0 || fmt > 3 || !nsamples) return -1;
+    if (rx->pending && wenet_rx_collect(rx) < 0) return -1;
+    DeviceGuard dg(rx->device);
+    LdpcTables *t = ldpc_tables();
+    if (!t) return -1;
+    const WrDemodCfg &c = rx->tab.cfg;
+    const size_t bps = (size_t)kBytesPerSample[fmt];
+    const size_t stb = (size_t)c.st_floats * 4;
+    hipStream_t stream = nullptr;
+    if (rx->live_n == 0) {                                              // first tick: fresh modem + deframer state per channel (fsk.c:182-245; bit_buffer = 0)
+        rx->live_n = nchan; rx->live_fmt = fmt; rx->live_ticks = 0;
+        rx->live_carry_smp.assign(nchan, 0); rx->live_carry_sym.assign(nchan, 0); rx->live_sym_base.assign(nchan, 0); rx->live_new_sym.assign(nchan, 0);
+        rx->live_in_stride = 0; rx->live_sd_stride = 0;
+        rx->slip_rate = 0.0;
+        std::vector<float> st0;
+        rx->tab.init_state(st0);
+        rx->h_states.resize((size_t)c.st_floats * nchan);
+        for (int i = 0; i < nchan; i++) memcpy(&rx->h_states[(size_t)i * c.st_floats], st0.data(), stb);
+        if (!rx->d_states.reserve(stb * nchan) || !rx->d_dstates.reserve(sizeof(WrDeframeState) * nchan) || !rx->d_live_meta.reserve((sizeof(WrLiveMeta) + 8) * nchan) ||
+            !rx->d_chans.reserve(sizeof(WrChan) * nchan) || !rx->d_dchans.reserve(sizeof(WrDeframeChan) * nchan) || !rx->d_census.reserve((size_t)nchan * WR_CENSUS_CLASSES * 4))
+            return -2;
+        WR_CHECK(hipMemcpy(rx->d_states.p, rx->h_states.data(), stb * nchan, hipMemcpyHostToDevice), -3);
+        WR_CHECK(hipMemset(rx->d_dstates.p, 0, sizeof(WrDeframeState) * nchan), -3);
+        WR_CHECK(hipMemset(rx->d_live_meta.p, 0, (sizeof(WrLiveMeta) + 8) * nchan), -3);
+    }
+    if (nchan != rx->live_n || fmt != rx->live_fmt) {
+        fprintf(stderr, "libwenet_rx: wenet_rx_push: %d channels of format %d were opened, the call has %d of format %d (wenet_rx_flush ends the streams)\n",
+                rx->live_n, rx->live_fmt, nchan, fmt);
+        return -1;
+    }
+    rx->nchan = nchan; rx->stream = stream; rx->sliced = false;
+    WrLiveMeta *d_meta = rx->d_live_meta.as<WrLiveMeta>();
+    long long *d_newsmp = (long long *)(d_meta + nchan);
+    // (1) what the previous tick left undone moves to the front of the blocks
+    if (rx->live_ticks > 0) {
+        hipLaunchKernelGGL(wenet_live_compact_kernel, dim3(nchan), dim3(256), 0, stream, rx->d_live_in.as<char>(), rx->live_in_stride, rx->d_sd.as<float>(),
+                           rx->live_sd_stride, rx->d_states.as<float>(), c.st_floats, rx->d_dstates.as<WrDeframeState>(), d_meta, d_newsmp, (int)bps, c.Nbits);
+        WR_CHECK(hipGetLastError(), -4);
+    }
+    // (2) room for this tick: carried + new samples per channel, carried + new symbols; growing keeps what is carried
+    const long long min_nin = c.N - c.Ts / 2;
+    long long need_smp = 0, need_sym = 0, max_pk = 1;
+    std::vector<long long> capf(nchan);
+    for (int i = 0; i < nchan; i++) {
+        if (nsamples[i] < 0) return -1;
+        const long long have = rx->live_carry_smp[i] + nsamples[i];
+        capf[i] = have / min_nin + 1;
+        const long long sym = rx->live_carry_sym[i] + capf[i] * c.Nbits;
+        need_smp = std::max(need_smp, have); need_sym = std::max(need_sym, sym);
+        max_pk = std::max(max_pk, sym / rx->spp + 1);
+    }
+    const long long in_stride = (((need_smp + need_smp / 4) * (long long)bps + 255) & ~255LL) + 256, sd_stride = ((need_sym + need_sym / 4 + 63) & ~63LL) + 64;
+    if (in_stride > rx->live_in_stride || sd_stride > rx->live_sd_stride) {
+        WR_CHECK(hipStreamSynchronize(stream), -4);
+        const long long nis = std::max(in_stride, rx->live_in_stride), nss = std::max(sd_stride, rx->live_sd_stride);
+        void *n_in = nullptr, *n_sd = nullptr;
+        if (hipMalloc(&n_in, (size_t)nis * nchan + 256) != hipSuccess || hipMalloc(&n_sd, (size_t)nss * nchan * 4 + 256) != hipSuccess) {
+            if (n_in) (void)hipFree(n_in);
+            fprintf(stderr, "libwenet_rx: wenet_rx_push: hipMalloc failed\n");
+            return -2;
+        }
+        for (int i = 0; i < nchan && rx->live_ticks > 0; i++) {
+            if (rx->live_carry_smp[i] > 0) WR_CHECK(hipMemcpy((char *)n_in + (size_t)i * nis, rx->d_live_in.as<char>() + (size_t)i * rx->live_in_stride, (size_t)rx->live_carry_smp[i] * bps, hipMemcpyDeviceToDevice), -3);
+            if (rx->live_carry_sym[i] > 0) WR_CHECK(hipMemcpy((float *)n_sd + (size_t)i * nss, rx->d_sd.as<float>() + (size_t)i * rx->live_sd_stride, (size_t)rx->live_carry_sym[i] * 4, hipMemcpyDeviceToDevice), -3);
+        }
+        if (rx->d_live_in.p) (void)hipFree(rx->d_live_in.p);
+        if (rx->d_sd.p) (void)hipFree(rx->d_sd.p);
+        rx->d_live_in.p = n_in; rx->d_live_in.cap = (size_t)nis * nchan + 256;
+        rx->d_sd.p = n_sd; rx->d_sd.cap = (size_t)nss * nchan * 4 + 256;
+        rx->live_in_stride = nis; rx->live_sd_stride = nss;
+    }
+    rx->max_pk = (int)max_pk;
+    if (!rx->d_starts.reserve((size_t)nchan * max_pk * 8) || !rx->d_out.reserve((size_t)nchan * max_pk * sizeof(WrPacketOut)) ||
+        !rx->d_esn0.reserve((size_t)nchan * max_pk * 8 + 4096))
+        return -2;
+    if (rx->want_trace && !rx->d_trace.reserve((size_t)nchan * (size_t)(rx->live_sd_stride / c.Nbits + 1) * WR_TRACE_FLOATS * 4)) return -2;
+    if (rx->want_llr && !rx->d_llr.reserve((size_t)nchan * max_pk * WR_NCODE * 4)) return -2;
+    const size_t oct_scr = (size_t)c.M * c.Ts * 64 * 8 + 64;
+    if (!rx->d_big.reserve((size_t)nchan * (c.big ? (size_t)c.big_bytes : oct_scr))) return -2;
+    rx->profile = false;
+    // (3) this tick's samples behind the carried ones; tables
+    std::vector<WrChan> chans(nchan);
+    std::vector<WrDeframeChan> dch(nchan);
+    rx->sd_off.assign(nchan + 1, 0);
+    rx->cap_frames = capf;
+    for (int i = 0; i < nchan; i++) {
+        char *blk = rx->d_live_in.as<char>() + (size_t)i * rx->live_in_stride;
+        if (nsamples[i] > 0) {
+            if (!chunk || !chunk[i]) return -1;
+            WR_CHECK(hipMemcpyAsync(blk + (size_t)rx->live_carry_smp[i] * bps, chunk[i], (size_t)nsamples[i] * bps, hipMemcpyHostToDevice, stream), -3);
+        }
+        float *sdb = rx->d_sd.as<float>() + (size_t)i * rx->live_sd_stride;
+        WrChan &ch = chans[i];
+        memset(&ch, 0, sizeof(ch));
+        ch.raw = blk; ch.nsamples = rx->live_carry_smp[i] + nsamples[i]; ch.fmt = fmt;
+        ch.state = rx->d_states.as<float>() + (size_t)i * c.st_floats;
+        ch.sd_out = sdb + rx->live_carry_sym[i];
+        ch.cap_frames = capf[i];
+        ch.trace = rx->want_trace ? rx->d_trace.as<float>() + (size_t)i * (size_t)(rx->live_sd_stride / c.Nbits + 1) * WR_TRACE_FLOATS : nullptr;
+        ch.big = rx->d_big.as<unsigned char>() + (size_t)i * (c.big ? (size_t)c.big_bytes : oct_scr);
+        rx->sd_off[i] = (long long)((size_t)i * rx->live_sd_stride) + rx->live_carry_sym[i];       // (wenet_rx_get_soft: this tick's soft decisions)
+        WrDeframeChan &d = dch[i];
+        memset(&d, 0, sizeof(d));
+        d.sd = sdb;
+        d.nsym = rx->live_carry_sym[i];
+        d.nframes_src = (const long long *)((const char *)ch.state + offsetof(WrChanHdr, frames_call));
+        d.nbits_per_frame = c.Nbits;
+        d.state = rx->d_dstates.as<WrDeframeState>() + i;
+        d.starts = rx->d_starts.as<long long>() + (size_t)i * max_pk;
+        d.cap_packets = max_pk;
+    }
+    WR_CHECK(hipMemcpyAsync(rx->d_chans.p, chans.data(), sizeof(WrChan) * nchan, hipMemcpyHostToDevice, stream), -3);
+    WR_CHECK(hipMemcpyAsync(rx->d_dchans.p, dch.data(), sizeof(WrDeframeChan) * nchan, hipMemcpyHostToDevice, stream), -3);
+    WR_CHECK(hipMemcpyAsync(d_newsmp, nsamples, sizeof(long long) * nchan, hipMemcpyHostToDevice, stream), -3);
+    WR_CHECK(hipMemsetAsync(rx->d_census.p, 0, (size_t)nchan * WR_CENSUS_CLASSES * 4, stream), -3);
+    // (4) demodulate every whole frame, look for unique words in carried + new symbols, decode every packet completed
+    rx->nchunks = 1;
+    if (!rx->chunk_events(1)) return -4;
+    wenet_rx::ChunkEv &e = rx->cev[0];
+    const DemodChoice dcs = choose_demod(rx, nchan, fmt);
+    rx->last_kernel = dcs.use_oct ? "wenet_demod_oct_kernel" : (dcs.launch_cfg.p_tri ? "wenet_demod_tri_kernel" : (dcs.launch_cfg.pipe_ok && !dcs.launch_cfg.big ? "wenet_demod_pipe_kernel" : "wenet_demod_kernel"));
+    WR_CHECK(hipEventRecord(e.ev[0], stream), -4);
+    if (dcs.use_oct) WR_CHECK(wr_launch_demod_oct(&dcs.oct_cfg, rx->d_chans.as<WrChan>(), nchan, stream), -4);
+    else WR_CHECK(wr_launch_demod_ex(&dcs.launch_cfg, rx->d_chans.as<WrChan>(), nchan, stream, 0), -4);
+    WR_CHECK(hipEventRecord(e.ev[1], stream), -4);
+    WR_CHECK(wr_launch_deframe(rx->d_dchans.as<WrDeframeChan>(), nchan, rx->mode, stream), -4);
+    WR_CHECK(hipEventRecord(e.ev[2], stream), -4);
+    WrDecodeArgs a;
+    memset(&a, 0, sizeof(a));
+    a.input_kind = WR_DEC_IN_STREAM; a.mode = rx->mode; a.max_iter = rx->max_iter; a.nchan = nchan; a.max_pk = (int)max_pk;
+    a.dchans = rx->d_dchans.as<WrDeframeChan>();
+    a.out = rx->d_out.as<WrPacketOut>();
+    a.esn0 = rx->d_esn0.as<double>();
+    a.work = (unsigned *)(a.esn0 + (size_t)nchan * max_pk);
+    a.census = rx->d_census.as<unsigned>();
+    a.llr_out = rx->want_llr ? rx->d_llr.as<float>() : nullptr;
+    fill_decode_tables(a, t);
+    WR_CHECK(wr_launch_decode(&a, stream), -4);
+    WR_CHECK(hipEventRecord(e.ev[3], stream), -4);
+    // (5) results: state headers, deframer states, packet slots
+    {
+        const size_t n_slots = (size_t)nchan * max_pk, out_bytes = n_slots * sizeof(WrPacketOut), st_bytes = n_slots * 8;
+        if (!rx->pin_reserve(out_bytes + st_bytes + 64)) return -2;
+        rx->h_out = (WrPacketOut *)rx->h_pin;
+        rx->h_starts = (long long *)((char *)rx->h_pin + ((out_bytes + 63) & ~(size_t)63));
+        rx->h_dstates.resize(nchan);
+        rx->h_census.resize((size_t)nchan * WR_CENSUS_CLASSES);
+        WR_CHECK(hipMemcpyAsync(rx->h_states.data(), rx->d_states.p, stb * nchan, hipMemcpyDeviceToHost, stream), -3);
+        WR_CHECK(hipMemcpyAsync(rx->h_dstates.data(), rx->d_dstates.p, sizeof(WrDeframeState) * nchan, hipMemcpyDeviceToHost, stream), -3);
+        WR_CHECK(hipMemcpyAsync(rx->h_census.data(), rx->d_census.p, rx->h_census.size() * 4, hipMemcpyDeviceToHost, stream), -3);
+        WR_CHECK(hipStreamSynchronize(stream), -4);
+        long long total = 0;
+        size_t used_slots = 0;
+        for (int i = 0; i < nchan; i++) if (rx->h_dstates[i].npackets > 0) used_slots = (size_t)(i + 1) * max_pk;
+        if (used_slots > 0) {
+            WR_CHECK(hipMemcpyAsync(rx->h_out, rx->d_out.p, used_slots * sizeof(WrPacketOut), hipMemcpyDeviceToHost, stream), -3);
+            WR_CHECK(hipMemcpyAsync(rx->h_starts, rx->d_starts.p, used_slots * 8, hipMemcpyDeviceToHost, stream), -3);
+            WR_CHECK(hipStreamSynchronize(stream), -4);
+        }
+        // (6) the host's mirror of what stays on the device for the next tick (wenet_live_compact_kernel computes the same from the same words)
+        long long fr = 0, sl = 0;
+        for (int i = 0; i < nchan; i++) {
+            const WrChanHdr *h = (const WrChanHdr *)&rx->h_states[(size_t)i * c.st_floats];
+            const long long have = rx->live_carry_smp[i] + nsamples[i], nsym = rx->live_carry_sym[i] + h->frames_call * c.Nbits, res = rx->h_dstates[i].resume;
+            rx->live_new_sym[i] = h->frames_call * c.Nbits;
+            // packets' start offsets become absolute positions in the channel's symbol stream
+            for (long long k = 0; k < rx->h_dstates[i].npackets; k++) rx->h_starts[(size_t)i * max_pk + k] += rx->live_sym_base[i];
+            rx->live_carry_smp[i] = have - h->consumed_call;
+            rx->live_carry_sym[i] = nsym - res;
+            rx->live_sym_base[i] += res;
+            total += rx->h_dstates[i].npackets;
+            fr += h->frames_call; sl += h->slips_call;
+        }
+        if (fr > 0) rx->slip_rate = (double)sl / (double)fr;
+        rx->live_ticks++;
+        return total;
+    }
 }
 
 extern "C" int wenet_rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const long long *nsamples, int fmt, void *stream_v) {
@@ -1597,7 +1843,7 @@ extern "C" long long wenet_rx_ssdv_images(wenet_rx *rx, int ch, wenet_ssdv_image
 extern "C" long long wenet_rx_get_soft(wenet_rx *rx, int ch, float *sd, long long cap) {
     long long fr = wenet_rx_frames(rx, ch);
     if (fr < 0) return fr;
-    long long n = fr * rx->tab.cfg.Nbits;
+    long long n = rx->live_n > 0 ? rx->live_new_sym[ch] : fr * rx->tab.cfg.Nbits;      // (live channels: the soft decisions of the last tick)
     if (n > cap) n = cap;
     DeviceGuard dg(rx->device);
     if (n > 0) WR_CHECK(hipMemcpy(sd, rx->d_sd.as<float>() + rx->sd_off[ch], (size_t)n * 4, hipMemcpyDeviceToHost), -3);
@@ -1606,9 +1852,12 @@ extern "C" long long wenet_rx_get_soft(wenet_rx *rx, int ch, float *sd, long lon
 extern "C" long long wenet_rx_get_trace(wenet_rx *rx, int ch, float *trace, long long cap_frames) {
     long long fr = wenet_rx_frames(rx, ch);
     if (fr < 0 || !rx->want_trace) return -1;
+    const bool live = rx->live_n > 0;
+    if (live) fr = rx->live_new_sym[ch] / rx->tab.cfg.Nbits;
     if (fr > cap_frames) fr = cap_frames;
     DeviceGuard dg(rx->device);
-    if (fr > 0) WR_CHECK(hipMemcpy(trace, rx->d_trace.as<float>() + (rx->sd_off[ch] / rx->tab.cfg.Nbits) * WR_TRACE_FLOATS,
+    const size_t row0 = live ? (size_t)ch * (size_t)(rx->live_sd_stride / rx->tab.cfg.Nbits + 1) : (size_t)(rx->sd_off[ch] / rx->tab.cfg.Nbits);
+    if (fr > 0) WR_CHECK(hipMemcpy(trace, rx->d_trace.as<float>() + row0 * WR_TRACE_FLOATS,
                                     (size_t)fr * WR_TRACE_FLOATS * 4, hipMemcpyDeviceToHost), -3);
     return fr;
 }

@@ -78,6 +78,25 @@ class RxBatch:
         if rc < 0:
             raise RuntimeError(f"wenet_rx_collect failed ({rc})")
 
+    # ---- live channels: N streams in ticks, state carried on the GPU ----------------------------
+    def push(self, chunks, fmt):
+        """chunks: one numpy array (or None / empty) per channel = the samples that arrived since the last tick.  Returns the number of
+        packets completed in this tick; the getters below then describe this tick (packets completed, frames demodulated)."""
+        bufs = [np.ascontiguousarray(c).view(np.uint8).reshape(-1) if c is not None else np.zeros(0, np.uint8) for c in chunks]
+        n = len(bufs)
+        ptrs = (C.c_void_p * n)(*[(b.ctypes.data if b.size else None) for b in bufs])
+        ns = (C.c_longlong * n)(*[b.size // BYTES_PER_SAMPLE[fmt] for b in bufs])
+        rc = int(self._L.wenet_rx_push(self._h, n, ptrs, ns, FMT[fmt]))
+        if rc < 0:
+            raise RuntimeError(f"wenet_rx_push failed ({rc})")
+        self.nchan = n
+        return rc
+
+    def flush(self):
+        """end of the live streams (what is left undone is dropped, as the reference pipe drops it at EOF)"""
+        if self._L.wenet_rx_flush(self._h) < 0:
+            raise RuntimeError("wenet_rx_flush failed")
+
     # ---- results ------------------------------------------------------------------------
     def frames(self, ch):
         return int(self._L.wenet_rx_frames(self._h, ch))
