@@ -188,3 +188,40 @@ def test_host_fed_time_slices_equal_one_launch(name, force, monkeypatch):
         ref = ol.oracle_deframe(sd, cfg.mode)
         assert rx.npackets(i) == ref["n"] and (rx.packets(i)["bytes"] == ref["bytes"]).all(), i
     rx.close()
+
+
+@pytest.mark.parametrize("name,group,slice_samples", [("v2", 7, 9000), ("v1", 4, 5000), ("v2", 3, 30000), ("4fsk", 3, 40000)])
+def test_device_resident_time_slices_inside_one_launch(name, group, slice_samples, monkeypatch):
+    """Round 4: a device-resident batch demodulated in TIME SLICES inside one launch of the batch demodulator (WrSliceCtl, wenet_internal.h: workgroups take
+    (slice, capture group) tickets, wait for the group's previous slice, move the table entries on themselves).  Slices forced short -- a few frames each,
+    up to 64 of them --, ragged captures (sorted by length on the device), an empty and a silent one, heavy clock errors: every capture equals the oracle
+    bit for bit, and the slip / park-all counters cover the whole capture, not the last slice."""
+    import torch
+    monkeypatch.setenv("WENET_RX_OCT", str(group))
+    monkeypatch.setenv("WENET_RX_DEV_SLICE_SAMPLES", str(slice_samples))
+    cfg = siggen.CONFIGS[name]()
+    if name == "4fsk":
+        caps = [siggen.make_capture(cfg, n, eb, seed=880 + i, ppm=ppm)[0] for i, (n, eb, ppm) in enumerate(SPEC[:7])]
+        caps.append(caps[0][:2 * cfg.Ts * 48 * 9 + 6])
+    else:
+        caps = _captures(cfg, 860)
+    rx = RxBatch(cfg.Fs, cfg.Rs, cfg.M, framing=cfg.mode)
+    dev = [torch.from_numpy(c).cuda() if c.size else torch.zeros(2, dtype=torch.uint8, device="cuda") for c in caps]
+    rx.enqueue_device([int(d.data_ptr()) for d in dev], [c.size // 2 for c in caps], "cu8")
+    rx.collect()
+    assert rx.last_kernel() == "wenet_demod_oct_kernel"
+    total_slips = 0
+    for i, c in enumerate(caps):
+        if not c.size:
+            assert rx.frames(i) == 0 and rx.npackets(i) == 0
+            continue
+        sd, tr = ol.oracle_demod(c, "cu8", cfg.Fs, cfg.Rs, cfg.M, want_trace=True)
+        assert rx.frames(i) == tr.shape[0], i
+        assert bits_equal(rx.soft(i), sd), i
+        ref = ol.oracle_deframe(sd, cfg.mode)
+        assert rx.npackets(i) == ref["n"] and (rx.packets(i)["bytes"] == ref["bytes"]).all(), i
+        slips = int((tr[:, 4] != cfg.Ts * 48).sum())
+        assert slips <= rx.channel_counter(i, 0) <= slips + 8, (i, rx.channel_counter(i, 0), slips)      # accumulated over the slices (a frame chained twice counts twice)
+        total_slips += slips
+    assert total_slips > 10
+    rx.close()

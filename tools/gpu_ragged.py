@@ -28,7 +28,7 @@ if len(sys.argv) > 2 and sys.argv[2] == "child":
     print(f"{rx.last_kernel()}: demod {rx.last_ms(0):.1f} ms, {tot / rx.last_ms(0) / 1e6:.1f} Gsamples/s demod-only; packets {sum(rx.npackets(i) for i in range(0, B, 97))}")
     sys.exit(0)
 B = sys.argv[1] if len(sys.argv) > 1 else "3584"
-for tag, env in (("by length", {}), ("as given", {"WENET_RX_NO_SORT": "1"})):
+for tag, env in (("by length", {}), ("as given", {"WENET_RX_NO_SORT": "1"}), ("by length, one launch per round (no time slices)", {"WENET_RX_NO_DEV_SLICES": "1"})):
     e = dict(os.environ); e.update(env)
     out = subprocess.run([sys.executable, __file__, B, "child"], env=e, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True).stdout.strip().splitlines()
     print(tag + ":", out[-1] if out else "failed")

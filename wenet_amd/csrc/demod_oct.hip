@@ -3,6 +3,8 @@
 
 extern "C" hipError_t wr_launch_demod_oct(const WrDemodCfg *cfg, const WrChan *d_chans, int nchan, hipStream_t stream) {
     if (nchan <= 0) return hipSuccess;
+    WrSliceCtl *d_ctl = nullptr;
+    const int nslices = 1;
     if (!cfg->o_ok) return hipErrorInvalidValue;
     const int groups = (nchan + cfg->o_caps - 1) / cfg->o_caps;
     const int threads = (cfg->o_caps + cfg->o_hlp + cfg->o_nd) * 64;   // the capture waves (+ the tone helpers of a single capture) + the duty wave(s)
@@ -12,7 +14,7 @@ extern "C" hipError_t wr_launch_demod_oct(const WrDemodCfg *cfg, const WrChan *d
         hipError_t e = hipFuncSetAttribute((const void *)wenet_demod_oct_kernel<MM, TT, NN, DD, HH>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                            cfg->o_lds_bytes);                                                                      \
         if (e != hipSuccess) return e;                                                                                             \
-        hipLaunchKernelGGL((wenet_demod_oct_kernel<MM, TT, NN, DD, HH>), dim3(groups), dim3(threads), cfg->o_lds_bytes, stream, *cfg, d_chans, nchan); \
+        hipLaunchKernelGGL((wenet_demod_oct_kernel<MM, TT, NN, DD, HH>), dim3(groups * nslices), dim3(threads), cfg->o_lds_bytes, stream, *cfg, d_chans, nchan, d_ctl); \
     } while (0)
     const bool duo = cfg->o_nd == 2;
     // (two duty waves pay for the large geometry -- 72.7 against 83.4 ms per 1024 captures x 2 s -- and cost the small ones 3 %: not instantiated there)

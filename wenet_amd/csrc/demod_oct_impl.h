@@ -193,6 +193,48 @@ __device__ __forceinline__ float nco_steps_split(float own, float k1, float k2) 
     return own;
 }
 
+// ---- time slices inside one launch (WrSliceCtl, wenet_internal.h).  Real calls (noinline): what they need in registers does not meet the frame loop's
+// allocation -- inlined, the same code cost the loop eight spilled vector registers and 18 % of its speed.
+// take the next queue position, wait until it is filled: tk[0] = capture group, tk[1] = the slice of it to do now
+__device__ __attribute__((noinline)) void oct_slice_take(WrSliceCtl *ctl, int *tk) {
+    const unsigned pos = atomicAdd(&ctl->head, 1u);
+    unsigned spins = 0, g1 = 0;
+    while ((g1 = __hip_atomic_load(&ctl->queue[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) {
+        __builtin_amdgcn_s_sleep(16);
+        if (++spins > (1u << 25)) { atomicExch(&ctl->error, 1u); g1 = 1u; break; }    // (~10 s: never expected; the host fails the batch)
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    tk[0] = (int)g1 - 1;
+    tk[1] = (int)__hip_atomic_load(&ctl->done[g1 - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// (one wavefront) the slice is written back: move the captures' table entries on to the next slice (what wenet_advance_kernel does between the launches
+// of a host-fed batch), publish it, and -- unless it was the last -- put the group at the end of the queue
+__device__ __attribute__((noinline)) void oct_slice_done(WrSliceCtl *ctl, WrChan *chans, int nchan, int G, const int *tk) {
+    const int lane = threadIdx.x & 63, bid = tk[0], slice = tk[1];
+    if (lane < G && bid * G + lane < nchan) {
+        WrChan &c = chans[bid * G + lane];
+        WrSliceInfo &inf = ctl->info[bid * G + lane];
+        const WrChanHdr *h = (const WrChanHdr *)c.state;
+        inf.slips_acc += h->slips_call; inf.allout_acc += h->allout_call;
+        const long long done_smp = ((const char *)c.raw - inf.base) / ctl->bps + h->consumed_call;
+        const long long next_end = (long long)(slice + 2) * ctl->slice_len, end = inf.total < next_end ? inf.total : next_end;
+        c.raw = inf.base + done_smp * ctl->bps;
+        c.nsamples = end > done_smp ? end - done_smp : 0;
+        c.sd_out += h->frames_call * ctl->nbits;
+        if (c.trace) c.trace += h->frames_call * WR_TRACE_FLOATS;
+        c.cap_frames -= h->frames_call;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (lane == 0) {
+        __hip_atomic_store(&ctl->done[bid], (unsigned)(slice + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (slice + 1 < ctl->nslices) {
+            const unsigned pos = atomicAdd(&ctl->tail, 1u);
+            __hip_atomic_store(&ctl->queue[pos], (unsigned)bid + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 }  // namespace
 
 // Geometries: (M 2, TS 8 | 10, NDFT 256) = Wenet v1 / v2; (M 4, TS 32, NDFT 1024) = BASELINE config 4 (4-FSK, Fs 1 843 200).  The small ones keep every
@@ -200,9 +242,10 @@ __device__ __forceinline__ float nco_steps_split(float own, float k1, float k2) 
 // where it uses them (the registers they would sit in are worth more than the microsecond in a 35 us frame).
 // ND = number of duty wavefronts: 1 (the chain, later the sums, on one wave) or 2 (a chain wave and a sum wave: see the frame loop)
 // HLP: the mix stage of a workgroup's ONE capture runs on M wavefronts, a tone each (large geometry, one stream: DESIGN.md 4.2)
-template <int M, int TS, int NDFT, int ND, bool HLP>
+// SL: time slices inside one launch (WrSliceCtl, wenet_internal.h): a separate instantiation, so that the plain one keeps its register allocation
+template <int M, int TS, int NDFT, int ND, bool HLP, bool SL = false>
 // (launch bounds: the LDS of the large geometry allows <= 10 wavefronts per CU anyway, so it may have 256 VGPRs)
-__global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WAVES_PER_EU) void wenet_demod_oct_kernel(WrDemodCfg cfg, const WrChan *chans, int nchan) {
+__global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WAVES_PER_EU) void wenet_demod_oct_kernel(WrDemodCfg cfg, const WrChan *chans, int nchan, WrSliceCtl *ctl) {
     static_assert(M == 2 || M == 4, "two or four tones");
     static_assert(NDFT == 256 || NDFT == 1024, "a power of four: radix-4 stages only");
     constexpr int H = TS / 2;                                            // checkpoint spacing = the unit of a timing slip
@@ -216,12 +259,31 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
     constexpr int NHLP = HLP ? M - 1 : 0;                                // tone-helper waves (G == 1 then): wave 1 + t mixes tone 1 + t
     const bool is_cap = wave < G, is_hlp = HLP && wave >= G && wave < G + NHLP, is_chain = wave == G + NHLP, is_sum = wave == G + NHLP + ND - 1;      // ND == 1: one duty wave, the chain and later the sums
     const int cap = is_cap ? wave : 0;
-    const int ch = blockIdx.x * G + cap;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    // Which capture group, and -- a launch over time slices (WrSliceCtl, wenet_internal.h) -- which slice of it: by ticket, in the order the workgroups
+    // really start, so that the workgroup this one may have to wait for (the group's previous slice) has started already.
+    int bid = blockIdx.x;
+    if constexpr (SL) {
+        int *tk = (int *)(smem_all + (G * LY.stride + LY.tab));         // two words behind the tables: capture group and slice (read again at the end:
+        if (tid == 0) oct_slice_take(ctl, tk);                           //  nothing of this lives in registers through the frame loop)
+        lds_barrier();
+        bid = __builtin_amdgcn_readfirstlane(((volatile int *)tk)[0]);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");               // the previous slice's state blocks and table entries, written on another CU
+    }
+    const int ch = bid * G + cap;
     const bool present = is_cap && ch < nchan;
     WrChan C = chans[ch < nchan ? ch : 0];
+    if constexpr (SL) {
+        // Behind the atomics and fences above the compiler no longer proves this table entry unclobbered, loads it with vector instructions and keeps its
+        // (wave-uniform) fields in vector registers through the frame loop -- eight spills and 18 % of the loop's speed.  Said explicitly: they are uniform.
+        auto up = [](auto *p) __attribute__((always_inline)) { return (decltype(p))uni64((long long)p); };
+        C.raw = up(C.raw); C.state = up(C.state); C.sd_out = up(C.sd_out); C.bits_out = up(C.bits_out); C.trace = up(C.trace); C.dump = up(C.dump);
+        C.prof = up(C.prof); C.prof2 = up(C.prof2); C.big = up(C.big);
+        C.nsamples = uni64(C.nsamples); C.cap_frames = uni64(C.cap_frames); C.dump_first = uni64(C.dump_first); C.dump_period = uni64(C.dump_period); C.dump_cap = uni64(C.dump_cap);
+        C.fmt = __builtin_amdgcn_readfirstlane(C.fmt);
+    }
     if (!present && !(is_hlp && ch < nchan)) { C.nsamples = 0; C.cap_frames = 0; C.sd_out = nullptr; C.trace = nullptr; }   // (helpers read the capture's samples)
 
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
     unsigned char *smem = smem_all + cap * LY.stride;
     float2 *FB = (float2 *)(smem + LY.FB);                        // [Ndft] estimator FFT buffer
     float  *TPf = (float *)(smem + LY.TP);                        // the frame's timing products: a row of re, a row of im
@@ -304,7 +366,7 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
     float own_s = 0.f;
     if (is_chain) {
         const int q = lane >> 1, cc = q / M, m = q % M;
-        const int chc = blockIdx.x * G + cc;
+        const int chc = bid * G + cc;
         own_s = (lane & 1) ? 0.f : 1.f;
         if (cc < G && chc < nchan) {
             const WrChanHdr *h = (const WrChanHdr *)chans[chc].state;
@@ -1339,12 +1401,21 @@ __global__ __launch_bounds__(NDFT == 1024 ? 512 : 1024, NDFT == 1024 ? 2 : WO_WA
             hdr->consumed_call = off;
         }
     }
+    int bid_e = blockIdx.x;
+    if constexpr (SL) bid_e = __builtin_amdgcn_readfirstlane(((volatile int *)(smem_all + (G * LY.stride + LY.tab)))[0]);
     if (is_chain) {                                                      // un-normalised, as saved at fsk.c:846
         const int q = lane >> 1, cc = q / M, m = q % M;
-        const int chc = blockIdx.x * G + cc;
+        const int chc = bid_e * G + cc;
         if (cc < G && chc < nchan && ((ran >> cc) & 1)) {
             WrChanHdr *h = (WrChanHdr *)chans[chc].state;
             ((float *)&h->phi_c[m])[lane & 1] = own_s;
         }
+    }
+    if constexpr (SL) {
+        // this slice is written back.  Every wave makes its own stores visible device-wide before the workgroup meets.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (wave == 0) oct_slice_done(ctl, const_cast<WrChan *>(chans), nchan, G, (const int *)(smem_all + (G * LY.stride + LY.tab)));
     }
 }

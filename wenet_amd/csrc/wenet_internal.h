@@ -158,6 +158,28 @@ struct WrChan {
     unsigned char *big;         // frame scratch of WrDemodCfg::big_bytes (only when WrDemodCfg::big)
 };
 
+// ---- time slices of a device-resident batch inside ONE launch of the batch demodulator (demod_oct_impl.h) ----
+// A capture is a serial job; a launch over more captures than the device holds at once ends with a nearly empty device (the last workgroups run
+// alone for a whole capture).  Cut in time instead: the grid is nslices x groups workgroups and the work is a QUEUE of ready capture groups --
+// it starts with every group once (slice 0); a workgroup takes the next queue position (atomic counter: positions are handed out in the order
+// workgroups really start), waits until that position is filled, demodulates the group's captures over their current slice from the carried
+// state, moves their table entries on to the next slice and, unless that was the group's last slice, appends the group to the queue again.
+// Position p >= groups is filled by the (p - groups + 1)-th such completion, and the workgroups that complete hold earlier positions, i.e. they
+// have started already: no deadlock whatever the dispatch order.  A freed CU slot thus takes the group that has waited longest -- usually the one
+// that has just finished there -- and the hardware's own workgroup dispatcher keeps every CU busy until the last slice.
+struct WrSliceInfo { const char *base; long long total; int slips_acc, allout_acc; };     // per capture: whole input; + the slip / park-all counts of the slices before the last
+struct WrSliceCtl {
+    unsigned head;              // next queue position to take
+    unsigned tail;              // next queue position to fill
+    unsigned error;             // a wait timed out (never expected; the host then fails the batch)
+    int nslices, groups;
+    long long slice_len;        // samples per slice
+    int bps, nbits;             // bytes per sample, soft decisions per frame
+    unsigned *queue;            // [nslices * groups] capture group + 1 (0 = not filled yet); the first `groups` entries are filled by the host
+    unsigned *done;             // [groups] slices written back
+    WrSliceInfo *info;          // [nchan]
+};
+
 // ---- deframer ----
 struct WrDeframeState {
     unsigned long long hist;    // last 64 hard bits seen while looking for the UW (LSB = newest)

@@ -29,6 +29,7 @@ extern "C" hipError_t wr_launch_demod(const WrDemodCfg *cfg, const WrChan *d_cha
 extern "C" hipError_t wr_launch_demod_pipe(const WrDemodCfg *cfg, const WrChan *d_chans, int nchan, hipStream_t stream, int prof);
 extern "C" hipError_t wr_launch_demod_ex(const WrDemodCfg *cfg, const WrChan *d_chans, int nchan, hipStream_t stream, int prof);
 extern "C" hipError_t wr_launch_demod_oct(const WrDemodCfg *cfg, const WrChan *d_chans, int nchan, hipStream_t stream);
+extern "C" hipError_t wr_launch_demod_oct_sliced(const WrDemodCfg *cfg, WrChan *d_chans, int nchan, WrSliceCtl *d_ctl, int nslices, hipStream_t stream);
 extern "C" hipError_t wr_launch_deframe(const WrDeframeChan *d_chans, int nchan, int mode, hipStream_t stream);
 extern "C" hipError_t wr_launch_decode(const WrDecodeArgs *args, hipStream_t stream);
 extern "C" hipError_t wr_launch_phi0(const uint4 *d_lut, const float *d_x, float *d_y, long long n, hipStream_t stream);
@@ -1008,7 +1009,6 @@ __global__ __launch_bounds__(256) void wenet_quantise_kernel(const WrQuantJob *j
 // Host-fed batches arrive in TIME slices (rx_enqueue): after the demodulator launch over a slice this kernel moves every capture's table entry on to
 // where that launch stopped -- the samples it consumed (whole frames; what is left over is demodulated with the next slice), the soft decisions
 // and trace rows it wrote, the frames it used of the cap -- and admits the samples of the next slice.  No host round trip between the launches.
-struct WrSliceInfo { const char *base; long long total; int slips_acc, allout_acc; };     // + the slip / park-all counts of the launches before the last one
 __global__ __launch_bounds__(256) void wenet_advance_kernel(WrChan *chans, WrSliceInfo *info, int nchan, long long next_end, int bps, int nbits) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nchan) return;
@@ -1082,6 +1082,8 @@ struct wenet_rx {
     std::vector<long long> live_carry_smp, live_carry_sym, live_sym_base, live_new_sym;   // host mirror, per channel
     DevBuf d_live_in, d_live_meta;
     bool pending = false;
+    size_t slice_info_off = 0;              // where the WrSliceInfo records start in d_slices (behind the control block of a one-launch sliced batch)
+    bool slice_ctl = false;                 // d_slices starts with a WrSliceCtl (time slices inside one launch)
     bool sliced = false;                    // the batch in flight / last collected was demodulated in time slices (counters accumulate in d_slices)
     bool chunk_events(int n) {
         while ((int)cev.size() < n) {
@@ -1330,8 +1332,8 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw_in, const 
     const int ncu = wenet_rx_device_info(1) > 0 ? wenet_rx_device_info(1) : 256;
     std::vector<int> bounds(1, 0);
     bounds.push_back(nchan);
-    long long max_ns = 0;
-    for (int i = 0; i < nchan; i++) max_ns = nsamples[i] > max_ns ? nsamples[i] : max_ns;
+    long long max_ns = 0, min_ns = nchan > 0 ? nsamples[0] : 0;
+    for (int i = 0; i < nchan; i++) { max_ns = nsamples[i] > max_ns ? nsamples[i] : max_ns; min_ns = nsamples[i] < min_ns ? nsamples[i] : min_ns; }
     int nslices = 1;
     if (host_src && !quant && getenv("WENET_RX_NO_SLICES") == nullptr) {
         // slices of ~2.5 M samples (a launch over a slice has a fixed cost of a few milliseconds: state in and out, the pipelines' fill), and no more
@@ -1343,7 +1345,7 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw_in, const 
         nslices = nslices < 1 ? 1 : (nslices > 32 ? 32 : nslices);
     }
     const long long slice_len = (max_ns + nslices - 1) / nslices;
-    rx->sliced = nslices > 1;
+    rx->sliced = nslices > 1; rx->slice_info_off = 0; rx->slice_ctl = false;
     if (nslices > 1) {
         std::vector<WrSliceInfo> info(nchan);
         for (int i = 0; i < nchan; i++) { info[i].base = (const char *)raw[i]; info[i].total = nsamples[i]; info[i].slips_acc = 0; info[i].allout_acc = 0; }
@@ -1414,8 +1416,49 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw_in, const 
         // pipelined kernel take 96 ms, a nearly empty round of the batch demodulator 177.
         const DemodChoice sub = whole;
         const int round_caps = sub.use_oct ? (sub.oct_cfg.o_nd == 2 ? 1 : 2) * sub.oct_cfg.o_caps * ncu : 0;     // captures a device holds at once
-        const int full = (sub.use_oct && !host_src && getenv("WENET_RX_OCT") == nullptr && round_caps > 0 && n > round_caps) ? (n / round_caps) * round_caps : n;
-        if (sub.use_oct) WR_CHECK(wr_launch_demod_oct(&sub.oct_cfg, rx->d_chans.as<WrChan>() + lo, full, stream), -4);
+        // Device-resident batches that are not a whole number of such rounds (round 4): ONE launch over time slices of every capture (WrSliceCtl,
+        // wenet_internal.h) -- workgroups take (slice, capture group) tickets and the dispatcher keeps every CU busy until the last slice, so 4 000
+        // captures cost 4 000 / 3 584 of a round instead of two rounds.  WENET_RX_DEV_SLICE_SAMPLES=<n> forces it with that slice length on any
+        // batch-demodulator launch (tests), WENET_RX_NO_DEV_SLICES turns it off.
+        long long dev_slice = 0;
+        if (sub.use_oct && !host_src && nslices == 1 && round_caps > 0 && getenv("WENET_RX_NO_DEV_SLICES") == nullptr) {
+            if (const char *f = getenv("WENET_RX_DEV_SLICE_SAMPLES")) dev_slice = atoll(f);
+            else if (n > round_caps && (n % round_caps != 0 || min_ns != max_ns) && getenv("WENET_RX_OCT") == nullptr) dev_slice = 1250LL * c.N;      // (measured, profiles/r04_dev_slices.txt)
+        }
+        int dev_nslices = dev_slice > 0 ? (int)((max_ns + dev_slice - 1) / dev_slice) : 1;
+        if (dev_nslices > 64) { dev_nslices = 64; dev_slice = (max_ns + 63) / 64; }
+        if (dev_nslices > 1 || (dev_slice > 0 && getenv("WENET_RX_DEV_SLICE_FORCE") != nullptr)) {      // (FORCE: the sliced instantiation even for one slice -- development)
+            const int groups = (n + sub.oct_cfg.o_caps - 1) / sub.oct_cfg.o_caps;
+            const size_t o_queue = (sizeof(WrSliceCtl) + 255) & ~(size_t)255, o_done = (o_queue + (size_t)groups * dev_nslices * 4 + 255) & ~(size_t)255,
+                         o_info = (o_done + (size_t)groups * 4 + 255) & ~(size_t)255;
+            if (!rx->d_slices.reserve(o_info + sizeof(WrSliceInfo) * n)) return -2;
+            std::vector<unsigned char> blob(o_info + sizeof(WrSliceInfo) * n, 0);
+            WrSliceCtl *hc = (WrSliceCtl *)blob.data();
+            hc->nslices = dev_nslices; hc->groups = groups; hc->slice_len = dev_slice; hc->bps = kBytesPerSample[fmt]; hc->nbits = c.Nbits;
+            hc->queue = (unsigned *)(rx->d_slices.as<char>() + o_queue);
+            hc->tail = (unsigned)groups;
+            for (int g = 0; g < groups; g++) ((unsigned *)(blob.data() + o_queue))[g] = (unsigned)g + 1u;      // every group once: its slice 0
+            hc->done = (unsigned *)(rx->d_slices.as<char>() + o_done);
+            hc->info = (WrSliceInfo *)(rx->d_slices.as<char>() + o_info);
+            // (the table on the device may have been sorted by length: the slice records follow the table's order)
+            std::vector<WrChan> tab(n);
+            WR_CHECK(hipMemcpy(tab.data(), rx->d_chans.as<WrChan>() + lo, sizeof(WrChan) * n, hipMemcpyDeviceToHost), -3);
+            WrSliceInfo *hi_ = (WrSliceInfo *)(blob.data() + o_info);
+            for (int i = 0; i < n; i++) {
+                hi_[i].base = (const char *)tab[i].raw; hi_[i].total = tab[i].nsamples;
+                tab[i].nsamples = tab[i].nsamples < dev_slice ? tab[i].nsamples : dev_slice;       // the first slice
+            }
+            WR_CHECK(hipMemcpyAsync(rx->d_chans.as<WrChan>() + lo, tab.data(), sizeof(WrChan) * n, hipMemcpyHostToDevice, stream), -3);
+            WR_CHECK(hipMemcpyAsync(rx->d_slices.p, blob.data(), blob.size(), hipMemcpyHostToDevice, stream), -3);
+            WR_CHECK(hipStreamSynchronize(stream), -3);
+            WR_CHECK(hipEventRecord(e.ev[0], stream), -4);             // (the set-up above is not demodulator time)
+            rx->sliced = true; rx->slice_info_off = o_info; rx->slice_ctl = true;
+            WR_CHECK(wr_launch_demod_oct_sliced(&sub.oct_cfg, rx->d_chans.as<WrChan>() + lo, n, (WrSliceCtl *)rx->d_slices.p, dev_nslices, stream), -4);
+        }
+        if (rx->slice_ctl) dev_nslices = dev_nslices > 1 ? dev_nslices : 2;      // (below: "the sliced launch has been made")
+        const int full = dev_nslices > 1 ? n : ((sub.use_oct && !host_src && getenv("WENET_RX_OCT") == nullptr && round_caps > 0 && n > round_caps) ? (n / round_caps) * round_caps : n);
+        if (dev_nslices > 1) {}
+        else if (sub.use_oct) WR_CHECK(wr_launch_demod_oct(&sub.oct_cfg, rx->d_chans.as<WrChan>() + lo, full, stream), -4);
         else WR_CHECK(wr_launch_demod_ex(&sub.launch_cfg, rx->d_chans.as<WrChan>() + lo, n, stream, prof), -4);
         if (full < n) {
             DemodChoice rest = choose_demod(rx, n - full, fmt);
@@ -1719,9 +1762,24 @@ extern "C" int wenet_rx_collect(wenet_rx *rx) {
     WR_CHECK(hipMemcpy(rx->h_dstates.data(), rx->d_dstates.p, sizeof(WrDeframeState) * nchan, hipMemcpyDeviceToHost), -3);
     if (rx->sliced) {   // host-fed time slices: every launch overwrote the per-launch counters -- add what the launches before the last one counted
         std::vector<WrSliceInfo> info(nchan);
-        WR_CHECK(hipMemcpy(info.data(), rx->d_slices.p, sizeof(WrSliceInfo) * nchan, hipMemcpyDeviceToHost), -3);
+        WR_CHECK(hipMemcpy(info.data(), rx->d_slices.as<char>() + rx->slice_info_off, sizeof(WrSliceInfo) * nchan, hipMemcpyDeviceToHost), -3);
+        if (rx->slice_ctl) {
+            WrSliceCtl hc;
+            WR_CHECK(hipMemcpy(&hc, rx->d_slices.p, sizeof(hc), hipMemcpyDeviceToHost), -3);
+            if (hc.error || hc.head != (unsigned)(hc.nslices * hc.groups)) {
+                fprintf(stderr, "libwenet_rx: time-sliced demodulator launch did not complete (error %u, %u of %d queue positions taken)\n", hc.error, hc.head, hc.nslices * hc.groups);
+                rx->pending = false;
+                return -6;
+            }
+        }
+        std::vector<WrChan> tab;
+        if (rx->slice_ctl) {                                            // (records follow the table's order, which may be sorted by length: find the channel by its state block)
+            tab.resize(nchan);
+            WR_CHECK(hipMemcpy(tab.data(), rx->d_chans.p, sizeof(WrChan) * nchan, hipMemcpyDeviceToHost), -3);
+        }
         for (int i = 0; i < nchan; i++) {
-            WrChanHdr *h = (WrChanHdr *)&rx->h_states[(size_t)i * c.st_floats];
+            const size_t chn = rx->slice_ctl ? (size_t)(tab[i].state - rx->d_states.as<float>()) / (size_t)c.st_floats : (size_t)i;
+            WrChanHdr *h = (WrChanHdr *)&rx->h_states[chn * c.st_floats];
             h->slips_call += info[i].slips_acc; h->allout_call += info[i].allout_acc;
         }
     }

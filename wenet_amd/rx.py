@@ -164,5 +164,9 @@ class RxBatch:
         got = self._L.wenet_rx_get_llrs(self._h, ch, out.ctypes.data, n)
         return out[:max(got, 0)]
 
+    def channel_counter(self, ch, what):
+        """diagnostics of the last collected batch: what = 0 frames with nin != N, 1 mix-stage passes that parked every integrator output"""
+        return int(self._L.wenet_rx_channel_counter(self._h, ch, what))
+
     def last_ms(self, what=3):
         return float(self._L.wenet_rx_last_ms(self._h, what))
