@@ -23,6 +23,7 @@
 // All float sums run in the reference's order, so iteration counts and bits are identical.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -110,13 +111,34 @@ namespace {
 // clamped key also covers y < 1, negatives and NaN/Inf/overflow (x86 cvttss2si -> INT_MIN -> 10.0).  No branches.
 // Two 4-byte LDS reads instead of one 12-byte read: the threshold of the cell, then the value below or above it (val[2 cell + above]).
 // The decode kernel is bound by LDS bandwidth, most of it the random 96-bit table reads (6 clocks per wavefront before bank conflicts).
+#ifndef WR_PHI0_FORM
+#define WR_PHI0_FORM 1
+#endif
 __device__ __forceinline__ float phi0_dev(float xf, const uint4 *lut) {
     const int b = __float_as_int(xf);
     const int key = min(max(b >> 18, WR_PHI0_KEY_BIAS), WR_PHI0_KEY_BIAS + WR_PHI0_LUT_ENTRIES - 1) - WR_PHI0_KEY_BIAS;
     const int *thr = (const int *)lut;
+#if WR_PHI0_FORM == 0                                                       // (round 2-3: two dependent 4-byte reads)
     const float *val = (const float *)(thr + WR_PHI0_LUT_ENTRIES + 2);
     const int t = thr[key];
     return val[2 * key + (b >= t ? 1 : 0)];
+#else
+    // round 4: the cell's threshold (4 bytes) and BOTH its values (8 bytes: ds_read_b64 costs the LDS the same two cycles as ds_read_b32) are read
+    // side by side -- one LDS round trip per evaluation instead of two dependent ones, and no address arithmetic on the comparison's result
+    const float2 *val = (const float2 *)(thr + WR_PHI0_LUT_ENTRIES + 2);
+    const int t = thr[key];
+    const float2 v = val[key];
+    return b >= t ? v.y : v.x;
+#endif
+}
+
+// the whole of wx_llr (x87emu.h) -- the integer emulation of the 80-bit product included -- as a real call: it is needed for one symbol in 2^29
+__device__ __attribute__((noinline)) float llr_exact(double estEsN0, double sd) { return wx_llr(estEsN0, sd); }
+
+// a wave-uniform 64-bit value the compiler carries in vector registers -> a scalar register pair
+__device__ __forceinline__ long long uni64(long long v) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
 }
 
 __device__ __forceinline__ float with_sign(float mag, int neg) {
@@ -135,16 +157,17 @@ __device__ __forceinline__ int var_edge(int v, int k, const uint16_t *vedge_lds)
 
 }  // namespace
 
-// soft symbol i (0..n-1) of a packet as the double the reference feeds to sd_to_llr
-__device__ __forceinline__ double packet_symbol(const WrDecodeArgs &A, const float *sd_stream, long long start, long long slot, int n, int i) {
-    if (A.input_kind == WR_DEC_IN_SD64) return A.sd64[slot * n + i];
+// soft symbol i (0..n-1) of the packet whose first stored symbol is at `base`, as the double the reference feeds to sd_to_llr
+__device__ __forceinline__ double packet_symbol(const WrDecodeArgs &A, unsigned long long base, int n, int i) {
+    if (A.input_kind == WR_DEC_IN_SD64) return ((const double *)(uintptr_t)base)[i];
+    const float *sd = (const float *)(uintptr_t)base;
     if (A.mode == 1) {                                  // RS232 strip: out[8b+j] = in[10b + 8 - j] (drs232_ldpc.c:220-225)
         const int b = i >> 3, j = i & 7;
-        return (double)sd_stream[start + 10 * b + 8 - j];
+        return (double)sd[10 * b + 8 - j];
     }
     const int kb = i % 1000;                            // v2: symbol * scramble_code[ind % 1000] (wenet_ldpc.c:207)
     const int neg = (A.scramble[kb >> 3] >> (7 - (kb & 7))) & 1;
-    return (double)sd_stream[start + i] * (neg ? -1.0 : 1.0);
+    return (double)sd[i] * (neg ? -1.0 : 1.0);
 }
 
 // sd_to_llr statistics (mpdecode_core.c:575-592): three running double sums whose rounding depends on the
@@ -177,6 +200,10 @@ __global__ __launch_bounds__(64) void wenet_llr_stats_kernel(WrDecodeArgs A) {
             live = pk < A.npk_direct[ch];
             if (live) base = (unsigned long long)(uintptr_t)(A.sd64 + slot * n);
         }
+    }
+    if (slot < (long long)A.nchan * A.max_pk) {                                         // the decoder's one-load way to the packet (0: the slot is empty)
+        A.pbase[slot] = live ? base : 0ull;
+        if (!live && A.rec) { WrSlotRec r; r.base = 0ull; r.esn0 = 0.0; A.rec[slot] = r; }
     }
     if (__ballot(live) == 0) return;
     pbase[lane] = live ? base : 0ull;
@@ -237,7 +264,9 @@ __global__ __launch_bounds__(64) void wenet_llr_stats_kernel(WrDecodeArgs A) {
     }
     if (live) {
         const double estvar = (n * sumsq - sum * sum) / (n * (n - 1));
-        A.esn0[slot] = wx_est_esn0(estvar);             // 1.0/(2.0L*estvar + 1E-3), x87 rounding
+        const double e = wx_est_esn0(estvar);            // 1.0/(2.0L*estvar + 1E-3), x87 rounding
+        A.esn0[slot] = e;
+        if (A.rec) { WrSlotRec r; r.base = base; r.esn0 = e; A.rec[slot] = r; }
     }
 }
 
@@ -285,8 +314,10 @@ __global__ __launch_bounds__(WR_DEC_THREADS, 8) void wenet_decode_kernel(WrDecod
     uint4    *lut  = (uint4 *)(smem + WR_DEC_OFF_LUT);
     uint8_t  *bitbuf = (uint8_t *)(smem + WR_DEC_OFF_BITS);                        // [2580] decoded bits, then [258] bytes
     int      *red = (int *)(smem + WR_DEC_OFF_RED);                                // [parity of the iteration][0: satisfied checks, 1: any data bit set]
-    int      *next_slot = red + 4;                                                 // the packet slot this workgroup works on
-
+    // packet claims: the slot this workgroup decodes now and the one it decodes next.  The next slot is taken from the shared counter while THIS packet is
+    // decoded (thread 0: the atomic at the packet's start, its value into LDS behind the last iteration), so the atomic's latency is not on a packet's path.
+    int *claim = (int *)(smem + WR_DEC_OFF_CLAIM);                                 // [2] (plain LDS words: the workgroup barriers order them)
+    const long long nslots = (long long)A.nchan * A.max_pk;
     // ---- once per workgroup: phi0 LUT into LDS; this thread's variables (LdpcTables::place_variables: the data variables are dealt
     //      to the positions tid + 512 t so that the variable pass loads the LDS banks evenly) and their edge addresses into registers.
     //      Positions t = 0..3 hold data bits (degree 3) for every thread; t = 4 straddles the data/parity boundary, t = 5 is parity or nothing.
@@ -309,52 +340,123 @@ __global__ __launch_bounds__(WR_DEC_THREADS, 8) void wenet_decode_kernel(WrDecod
         for (int k = 0; k < 3; k++) ea[t][k] = (k < deg[t]) ? var_edge(v, k, A.vedge) : 0;
     }
     const bool data4 = var_at(4) < WR_NDATA;                                      // position t = 4 holds a data bit (positions t < 4 always do, t = 5 never)
-    const long long nslots = (long long)A.nchan * A.max_pk;
-
-  for (;;) {
-    __syncthreads();                                                               // (the previous packet's staging is read out; LUT is in place)
-    if (tid == 0) *next_slot = (int)atomicAdd(A.work, 1u);
-    __syncthreads();
-    const long long slot = *next_slot;
-    if (slot >= nslots) break;
-    const int ch = (int)(slot / A.max_pk), pk = (int)(slot - (long long)ch * A.max_pk);
-
-    // ---- does this slot hold a packet?  (uniform) ----------------------------------------------
-    long long npk;
-    const float *sd_stream = nullptr;
-    long long start = 0;
-    if (A.input_kind == WR_DEC_IN_STREAM) {
-        const WrDeframeChan D = A.dchans[ch];
-        npk = D.state->npackets;
-        if (pk >= npk) continue;
-        sd_stream = D.sd;
-        start = D.starts[pk];
-    } else {
-        npk = A.npk_direct[ch];
-        if (pk >= npk) continue;
+    // Where this thread's six soft symbols sit in a stored packet, and which of them the v2 scrambler negates: functions of the thread's variables alone,
+    // so they are formed once here -- the per-packet prologue is then six loads issued together and six products (round 3 walked, per packet and variable,
+    // the chain placement table -> symbol -> scramble byte: a dozen dependent global loads, ~10 us per packet = two iterations' worth).
+    unsigned soff[3] = {0u, 0u, 0u}, sneg = 0u, svalid = 0u;              // 16-bit offsets packed in pairs; bit t: negate / position holds a variable
+    {
+        const bool stream = A.input_kind == WR_DEC_IN_STREAM;
+#pragma unroll
+        for (int t = 0; t < WR_VARS_PER_THREAD; t++) {
+            const int v = var_at(t);
+            unsigned o = 0u;
+            if (v < WR_NCODE) {
+                svalid |= 1u << t;
+                o = (unsigned)v;
+                if (stream && A.mode == 1) o = (unsigned)(10 * (v >> 3) + 8 - (v & 7));               // RS232 strip: out[8b+j] = in[10b + 8 - j] (drs232_ldpc.c:220-225)
+                if (stream && A.mode == 2) {                                                          // v2: symbol * scramble_code[ind % 1000] (wenet_ldpc.c:207)
+                    const int kb = v % 1000;
+                    if ((A.scramble[kb >> 3] >> (7 - (kb & 7))) & 1) sneg |= 1u << t;
+                }
+            }
+            soff[t >> 1] |= o << (16 * (t & 1));
+        }
     }
+    if (tid == 0) { const unsigned s0 = atomicAdd(A.work, 1u); claim[0] = (long long)s0 < nslots ? (int)s0 : -1; }     // the first packet: taken here, synchronously
+    int cur = 0;
+
+#ifdef WR_DEC_STAMPS
+    long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = 0;
+#define DSTAMP(k) do { const long long t1_ = (long long)__builtin_readcyclecounter(); st_acc[k] += t1_ - st_t; st_t = t1_; } while (0)
+#else
+#define DSTAMP(k) do { } while (0)
+#endif
+  for (;; cur ^= 1) {
+    __syncthreads();
+#ifdef WR_DEC_STAMPS
+    if (st_t) DSTAMP(5);                                                           // [5] end of the previous packet -> everyone at the top
+    st_t = (long long)__builtin_readcyclecounter();
+#endif                                                               // (the previous packet's staging is read out; LUT and this packet's claim are in place)
+    const int slot_i = __builtin_amdgcn_readfirstlane(claim[cur]);
+    if (slot_i < 0) break;
+    const long long slot = slot_i;
+    unsigned nxt = 0;
+    if (tid == 0) nxt = atomicAdd(A.work, 1u);                                     // the NEXT packet's slot: the value is not waited for here
+    auto put_claim = [&]() __attribute__((always_inline)) { if (tid == 0) claim[cur ^ 1] = (long long)nxt < nslots ? (int)nxt : -1; };
+    // the slot's record from the statistics kernel -- where the packet's first stored symbol is (0: no packet in this slot) and its estEsN0: ONE load
+    // (round 3: channel table -> deframer state -> start offset, three dependent ones)
+    unsigned long long base = 0ull;
+    double estEsN0 = 0.0;
+    if (A.input_kind == WR_DEC_IN_LLR) {                                           // (dense LLR input: no statistics kernel has run)
+        const int chs = slot_i / A.max_pk, pks = slot_i - chs * A.max_pk;
+        if (pks < A.npk_direct[chs]) base = (unsigned long long)(uintptr_t)(A.llr_in + slot * WR_NCODE);
+    } else {
+        base = (unsigned long long)uni64((long long)A.pbase[slot]);
+        estEsN0 = __longlong_as_double(uni64(__double_as_longlong(A.esn0[slot])));
+    }
+    if (base == 0ull) { put_claim(); continue; }                                   // nothing in this slot
     const int n = (A.input_kind == WR_DEC_IN_SD64) ? A.n_sd : WR_NCODE;
 
     float llr[WR_VARS_PER_THREAD];
     WrPacketOut *out = A.out ? &A.out[slot] : nullptr;
 
-    if (A.input_kind != WR_DEC_IN_LLR) {
-        // ---- LLRs: llr = (float)(4.0L*estEsN0*sd) with estEsN0 from wenet_llr_stats_kernel (mpdecode_core.c:593-594)
-        const double estEsN0 = A.esn0[slot];
-#pragma unroll
+    if (A.input_kind == WR_DEC_IN_SD64) {
+        // ---- sd_to_llr API (doubles, any n <= 3072, plain order; no decoding follows): llr = (float)(4.0L*estEsN0*sd) (mpdecode_core.c:593-594)
         for (int t = 0; t < WR_VARS_PER_THREAD; t++) {
-            const int i = (n == WR_NCODE) ? var_at(t) : tid + t * WR_DEC_THREADS;   // (sd_to_llr API with another n: plain order, no decoding follows)
-            llr[t] = (i < n) ? wx_llr(estEsN0, packet_symbol(A, sd_stream, start, slot, n, i)) : 0.f;
-            if (A.llr_out && i < n) A.llr_out[(long long)slot * n + i] = llr[t];
+            const int i = (n == WR_NCODE) ? var_at(t) : tid + t * WR_DEC_THREADS;
+            float l = 0.f;
+            if (i < n) l = llr_exact(estEsN0, ((const double *)(uintptr_t)base)[i]);
+            if (A.llr_out && i < n) A.llr_out[(long long)slot * n + i] = l;
+#pragma unroll
+            for (int u = 0; u < WR_VARS_PER_THREAD; u++) if (u == t) llr[u] = l;
         }
     } else {
+        // ---- this thread's six stored symbols: loaded together (one memory round trip), then
+        //      llr = (float)(4.0L*estEsN0*sd) with estEsN0 from wenet_llr_stats_kernel (mpdecode_core.c:593-594), or the dense LLR input as it is
+        const __attribute__((address_space(1))) float *sdp = (const __attribute__((address_space(1))) float *)base;
+        float raw[WR_VARS_PER_THREAD];
 #pragma unroll
-        for (int t = 0; t < WR_VARS_PER_THREAD; t++) {
-            const int i = var_at(t);
-            llr[t] = (i < WR_NCODE) ? A.llr_in[(long long)slot * WR_NCODE + i] : 0.f;
+#ifdef WR_DBG_NO_SD                                                              // development (timing only, wrong results): no symbol loads
+        for (int t = 0; t < WR_VARS_PER_THREAD; t++) raw[t] = 0.25f + 0.001f * (float)((tid + t) & 15);
+        (void)sdp;
+#else
+        for (int t = 0; t < WR_VARS_PER_THREAD; t++) raw[t] = ((svalid >> t) & 1u) ? sdp[(soff[t >> 1] >> (16 * (t & 1))) & 0xffffu] : 0.f;
+#endif
+        if (A.input_kind == WR_DEC_IN_LLR) {
+#pragma unroll
+            for (int t = 0; t < WR_VARS_PER_THREAD; t++) llr[t] = raw[t];
+        } else {
+                // wx_llr's fast path (x87emu.h) for all six, its integer emulation out of line for the rare rest: one double product decides the float unless
+            // it lands exactly half-way between two floats or outside the normal float range
+            const double c4 = 4.0 * estEsN0;
+            const bool c4ok = wx_finite(c4) && wx_finite(estEsN0);
+            unsigned hard = 0u;
+#pragma unroll
+            for (int t = 0; t < WR_VARS_PER_THREAD; t++) {
+                const double sd = ((sneg >> t) & 1u) ? -(double)raw[t] : (double)raw[t];
+                const double hi = c4 * sd;
+                const unsigned long long u = wx_d2u(hi);
+                const int be = (int)((u >> 52) & 0x7ff);
+                llr[t] = (float)hi;
+                if (!(c4ok && be >= 1023 - 126 && be <= 1023 + 126 && (u & 0x1fffffffULL) != 0x10000000ULL)) hard |= 1u << t;
+            }
+            hard &= svalid;
+            if (hard) {
+                for (int t = 0; t < WR_VARS_PER_THREAD; t++) {
+                    if (!((hard >> t) & 1u)) continue;
+                    const float l = llr_exact(estEsN0, ((sneg >> t) & 1u) ? -(double)raw[t] : (double)raw[t]);
+#pragma unroll
+                    for (int u = 0; u < WR_VARS_PER_THREAD; u++) if (u == t) llr[u] = l;
+                }
+            }
+            if (A.llr_out) {
+#pragma unroll
+                for (int t = 0; t < WR_VARS_PER_THREAD; t++) { const int i = var_at(t); if (i < n) A.llr_out[(long long)slot * n + i] = llr[t]; }
+            }
         }
     }
-    if (A.stop_after_llr) continue;
+    DSTAMP(0);                                                                     // [0] claim, record, symbol loads, LLRs
+    if (A.stop_after_llr) { put_claim(); continue; }
 
     if (tid == 0) msg[13 * WR_NPAR] = 0.f;                      // check 0 has 13 edges: its 14th slot stays a neutral +0
     __syncthreads();
@@ -369,6 +471,7 @@ __global__ __launch_bounds__(WR_DEC_THREADS, 8) void wenet_decode_kernel(WrDecod
     if (tid < 4) red[tid] = 0;
     __syncthreads();
 
+    DSTAMP(1);                                                                     // [1] initial messages + two barriers
     int result = A.max_iter, pcc = 0, pcc_written = 0;
     unsigned bits = 0;                                          // bit t = hard decision of variable tid+t*512
     for (int iter = 0; iter < A.max_iter; iter++) {
@@ -465,6 +568,15 @@ __global__ __launch_bounds__(WR_DEC_THREADS, 8) void wenet_decode_kernel(WrDecod
         if (ssum == WR_NPAR) { result = iter + 1; break; }
     }
 
+    DSTAMP(2);                                                      // [2] the iterations
+    put_claim();                                                    // (the atomic has returned long ago)
+#ifdef WR_DEC_STAMPS
+    st_acc[6] += 1; st_acc[7] += result;
+#endif
+#ifdef WR_DBG_NO_EPI                                                             // development (timing only, wrong results): no packing, no output
+    if (result < 0) bitbuf[tid] = (uint8_t)bits;
+    continue;
+#endif
     // ---- pack MSB-first, CRC-16/CCITT-FALSE gate (drs232_ldpc.c:234-257) ----------------------
     __syncthreads();
 #pragma unroll
@@ -489,7 +601,11 @@ __global__ __launch_bounds__(WR_DEC_THREADS, 8) void wenet_decode_kernel(WrDecod
         out->pcc = pcc;
         out->pcc_written = pcc_written;
     }
+    DSTAMP(3);                                              // [3] bits -> bytes -> packet slot
   }
+#ifdef WR_DEC_STAMPS
+  if (tid == 0 && A.dbg) for (int k = 0; k < 8; k++) atomicAdd((unsigned long long *)&A.dbg[k], (unsigned long long)st_acc[k]);
+#endif
 }
 
 
@@ -519,6 +635,7 @@ extern "C" hipError_t wr_launch_deframe(const WrDeframeChan *d_chans, int nchan,
     return hipGetLastError();
 }
 
+extern "C" hipError_t wr_launch_decode2(const WrDecodeArgs *args, hipStream_t stream, int grid);
 extern "C" hipError_t wr_launch_decode(const WrDecodeArgs *args, hipStream_t stream) {
     if (args->nchan <= 0 || args->max_pk <= 0) return hipSuccess;
     const long long slots = (long long)args->nchan * args->max_pk;
@@ -538,6 +655,14 @@ extern "C" hipError_t wr_launch_decode(const WrDecodeArgs *args, hipStream_t str
     const unsigned grid = (unsigned)(slots < want ? slots : want);
     hipError_t e = hipMemsetAsync(args->work, 0, sizeof(unsigned), stream);
     if (e != hipSuccess) return e;
+    // round 4: the byte-cell decoder (ldpc_decode2.hip) for everything that is decoded; the sd_to_llr API (doubles, any n, LLRs only) stays with the round-3
+    // kernel.  WENET_RX_DEC=1 selects the round-3 kernel throughout (comparison runs).
+    static const int which = getenv("WENET_RX_DEC") ? atoi(getenv("WENET_RX_DEC")) : 2;
+    if (which == 2 && args->input_kind != WR_DEC_IN_SD64 && !args->stop_after_llr) {
+        const long long want2 = (long long)(getenv("WENET_RX_DEC_WGS") ? atoi(getenv("WENET_RX_DEC_WGS")) : 4) * ncu;     // (development: workgroups per CU of the grid)
+        e = wr_launch_decode2(args, stream, (int)(slots < want2 ? slots : want2));
+        if (e != hipSuccess) return e;
+    } else
     hipLaunchKernelGGL(wenet_decode_kernel, dim3(grid), dim3(WR_DEC_THREADS), lds, stream, *args);
     if (!args->stop_after_llr && args->out)
         hipLaunchKernelGGL(wenet_crc_kernel, dim3(blocks), dim3(256), 0, stream, *args);

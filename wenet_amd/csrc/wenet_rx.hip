@@ -477,6 +477,59 @@ float phi0_x86(float xf) {                                              // phi0.
     return phi0_linear_int(x);
 }
 
+// Which variable does thread tid handle as its t-th (position tid + 512 t)?  The variable pass reads and writes one message per lane and instruction
+// at an address given by the graph; with the variables in natural order the 64 addresses of a wavefront hit the 32 LDS banks unevenly (the fullest
+// bank serves ~5 of them where 2 would do).  The graph is static, so the data variables are dealt to the positions once such that every
+// (wavefront, t, socket) instruction loads each bank as evenly as a local search finds (deterministic: fixed seed).  Parity variables keep their
+// places: their edge addresses are consecutive already.  bank(v, k) = LDS bank of socket k of data variable v in the layout at hand.
+template <class BankFn>
+static void place_variables(std::vector<uint16_t> &vpos, BankFn bank, int *cost0, int *cost1) {
+    vpos.resize(WR_NCODE);
+    for (int v = 0; v < WR_NCODE; v++) vpos[v] = (uint16_t)v;
+    const int NG = (WR_NDATA + 63) / 64;                        // instruction groups of 64 positions (the last one has 16)
+    std::vector<int> cnt((size_t)NG * 3 * 32, 0);
+    auto over = [](int c) { return c > 2 ? (c - 2) * (c - 2) : 0; };
+    long cost = 0;
+    for (int p = 0; p < WR_NDATA; p++) for (int k = 0; k < 3; k++) cnt[((size_t)(p / 64) * 3 + k) * 32 + bank(vpos[p], k)]++;
+    for (size_t i = 0; i < cnt.size(); i++) cost += over(cnt[i]);
+    *cost0 = (int)cost;
+    uint64_t rng = 0x9E3779B97F4A7C15ull;
+    auto next = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return rng; };
+    for (long it = 0; it < 3000000 && cost > 0; it++) {
+        const int p = (int)(next() % WR_NDATA), q = (int)(next() % WR_NDATA);
+        const int gp = p / 64, gq = q / 64;
+        if (gp == gq) continue;
+        const int vp = vpos[p], vq = vpos[q];
+        long d = 0;
+        for (int k = 0; k < 3; k++) {
+            const int bp = bank(vp, k), bq = bank(vq, k);
+            if (bp == bq) continue;
+            int *cp = &cnt[((size_t)gp * 3 + k) * 32], *cq = &cnt[((size_t)gq * 3 + k) * 32];
+            d += over(cp[bp] - 1) - over(cp[bp]) + over(cp[bq] + 1) - over(cp[bq]);
+            d += over(cq[bq] - 1) - over(cq[bq]) + over(cq[bp] + 1) - over(cq[bp]);
+        }
+        if (d > 0) continue;
+        for (int k = 0; k < 3; k++) {
+            const int bp = bank(vp, k), bq = bank(vq, k);
+            cnt[((size_t)gp * 3 + k) * 32 + bp]--; cnt[((size_t)gp * 3 + k) * 32 + bq]++;
+            cnt[((size_t)gq * 3 + k) * 32 + bq]--; cnt[((size_t)gq * 3 + k) * 32 + bp]++;
+        }
+        vpos[p] = (uint16_t)vq; vpos[q] = (uint16_t)vp;
+        cost += d;
+    }
+    *cost1 = (int)cost;
+    if (getenv("WENET_RX_NO_PLACE")) for (int v = 0; v < WR_NCODE; v++) vpos[v] = (uint16_t)v;     // development: natural order
+}
+
+// host twin of the round-4 decoder's phi0 (ldpc_decode2.hip): index of the value, from the cell {threshold as a float, index below it}
+inline int phi0_cells_index(const int *cells, float xf_nonneg) {
+    int32_t b; memcpy(&b, &xf_nonneg, 4);
+    int key = (b >> 18) - WR_PHI0_KEY_BIAS;
+    key = key < 0 ? 0 : (key > WR_PHI0_LUT_ENTRIES - 1 ? WR_PHI0_LUT_ENTRIES - 1 : key);
+    float thr; memcpy(&thr, &cells[2 * key], 4);
+    return cells[2 * key + 1] + (!(xf_nonneg < thr) ? 1 : 0);
+}
+
 struct LdpcTables {
     DevBuf blob;
     const uint16_t *d_vedge = nullptr;
@@ -484,6 +537,8 @@ struct LdpcTables {
     int place_cost0 = 0, place_cost = 0;                // bank overload of the variable pass before / after the placement search
     const uint4 *d_lut = nullptr;
     const uint8_t *d_scramble = nullptr;
+    const int2 *d_cells2 = nullptr; const float *d_vt2 = nullptr; const uint16_t *d_vedge2 = nullptr, *d_vpos2 = nullptr;   // round-4 decoder (byte cells)
+    int place2_cost0 = 0, place2_cost = 0;
     bool ok = false;
 
     bool build() {
@@ -498,49 +553,12 @@ struct LdpcTables {
                 vedge[v * 3 + deg[v]++] = (uint16_t)(j * WR_NPAR + c);   // slot-major edge address
             }
         for (int v = 0; v < WR_NDATA; v++) if (deg[v] != 3) { fprintf(stderr, "libwenet_rx: code table: column weight != 3\n"); return false; }
-        // Which variable does thread tid handle as its t-th (position tid + 512 t)?  The variable pass reads and writes one message per
-        // lane and instruction at msg[edge address]; with the variables in natural order the 64 addresses of a wavefront hit the 32 LDS
-        // banks unevenly (the fullest bank serves ~5 of them where 2 would do).  The graph is static, so the data variables are dealt to
-        // the positions once, here, such that every (wavefront, t, socket) instruction loads each bank as evenly as a local search
-        // finds (deterministic: fixed seed).  Parity variables keep their places: their edge addresses are consecutive already.
-        std::vector<uint16_t> vpos(WR_NCODE);
-        for (int v = 0; v < WR_NCODE; v++) vpos[v] = (uint16_t)v;
-        {
-            const int NG = (WR_NDATA + 63) / 64;                        // instruction groups of 64 positions (the last one has 16)
-            std::vector<int> cnt((size_t)NG * 3 * 32, 0);
-            auto bank = [&](int v, int k) { return vedge[v * 3 + k] & 31; };
-            auto over = [](int c) { return c > 2 ? (c - 2) * (c - 2) : 0; };
-            long cost = 0;
-            for (int p = 0; p < WR_NDATA; p++) for (int k = 0; k < 3; k++) cnt[((size_t)(p / 64) * 3 + k) * 32 + bank(vpos[p], k)]++;
-            for (size_t i = 0; i < cnt.size(); i++) cost += over(cnt[i]);
-            place_cost0 = (int)cost;
-            uint64_t rng = 0x9E3779B97F4A7C15ull;
-            auto next = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return rng; };
-            for (long it = 0; it < 3000000 && cost > 0; it++) {
-                const int p = (int)(next() % WR_NDATA), q = (int)(next() % WR_NDATA);
-                const int gp = p / 64, gq = q / 64;
-                if (gp == gq) continue;
-                const int vp = vpos[p], vq = vpos[q];
-                long d = 0;
-                for (int k = 0; k < 3; k++) {
-                    const int bp = bank(vp, k), bq = bank(vq, k);
-                    if (bp == bq) continue;
-                    int *cp = &cnt[((size_t)gp * 3 + k) * 32], *cq = &cnt[((size_t)gq * 3 + k) * 32];
-                    d += over(cp[bp] - 1) - over(cp[bp]) + over(cp[bq] + 1) - over(cp[bq]);
-                    d += over(cq[bq] - 1) - over(cq[bq]) + over(cq[bp] + 1) - over(cq[bp]);
-                }
-                if (d > 0) continue;
-                for (int k = 0; k < 3; k++) {
-                    const int bp = bank(vp, k), bq = bank(vq, k);
-                    cnt[((size_t)gp * 3 + k) * 32 + bp]--; cnt[((size_t)gp * 3 + k) * 32 + bq]++;
-                    cnt[((size_t)gq * 3 + k) * 32 + bq]--; cnt[((size_t)gq * 3 + k) * 32 + bp]++;
-                }
-                vpos[p] = (uint16_t)vq; vpos[q] = (uint16_t)vp;
-                cost += d;
-            }
-            place_cost = (int)cost;
-            if (getenv("WENET_RX_NO_PLACE")) for (int v = 0; v < WR_NCODE; v++) vpos[v] = (uint16_t)v;     // development: natural order
-        }
+        std::vector<uint16_t> vpos;
+        place_variables(vpos, [&](int v, int k) { return vedge[v * 3 + k] & 31; }, &place_cost0, &place_cost);
+        // round-4 decoder: message bytes at check * 16 + slot; bank = dword address mod 32
+        std::vector<uint16_t> vedge2(WR_NDATA * 3), vpos2;
+        for (int v = 0; v < WR_NDATA; v++) for (int k = 0; k < 3; k++) { const int e = vedge[v * 3 + k], slot = e / WR_NPAR, chk = e % WR_NPAR; vedge2[v * 3 + k] = (uint16_t)(chk * 16 + slot); }
+        place_variables(vpos2, [&](int v, int k) { return (vedge2[v * 3 + k] >> 2) & 31; }, &place2_cost0, &place2_cost);
         // phi0 LUT keyed by the float bits of y (see wenet_internal.h)
         std::vector<uint32_t> lut(WR_PHI0_LUT_ENTRIES * 4, 0);
         {
@@ -577,13 +595,55 @@ struct LdpcTables {
                 fprintf(stderr, "libwenet_rx: phi0 table self-check failed at xf=%g\n", (double)xf);
                 return false;
             }
+        // round-4 decoder: the same function as {threshold, index of the value below it} per cell and a list of the values in the order of rising argument
+        // (phi0 falls monotonically, so the value above a cell's threshold is the next of the list); the list ends with 10.0 again for arguments
+        // beyond 2^15 (x86 cvttss2si overflow).  The kernel compares |x| with the threshold as FLOATS (not-less-than: true for NaN, which lands in
+        // the last cell); cells without a step carry +Inf.
+        std::vector<int> cells(WR_PHI0_LUT_ENTRIES * 2, 0);
+        std::vector<float> vals;
+        {
+            auto u2f = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
+            vals.push_back(u2f(lut[1]));                                             // entry 0: 10.0
+            for (int k = 0; k < WR_PHI0_LUT_ENTRIES; k++) {
+                const uint32_t thr = lut[k * 4], below = lut[k * 4 + 1], above = lut[k * 4 + 2];
+                if (k == WR_PHI0_LUT_ENTRIES - 1) {                                  // {2^15, 0.0 below, 10.0 at and above}
+                    if (f2u(vals.back()) != below) vals.push_back(u2f(below));
+                    cells[2 * k] = (int)thr; cells[2 * k + 1] = (int)vals.size() - 1;
+                    vals.push_back(u2f(above));
+                    continue;
+                }
+                if (f2u(vals.back()) != below) {                                     // a step exactly on the cell's lower edge: the cell starts with the next value
+                    if (!(u2f(below) < vals.back())) { fprintf(stderr, "libwenet_rx: phi0 cells: cell %d does not continue the value list\n", k); return false; }
+                    vals.push_back(u2f(below));
+                }
+                cells[2 * k + 1] = (int)vals.size() - 1;
+                if (thr == 0x7fffffffu || above == below) cells[2 * k] = 0x7f800000;  // no step: +Inf
+                else { cells[2 * k] = (int)thr; vals.push_back(u2f(above)); }
+            }
+            if ((int)vals.size() != WR_PHI0_NVALS) { fprintf(stderr, "libwenet_rx: phi0 cells: %zu values, expected %d\n", vals.size(), WR_PHI0_NVALS); return false; }
+            for (int x = 0; x <= 1100000; x++)
+                for (float fr : {0.0f, 0.5f}) {
+                    const float xf = ((float)x + fr) / 65536.0f;
+                    if (f2u(vals[phi0_cells_index(cells.data(), xf)]) != f2u(phi0_x86(xf))) { fprintf(stderr, "libwenet_rx: phi0 cells self-check failed at y=%g\n", (double)x + fr); return false; }
+                }
+            for (float xf : {0.0f, 1e-30f, 1.5e-5f, 16.0f, 32767.0f, 32767.99f, 32768.0f, 1e9f, 3e38f, INFINITY, NAN})
+                if (f2u(vals[phi0_cells_index(cells.data(), xf)]) != f2u(phi0_x86(xf))) { fprintf(stderr, "libwenet_rx: phi0 cells self-check failed at xf=%g\n", (double)xf); return false; }
+        }
+        std::vector<uint32_t> vt(256, 0);
+        for (int i = 0; i < WR_PHI0_NVALS; i++) { vt[i] = f2u(vals[i]); vt[128 + i] = f2u(vals[i]) | 0x80000000u; }
         size_t a_v = 0, a_l = (WR_NDATA * 3 * 2 + 255) & ~255, a_s = a_l + ((WR_PHI0_LUT_ENTRIES * 16 + 255) & ~255), a_p = a_s + 256;
-        if (!blob.reserve(a_p + WR_NCODE * 2 + 256)) return false;
+        const size_t a_c2 = (a_p + WR_NCODE * 2 + 255) & ~(size_t)255, a_vt = a_c2 + ((WR_PHI0_LUT_ENTRIES * 8 + 255) & ~255), a_ve2 = a_vt + 1024, a_vp2 = (a_ve2 + WR_NDATA * 3 * 2 + 255) & ~(size_t)255;
+        if (!blob.reserve(a_vp2 + WR_NCODE * 2 + 256)) return false;
         char *base = blob.as<char>();
         WR_CHECK(hipMemcpy(base + a_v, vedge.data(), WR_NDATA * 3 * 2, hipMemcpyHostToDevice), false);
         WR_CHECK(hipMemcpy(base + a_l, lut.data(), WR_PHI0_LUT_ENTRIES * 16, hipMemcpyHostToDevice), false);
         WR_CHECK(hipMemcpy(base + a_s, kScramble, 125, hipMemcpyHostToDevice), false);
         WR_CHECK(hipMemcpy(base + a_p, vpos.data(), WR_NCODE * 2, hipMemcpyHostToDevice), false);
+        WR_CHECK(hipMemcpy(base + a_c2, cells.data(), WR_PHI0_LUT_ENTRIES * 8, hipMemcpyHostToDevice), false);
+        WR_CHECK(hipMemcpy(base + a_vt, vt.data(), 1024, hipMemcpyHostToDevice), false);
+        WR_CHECK(hipMemcpy(base + a_ve2, vedge2.data(), WR_NDATA * 3 * 2, hipMemcpyHostToDevice), false);
+        WR_CHECK(hipMemcpy(base + a_vp2, vpos2.data(), WR_NCODE * 2, hipMemcpyHostToDevice), false);
+        d_cells2 = (const int2 *)(base + a_c2); d_vt2 = (const float *)(base + a_vt); d_vedge2 = (const uint16_t *)(base + a_ve2); d_vpos2 = (const uint16_t *)(base + a_vp2);
         d_vpos = (const uint16_t *)(base + a_p);
         d_vedge = (const uint16_t *)(base + a_v);
         d_lut = (const uint4 *)(base + a_l);
@@ -609,6 +669,7 @@ LdpcTables *ldpc_tables() {                                            // the co
 
 void fill_decode_tables(WrDecodeArgs &a, const LdpcTables *t) {
     a.vedge = t->d_vedge; a.vpos = t->d_vpos; a.phi0_lut = t->d_lut; a.scramble = t->d_scramble;
+    a.d2_cells = t->d_cells2; a.d2_vt = t->d_vt2; a.vedge2 = t->d_vedge2; a.vpos2 = t->d_vpos2;
 }
 
 }  // namespace
@@ -837,7 +898,7 @@ int run_dense(int kind, const void *in, int npk, int n, int mode, int max_iter, 
     if (!g_dec.d_in.reserve(in_bytes) || !g_dec.d_out.reserve((size_t)npk * sizeof(WrPacketOut)) || !g_dec.d_npk.reserve(16)) return -2;
     if (llr_host && !g_dec.d_llr.reserve((size_t)npk * n * 4)) return -2;
     if (bits_host && !g_dec.d_bits.reserve((size_t)npk * WR_NCODE)) return -2;
-    if (!g_dec.d_esn0.reserve((size_t)npk * 8 + 256)) return -2;        // (+ the work counter behind the last estimate)
+    if (!g_dec.d_esn0.reserve(wr_dec_scratch_bytes((size_t)npk))) return -2;
     WR_CHECK(hipMemcpy(g_dec.d_in.p, in, in_bytes, hipMemcpyHostToDevice), -3);
     WR_CHECK(hipMemset(g_dec.d_out.p, 0, (size_t)npk * sizeof(WrPacketOut)), -3);
     WR_CHECK(hipMemcpy(g_dec.d_npk.p, &npk, 4, hipMemcpyHostToDevice), -3);
@@ -853,7 +914,9 @@ int run_dense(int kind, const void *in, int npk, int n, int mode, int max_iter, 
     a.llr_out = llr_host ? g_dec.d_llr.as<float>() : nullptr;
     a.bits_out = bits_host ? g_dec.d_bits.as<uint8_t>() : nullptr;
     a.esn0 = g_dec.d_esn0.as<double>();
-    a.work = (unsigned *)(g_dec.d_esn0.as<double>() + npk);            // (inside the 256 bytes reserved behind the estimates)
+    a.work = (unsigned *)(g_dec.d_esn0.as<double>() + npk);            // (inside the 4096 bytes reserved behind the estimates)
+    a.pbase = (unsigned long long *)(g_dec.d_esn0.as<char>() + (size_t)npk * 8 + 4096);
+    a.rec = (WrSlotRec *)(g_dec.d_esn0.as<char>() + (size_t)npk * 16 + 4096);
     fill_decode_tables(a, t);
     WR_CHECK(wr_launch_decode(&a, 0), -4);
     WR_CHECK(hipDeviceSynchronize(), -4);
@@ -929,7 +992,7 @@ extern "C" long wenet_deframer_push(wenet_deframer *d, const float *symbols, lon
     const long long n = (long long)d->carry.size();
     if (n == 0) return 0;
     const int max_pk = (int)(n / d->spp + 1);
-    if (!d->d_sd.reserve((size_t)n * 4) || !d->d_starts.reserve((size_t)max_pk * 8) || !d->d_out.reserve((size_t)max_pk * sizeof(WrPacketOut)) || !d->d_esn0.reserve((size_t)max_pk * 8 + 256)) return -2;
+    if (!d->d_sd.reserve((size_t)n * 4) || !d->d_starts.reserve((size_t)max_pk * 8) || !d->d_out.reserve((size_t)max_pk * sizeof(WrPacketOut)) || !d->d_esn0.reserve(wr_dec_scratch_bytes((size_t)max_pk))) return -2;
     WR_CHECK(hipMemcpy(d->d_sd.p, d->carry.data(), (size_t)n * 4, hipMemcpyHostToDevice), -3);
     WrDeframeState st;
     memset(&st, 0, sizeof(st));
@@ -948,6 +1011,8 @@ extern "C" long wenet_deframer_push(wenet_deframer *d, const float *symbols, lon
     a.out = d->d_out.as<WrPacketOut>();
     a.esn0 = d->d_esn0.as<double>();
     a.work = (unsigned *)(d->d_esn0.as<double>() + max_pk);
+    a.pbase = (unsigned long long *)(d->d_esn0.as<char>() + (size_t)max_pk * 8 + 4096);
+    a.rec = (WrSlotRec *)(d->d_esn0.as<char>() + (size_t)max_pk * 16 + 4096);
     fill_decode_tables(a, t);
     WR_CHECK(wr_launch_decode(&a, 0), -4);
     WR_CHECK(hipMemcpy(&st, d->d_state.p, sizeof(st), hipMemcpyDeviceToHost), -3);   // synchronises
@@ -1246,7 +1311,7 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw_in, const 
     if (!rx->d_states.reserve(stb * nchan) || !rx->d_chans.reserve(sizeof(WrChan) * nchan) ||
         !rx->d_dchans.reserve(sizeof(WrDeframeChan) * nchan) || !rx->d_dstates.reserve(sizeof(WrDeframeState) * nchan) ||
         !rx->d_sd.reserve((size_t)rx->sd_off[nchan] * 4) || !rx->d_starts.reserve((size_t)nchan * max_pk * 8) ||
-        !rx->d_out.reserve((size_t)nchan * max_pk * sizeof(WrPacketOut)) || !rx->d_esn0.reserve((size_t)nchan * max_pk * 8 + 4096) ||
+        !rx->d_out.reserve((size_t)nchan * max_pk * sizeof(WrPacketOut)) || !rx->d_esn0.reserve(wr_dec_scratch_bytes((size_t)nchan * max_pk)) ||
         !rx->d_census.reserve((size_t)nchan * WR_CENSUS_CLASSES * 4))
         return -2;
     if (rx->want_trace && !rx->d_trace.reserve((size_t)(rx->sd_off[nchan] / c.Nbits) * WR_TRACE_FLOATS * 4)) return -2;
@@ -1296,9 +1361,14 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw_in, const 
     a.dchans = rx->d_dchans.as<WrDeframeChan>();
     a.out = rx->d_out.as<WrPacketOut>();
     a.esn0 = rx->d_esn0.as<double>();
+    a.pbase = (unsigned long long *)(rx->d_esn0.as<char>() + (size_t)nchan * max_pk * 8 + 4096);
+    a.rec = (WrSlotRec *)(rx->d_esn0.as<char>() + (size_t)nchan * max_pk * 16 + 4096);
     a.census = rx->d_census.as<unsigned>();
     a.llr_out = rx->want_llr ? rx->d_llr.as<float>() : nullptr;
     fill_decode_tables(a, t);
+#ifdef WR_DEC_STAMPS
+    if (rx->d_prof.reserve(4096)) { a.dbg = rx->d_prof.as<long long>(); (void)hipMemsetAsync(a.dbg, 0, 64, stream); }
+#endif
     const DemodChoice whole = choose_demod(rx, nchan, fmt);
     const bool use_oct = whole.use_oct;
     auto kernel_name = [](const DemodChoice &d) -> const char * {
@@ -1408,6 +1478,8 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw_in, const 
         ak.dchans = a.dchans + lo;
         ak.out = a.out + (size_t)lo * max_pk;
         ak.esn0 = a.esn0 + (size_t)lo * max_pk;
+        ak.pbase = a.pbase + (size_t)lo * max_pk;
+        ak.rec = a.rec + (size_t)lo * max_pk;
         ak.census = a.census + (size_t)lo * WR_CENSUS_CLASSES;
         if (a.llr_out) ak.llr_out = a.llr_out + (size_t)lo * max_pk * WR_NCODE;
         WR_CHECK(hipEventRecord(e.ev[0], stream), -4);
@@ -1490,6 +1562,8 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw_in, const 
             ap.dchans = ak.dchans + plo;
             ap.out = ak.out + (size_t)plo * max_pk;
             ap.esn0 = ak.esn0 + (size_t)plo * max_pk;
+            ap.pbase = ak.pbase + (size_t)plo * max_pk;
+            ap.rec = ak.rec + (size_t)plo * max_pk;
             ap.work = (unsigned *)(a.esn0 + (size_t)nchan * max_pk) + (k * 4 + p);      // one counter per launch, behind the array
             ap.census = ak.census + (size_t)plo * WR_CENSUS_CLASSES;
             if (ak.llr_out) ap.llr_out = ak.llr_out + (size_t)plo * max_pk * WR_NCODE;
@@ -1641,7 +1715,7 @@ extern "C" long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *c
     }
     rx->max_pk = (int)max_pk;
     if (!rx->d_starts.reserve((size_t)nchan * max_pk * 8) || !rx->d_out.reserve((size_t)nchan * max_pk * sizeof(WrPacketOut)) ||
-        !rx->d_esn0.reserve((size_t)nchan * max_pk * 8 + 4096))
+        !rx->d_esn0.reserve(wr_dec_scratch_bytes((size_t)nchan * max_pk)))
         return -2;
     if (rx->want_trace && !rx->d_trace.reserve((size_t)nchan * (size_t)(rx->live_sd_stride / c.Nbits + 1) * WR_TRACE_FLOATS * 4)) return -2;
     if (rx->want_llr && !rx->d_llr.reserve((size_t)nchan * max_pk * WR_NCODE * 4)) return -2;
@@ -1702,6 +1776,8 @@ extern "C" long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *c
     a.out = rx->d_out.as<WrPacketOut>();
     a.esn0 = rx->d_esn0.as<double>();
     a.work = (unsigned *)(a.esn0 + (size_t)nchan * max_pk);
+    a.pbase = (unsigned long long *)(rx->d_esn0.as<char>() + (size_t)nchan * max_pk * 8 + 4096);
+    a.rec = (WrSlotRec *)(rx->d_esn0.as<char>() + (size_t)nchan * max_pk * 16 + 4096);
     a.census = rx->d_census.as<unsigned>();
     a.llr_out = rx->want_llr ? rx->d_llr.as<float>() : nullptr;
     fill_decode_tables(a, t);
@@ -1791,6 +1867,14 @@ extern "C" int wenet_rx_collect(wenet_rx *rx) {
         }
         rx->slip_rate = fr > 0 ? (double)sl / (double)fr : 0.0;
     }
+#ifdef WR_DEC_STAMPS
+    {
+        long long d[8];
+        if (rx->d_prof.p && hipMemcpy(d, rx->d_prof.p, 64, hipMemcpyDeviceToHost) == hipSuccess && d[6] > 0)
+            fprintf(stderr, "decode stamps (cycles per packet, wave 0): load+llr %.0f | init %.0f | iterations %.0f (%.2f per packet: %.0f each) | pack+store %.0f | to the next top %.0f | packets %lld\n",
+                    (double)d[0] / d[6], (double)d[1] / d[6], (double)d[2] / d[6], (double)d[7] / d[6], (double)d[2] / (d[7] > 0 ? d[7] : 1), (double)d[3] / d[6], (double)d[5] / d[6], d[6]);
+    }
+#endif
     rx->h_census.resize((size_t)nchan * WR_CENSUS_CLASSES);
     WR_CHECK(hipMemcpy(rx->h_census.data(), rx->d_census.p, rx->h_census.size() * 4, hipMemcpyDeviceToHost), -3);
     // packet slots + start offsets were copied to the pinned host buffer behind each decode launch (rx_enqueue)
