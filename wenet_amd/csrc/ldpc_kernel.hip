@@ -203,7 +203,6 @@ __global__ __launch_bounds__(64) void wenet_llr_stats_kernel(WrDecodeArgs A) {
     }
     if (slot < (long long)A.nchan * A.max_pk) {                                         // the decoder's one-load way to the packet (0: the slot is empty)
         A.pbase[slot] = live ? base : 0ull;
-        if (!live && A.rec) { WrSlotRec r; r.base = 0ull; r.esn0 = 0.0; A.rec[slot] = r; }
     }
     if (__ballot(live) == 0) return;
     pbase[lane] = live ? base : 0ull;
@@ -266,7 +265,6 @@ __global__ __launch_bounds__(64) void wenet_llr_stats_kernel(WrDecodeArgs A) {
         const double estvar = (n * sumsq - sum * sum) / (n * (n - 1));
         const double e = wx_est_esn0(estvar);            // 1.0/(2.0L*estvar + 1E-3), x87 rounding
         A.esn0[slot] = e;
-        if (A.rec) { WrSlotRec r; r.base = base; r.esn0 = e; A.rec[slot] = r; }
     }
 }
 
@@ -635,7 +633,6 @@ extern "C" hipError_t wr_launch_deframe(const WrDeframeChan *d_chans, int nchan,
     return hipGetLastError();
 }
 
-extern "C" hipError_t wr_launch_decode2(const WrDecodeArgs *args, hipStream_t stream, int grid);
 extern "C" hipError_t wr_launch_decode(const WrDecodeArgs *args, hipStream_t stream) {
     if (args->nchan <= 0 || args->max_pk <= 0) return hipSuccess;
     const long long slots = (long long)args->nchan * args->max_pk;
@@ -655,14 +652,6 @@ extern "C" hipError_t wr_launch_decode(const WrDecodeArgs *args, hipStream_t str
     const unsigned grid = (unsigned)(slots < want ? slots : want);
     hipError_t e = hipMemsetAsync(args->work, 0, sizeof(unsigned), stream);
     if (e != hipSuccess) return e;
-    // round 4: the byte-cell decoder (ldpc_decode2.hip) for everything that is decoded; the sd_to_llr API (doubles, any n, LLRs only) stays with the round-3
-    // kernel.  WENET_RX_DEC=1 selects the round-3 kernel throughout (comparison runs).
-    static const int which = getenv("WENET_RX_DEC") ? atoi(getenv("WENET_RX_DEC")) : 2;
-    if (which == 2 && args->input_kind != WR_DEC_IN_SD64 && !args->stop_after_llr) {
-        const long long want2 = (long long)(getenv("WENET_RX_DEC_WGS") ? atoi(getenv("WENET_RX_DEC_WGS")) : 4) * ncu;     // (development: workgroups per CU of the grid)
-        e = wr_launch_decode2(args, stream, (int)(slots < want2 ? slots : want2));
-        if (e != hipSuccess) return e;
-    } else
     hipLaunchKernelGGL(wenet_decode_kernel, dim3(grid), dim3(WR_DEC_THREADS), lds, stream, *args);
     if (!args->stop_after_llr && args->out)
         hipLaunchKernelGGL(wenet_crc_kernel, dim3(blocks), dim3(256), 0, stream, *args);

@@ -221,12 +221,10 @@ struct WrPacketOut {            // one per packet slot
 
 enum { WR_DEC_IN_STREAM = 0, WR_DEC_IN_SD64 = 1, WR_DEC_IN_LLR = 2 };
 // per-launch scratch of the decoder behind one allocation: estEsN0[nslots] | 4096 bytes of work counters | packet addresses [nslots]
-static inline size_t wr_dec_scratch_bytes(size_t nslots) { return nslots * 32 + 4096; }         // (+ the 16-byte records of the round-4 decoder)
+static inline size_t wr_dec_scratch_bytes(size_t nslots) { return nslots * 16 + 4096; }
 // packet type classes (first payload byte, rx/WenetPackets.py:28-35): 0x00 text, 0x01 GPS, 0x02 orientation,
 // 0x03 secondary payload, 0x54 image telemetry, 0x55 SSDV, 0x56 idle, anything else
 #define WR_CENSUS_CLASSES 8
-
-struct WrSlotRec { unsigned long long base; double esn0; };      // where a slot's packet starts (0: none) and its estEsN0
 
 struct WrDecodeArgs {
     int input_kind;             // WR_DEC_IN_*
@@ -246,7 +244,6 @@ struct WrDecodeArgs {
     float       *llr_out;               // optional [nchan*max_pk*n]
     uint8_t     *bits_out;              // optional [nchan*max_pk*2580] all decoded bits (run_ldpc_decoder API)
     double      *esn0;                  // [nchan*max_pk] estEsN0 per packet (wenet_llr_stats_kernel -> decode)
-    struct WrSlotRec *rec;              // [nchan*max_pk] the same two as one 16-byte record per slot (the round-4 decoder fetches it with one LDS-DMA instruction)
     unsigned long long *pbase;          // [nchan*max_pk] address of the packet's first stored symbol, 0 = the slot holds no packet (wenet_llr_stats_kernel -> decode:
                                         //  the decoder finds a packet with ONE load instead of the chain channel table -> deframer state -> start offset)
     unsigned    *census;                // optional [nchan][WR_CENSUS_CLASSES]: CRC-valid packets by type byte (wenet_crc_kernel)
@@ -257,11 +254,6 @@ struct WrDecodeArgs {
     const uint4    *phi0_lut;           // [90]
     int             phase;              // wr_launch_decode: 0 = everything, 1 = LLR statistics only, 2 = decode + CRC only (statistics done by an earlier call)
     const uint8_t  *scramble;           // [125]
-    // round 4 decoder (wenet_decode2_kernel, ldpc_decode2.hip): one-byte message cells [check][16] = sign << 7 | index into the 104 phi0 values
-    const int2     *d2_cells;           // [WR_PHI0_LUT_ENTRIES] {threshold as float bits (+Inf: no step in the cell), index of the value below it}; above it: index + 1
-    const float    *d2_vt;              // [256] value of a message byte: vt[i] = value i, vt[128 + i] = -value i
-    const uint16_t *vedge2;             // [2064*3] byte address check * 16 + slot of each data bit's edges, socket order
-    const uint16_t *vpos2;              // [2580] placement of the variables for that layout's bank pattern
     long long      *dbg;                // development (-DWR_DEC_STAMPS builds only): cycle totals of the decode kernel's per-packet phases
 };
 
@@ -304,17 +296,3 @@ static const float WR_PHI0_LT1_V[27] = {  // value when x > T[k] (and x <= T[k-1
 #define WR_DEC_OFF_RED  (WR_DEC_OFF_LUT + WR_PHI0_LUT_ENTRIES * 16)                 // [2][2] reduction cells: satisfied checks / any data bit set, by iteration parity
 #define WR_DEC_OFF_CLAIM (WR_DEC_OFF_RED + 16)                                       // [2] packet claims {slot, -, address (2 words), estEsN0 (2 words)}: this packet's and the next one's
 #define WR_DEC_LDS_BYTES (WR_DEC_OFF_CLAIM + 64)
-// LDS carve-up of wenet_decode2_kernel (round 4): message bytes [516][16] | phi0 cells [642] int2 | byte -> value [256] | two buffers of the thread-ordered
-// soft symbols / LLRs [6][512] floats (this packet's, and the next one's landing there by LDS-DMA) | packed output bits | reduction cells | claims and records
-#define WR_PHI0_NVALS   104                                                         // the 103 values of phi0 in the order of rising argument + 10.0 again (arguments >= 2^15: x86 cvttss2si overflow)
-#define WR_D2_LLB_BYTES (WR_VARS_PER_THREAD * WR_DEC_THREADS * 4)
-#define WR_D2_OFF_LLB   0
-#define WR_D2_OFF_VT    (WR_D2_OFF_LLB + 2 * WR_D2_LLB_BYTES)
-#define WR_D2_OFF_WORDS (WR_D2_OFF_VT + 1024)
-#define WR_D2_OFF_RED   (WR_D2_OFF_WORDS + 336)
-#define WR_D2_OFF_CLAIM (WR_D2_OFF_RED + 16)
-#define WR_D2_OFF_REC   (WR_D2_OFF_CLAIM + 16)                                      // [2] {packet address (2 words), estEsN0 (2 words)}: 16-byte records, the LDS-DMA's destination
-#define WR_D2_OFF_MSG   (WR_D2_OFF_REC + 32 + 112)                                  // (16-byte aligned)
-#define WR_D2_OFF_CELL  (WR_D2_OFF_MSG + WR_NPAR * 16)                              // behind everything else: cell address = key * 8 + (this - 8 * WR_PHI0_KEY_BIAS) with a
-                                                                                    // non-negative constant, i.e. the key's bias rides in the LDS instruction's offset field
-#define WR_D2_LDS_BYTES (WR_D2_OFF_CELL + WR_PHI0_LUT_ENTRIES * 8)

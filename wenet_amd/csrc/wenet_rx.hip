@@ -521,15 +521,6 @@ static void place_variables(std::vector<uint16_t> &vpos, BankFn bank, int *cost0
     if (getenv("WENET_RX_NO_PLACE")) for (int v = 0; v < WR_NCODE; v++) vpos[v] = (uint16_t)v;     // development: natural order
 }
 
-// host twin of the round-4 decoder's phi0 (ldpc_decode2.hip): index of the value, from the cell {threshold as a float, index below it}
-inline int phi0_cells_index(const int *cells, float xf_nonneg) {
-    int32_t b; memcpy(&b, &xf_nonneg, 4);
-    int key = (b >> 18) - WR_PHI0_KEY_BIAS;
-    key = key < 0 ? 0 : (key > WR_PHI0_LUT_ENTRIES - 1 ? WR_PHI0_LUT_ENTRIES - 1 : key);
-    float thr; memcpy(&thr, &cells[2 * key], 4);
-    return cells[2 * key + 1] + (!(xf_nonneg < thr) ? 1 : 0);
-}
-
 struct LdpcTables {
     DevBuf blob;
     const uint16_t *d_vedge = nullptr;
@@ -537,8 +528,6 @@ struct LdpcTables {
     int place_cost0 = 0, place_cost = 0;                // bank overload of the variable pass before / after the placement search
     const uint4 *d_lut = nullptr;
     const uint8_t *d_scramble = nullptr;
-    const int2 *d_cells2 = nullptr; const float *d_vt2 = nullptr; const uint16_t *d_vedge2 = nullptr, *d_vpos2 = nullptr;   // round-4 decoder (byte cells)
-    int place2_cost0 = 0, place2_cost = 0;
     bool ok = false;
 
     bool build() {
@@ -555,10 +544,6 @@ struct LdpcTables {
         for (int v = 0; v < WR_NDATA; v++) if (deg[v] != 3) { fprintf(stderr, "libwenet_rx: code table: column weight != 3\n"); return false; }
         std::vector<uint16_t> vpos;
         place_variables(vpos, [&](int v, int k) { return vedge[v * 3 + k] & 31; }, &place_cost0, &place_cost);
-        // round-4 decoder: message bytes at check * 16 + slot; bank = dword address mod 32
-        std::vector<uint16_t> vedge2(WR_NDATA * 3), vpos2;
-        for (int v = 0; v < WR_NDATA; v++) for (int k = 0; k < 3; k++) { const int e = vedge[v * 3 + k], slot = e / WR_NPAR, chk = e % WR_NPAR; vedge2[v * 3 + k] = (uint16_t)(chk * 16 + slot); }
-        place_variables(vpos2, [&](int v, int k) { return (vedge2[v * 3 + k] >> 2) & 31; }, &place2_cost0, &place2_cost);
         // phi0 LUT keyed by the float bits of y (see wenet_internal.h)
         std::vector<uint32_t> lut(WR_PHI0_LUT_ENTRIES * 4, 0);
         {
@@ -595,55 +580,13 @@ struct LdpcTables {
                 fprintf(stderr, "libwenet_rx: phi0 table self-check failed at xf=%g\n", (double)xf);
                 return false;
             }
-        // round-4 decoder: the same function as {threshold, index of the value below it} per cell and a list of the values in the order of rising argument
-        // (phi0 falls monotonically, so the value above a cell's threshold is the next of the list); the list ends with 10.0 again for arguments
-        // beyond 2^15 (x86 cvttss2si overflow).  The kernel compares |x| with the threshold as FLOATS (not-less-than: true for NaN, which lands in
-        // the last cell); cells without a step carry +Inf.
-        std::vector<int> cells(WR_PHI0_LUT_ENTRIES * 2, 0);
-        std::vector<float> vals;
-        {
-            auto u2f = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
-            vals.push_back(u2f(lut[1]));                                             // entry 0: 10.0
-            for (int k = 0; k < WR_PHI0_LUT_ENTRIES; k++) {
-                const uint32_t thr = lut[k * 4], below = lut[k * 4 + 1], above = lut[k * 4 + 2];
-                if (k == WR_PHI0_LUT_ENTRIES - 1) {                                  // {2^15, 0.0 below, 10.0 at and above}
-                    if (f2u(vals.back()) != below) vals.push_back(u2f(below));
-                    cells[2 * k] = (int)thr; cells[2 * k + 1] = (int)vals.size() - 1;
-                    vals.push_back(u2f(above));
-                    continue;
-                }
-                if (f2u(vals.back()) != below) {                                     // a step exactly on the cell's lower edge: the cell starts with the next value
-                    if (!(u2f(below) < vals.back())) { fprintf(stderr, "libwenet_rx: phi0 cells: cell %d does not continue the value list\n", k); return false; }
-                    vals.push_back(u2f(below));
-                }
-                cells[2 * k + 1] = (int)vals.size() - 1;
-                if (thr == 0x7fffffffu || above == below) cells[2 * k] = 0x7f800000;  // no step: +Inf
-                else { cells[2 * k] = (int)thr; vals.push_back(u2f(above)); }
-            }
-            if ((int)vals.size() != WR_PHI0_NVALS) { fprintf(stderr, "libwenet_rx: phi0 cells: %zu values, expected %d\n", vals.size(), WR_PHI0_NVALS); return false; }
-            for (int x = 0; x <= 1100000; x++)
-                for (float fr : {0.0f, 0.5f}) {
-                    const float xf = ((float)x + fr) / 65536.0f;
-                    if (f2u(vals[phi0_cells_index(cells.data(), xf)]) != f2u(phi0_x86(xf))) { fprintf(stderr, "libwenet_rx: phi0 cells self-check failed at y=%g\n", (double)x + fr); return false; }
-                }
-            for (float xf : {0.0f, 1e-30f, 1.5e-5f, 16.0f, 32767.0f, 32767.99f, 32768.0f, 1e9f, 3e38f, INFINITY, NAN})
-                if (f2u(vals[phi0_cells_index(cells.data(), xf)]) != f2u(phi0_x86(xf))) { fprintf(stderr, "libwenet_rx: phi0 cells self-check failed at xf=%g\n", (double)xf); return false; }
-        }
-        std::vector<uint32_t> vt(256, 0);
-        for (int i = 0; i < WR_PHI0_NVALS; i++) { vt[i] = f2u(vals[i]); vt[128 + i] = f2u(vals[i]) | 0x80000000u; }
         size_t a_v = 0, a_l = (WR_NDATA * 3 * 2 + 255) & ~255, a_s = a_l + ((WR_PHI0_LUT_ENTRIES * 16 + 255) & ~255), a_p = a_s + 256;
-        const size_t a_c2 = (a_p + WR_NCODE * 2 + 255) & ~(size_t)255, a_vt = a_c2 + ((WR_PHI0_LUT_ENTRIES * 8 + 255) & ~255), a_ve2 = a_vt + 1024, a_vp2 = (a_ve2 + WR_NDATA * 3 * 2 + 255) & ~(size_t)255;
-        if (!blob.reserve(a_vp2 + WR_NCODE * 2 + 256)) return false;
+        if (!blob.reserve(a_p + WR_NCODE * 2 + 256)) return false;
         char *base = blob.as<char>();
         WR_CHECK(hipMemcpy(base + a_v, vedge.data(), WR_NDATA * 3 * 2, hipMemcpyHostToDevice), false);
         WR_CHECK(hipMemcpy(base + a_l, lut.data(), WR_PHI0_LUT_ENTRIES * 16, hipMemcpyHostToDevice), false);
         WR_CHECK(hipMemcpy(base + a_s, kScramble, 125, hipMemcpyHostToDevice), false);
         WR_CHECK(hipMemcpy(base + a_p, vpos.data(), WR_NCODE * 2, hipMemcpyHostToDevice), false);
-        WR_CHECK(hipMemcpy(base + a_c2, cells.data(), WR_PHI0_LUT_ENTRIES * 8, hipMemcpyHostToDevice), false);
-        WR_CHECK(hipMemcpy(base + a_vt, vt.data(), 1024, hipMemcpyHostToDevice), false);
-        WR_CHECK(hipMemcpy(base + a_ve2, vedge2.data(), WR_NDATA * 3 * 2, hipMemcpyHostToDevice), false);
-        WR_CHECK(hipMemcpy(base + a_vp2, vpos2.data(), WR_NCODE * 2, hipMemcpyHostToDevice), false);
-        d_cells2 = (const int2 *)(base + a_c2); d_vt2 = (const float *)(base + a_vt); d_vedge2 = (const uint16_t *)(base + a_ve2); d_vpos2 = (const uint16_t *)(base + a_vp2);
         d_vpos = (const uint16_t *)(base + a_p);
         d_vedge = (const uint16_t *)(base + a_v);
         d_lut = (const uint4 *)(base + a_l);
@@ -669,7 +612,6 @@ LdpcTables *ldpc_tables() {                                            // the co
 
 void fill_decode_tables(WrDecodeArgs &a, const LdpcTables *t) {
     a.vedge = t->d_vedge; a.vpos = t->d_vpos; a.phi0_lut = t->d_lut; a.scramble = t->d_scramble;
-    a.d2_cells = t->d_cells2; a.d2_vt = t->d_vt2; a.vedge2 = t->d_vedge2; a.vpos2 = t->d_vpos2;
 }
 
 }  // namespace
@@ -916,7 +858,6 @@ int run_dense(int kind, const void *in, int npk, int n, int mode, int max_iter, 
     a.esn0 = g_dec.d_esn0.as<double>();
     a.work = (unsigned *)(g_dec.d_esn0.as<double>() + npk);            // (inside the 4096 bytes reserved behind the estimates)
     a.pbase = (unsigned long long *)(g_dec.d_esn0.as<char>() + (size_t)npk * 8 + 4096);
-    a.rec = (WrSlotRec *)(g_dec.d_esn0.as<char>() + (size_t)npk * 16 + 4096);
     fill_decode_tables(a, t);
     WR_CHECK(wr_launch_decode(&a, 0), -4);
     WR_CHECK(hipDeviceSynchronize(), -4);
@@ -1012,7 +953,6 @@ extern "C" long wenet_deframer_push(wenet_deframer *d, const float *symbols, lon
     a.esn0 = d->d_esn0.as<double>();
     a.work = (unsigned *)(d->d_esn0.as<double>() + max_pk);
     a.pbase = (unsigned long long *)(d->d_esn0.as<char>() + (size_t)max_pk * 8 + 4096);
-    a.rec = (WrSlotRec *)(d->d_esn0.as<char>() + (size_t)max_pk * 16 + 4096);
     fill_decode_tables(a, t);
     WR_CHECK(wr_launch_decode(&a, 0), -4);
     WR_CHECK(hipMemcpy(&st, d->d_state.p, sizeof(st), hipMemcpyDeviceToHost), -3);   // synchronises
@@ -1362,7 +1302,6 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw_in, const 
     a.out = rx->d_out.as<WrPacketOut>();
     a.esn0 = rx->d_esn0.as<double>();
     a.pbase = (unsigned long long *)(rx->d_esn0.as<char>() + (size_t)nchan * max_pk * 8 + 4096);
-    a.rec = (WrSlotRec *)(rx->d_esn0.as<char>() + (size_t)nchan * max_pk * 16 + 4096);
     a.census = rx->d_census.as<unsigned>();
     a.llr_out = rx->want_llr ? rx->d_llr.as<float>() : nullptr;
     fill_decode_tables(a, t);
@@ -1479,7 +1418,6 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw_in, const 
         ak.out = a.out + (size_t)lo * max_pk;
         ak.esn0 = a.esn0 + (size_t)lo * max_pk;
         ak.pbase = a.pbase + (size_t)lo * max_pk;
-        ak.rec = a.rec + (size_t)lo * max_pk;
         ak.census = a.census + (size_t)lo * WR_CENSUS_CLASSES;
         if (a.llr_out) ak.llr_out = a.llr_out + (size_t)lo * max_pk * WR_NCODE;
         WR_CHECK(hipEventRecord(e.ev[0], stream), -4);
@@ -1563,7 +1501,6 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw_in, const 
             ap.out = ak.out + (size_t)plo * max_pk;
             ap.esn0 = ak.esn0 + (size_t)plo * max_pk;
             ap.pbase = ak.pbase + (size_t)plo * max_pk;
-            ap.rec = ak.rec + (size_t)plo * max_pk;
             ap.work = (unsigned *)(a.esn0 + (size_t)nchan * max_pk) + (k * 4 + p);      // one counter per launch, behind the array
             ap.census = ak.census + (size_t)plo * WR_CENSUS_CLASSES;
             if (ak.llr_out) ap.llr_out = ak.llr_out + (size_t)plo * max_pk * WR_NCODE;
@@ -1777,7 +1714,6 @@ extern "C" long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *c
     a.esn0 = rx->d_esn0.as<double>();
     a.work = (unsigned *)(a.esn0 + (size_t)nchan * max_pk);
     a.pbase = (unsigned long long *)(rx->d_esn0.as<char>() + (size_t)nchan * max_pk * 8 + 4096);
-    a.rec = (WrSlotRec *)(rx->d_esn0.as<char>() + (size_t)nchan * max_pk * 16 + 4096);
     a.census = rx->d_census.as<unsigned>();
     a.llr_out = rx->want_llr ? rx->d_llr.as<float>() : nullptr;
     fill_decode_tables(a, t);
