@@ -6,8 +6,8 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 D=$ROOT/tools/prof_build
 rm -rf $D; mkdir -p $D/wenet_amd/csrc $D/include
 cp -r $ROOT/wenet_amd/csrc/*.h $ROOT/wenet_amd/csrc/*.hip $ROOT/wenet_amd/csrc/*.inc $ROOT/wenet_amd/csrc/*.cpp $ROOT/wenet_amd/csrc/Makefile $ROOT/wenet_amd/csrc/tables $D/wenet_amd/csrc/
-cp $ROOT/include/*.h $D/include/
-make -s -C $D/wenet_amd/csrc PROF=1 ../libwenet_rx.so
+cp $ROOT/include/*.h $D/include/; cp $ROOT/wenet_amd/codeid.py $D/wenet_amd/
+make -s -j8 -C $D/wenet_amd/csrc PROF=1 EXTRA="$PROF_EXTRA" ../libwenet_rx.so
 mv $D/wenet_amd/libwenet_rx.so $D/libwenet_rx.so
 rm -rf $D/wenet_amd $D/include
 ls -la $D

@@ -18,6 +18,9 @@ extern "C" hipError_t wr_launch_demod_oct(const WrDemodCfg *cfg, const WrChan *d
     } while (0)
     const bool duo = cfg->o_nd == 2;
     // (two duty waves pay for the large geometry -- 72.7 against 83.4 ms per 1024 captures x 2 s -- and cost the small ones 3 %: not instantiated there)
+#ifdef WO_SMALL_ND2                                                          // development (tools/variant_build.sh ... -DWO_SMALL_ND2): the small geometry with a chain wave and a sum wave
+    if (cfg->M == 2 && cfg->Ts == 10 && cfg->Ndft == 256 && duo && !cfg->o_hlp) { WO_LAUNCH(2, 10, 256, 2, false); } else
+#endif
     if (cfg->M == 2 && cfg->Ts == 10 && cfg->Ndft == 256)       { if (duo || cfg->o_hlp) return hipErrorInvalidValue; WO_LAUNCH(2, 10, 256, 1, false); }
     else if (cfg->M == 2 && cfg->Ts == 8 && cfg->Ndft == 256)   { if (duo || cfg->o_hlp) return hipErrorInvalidValue; WO_LAUNCH(2, 8, 256, 1, false); }
     else if (cfg->M == 4 && cfg->Ts == 32 && cfg->Ndft == 1024) {

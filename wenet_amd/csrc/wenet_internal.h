@@ -90,8 +90,11 @@ struct WrDemodCfg {
 // The mix stage of the batch kernel parks, of the Ts integrator outputs per symbol and tone, only those the resampler can ask for while the
 // timing estimate stays near the previous frame's: offsets low - W .. low + W + 1 around the previous low_sample cover every rx_timing within
 // W - 0.06 samples of the previous one (W = 1: four outputs; the 32-sample symbols of the 4-FSK geometry move by more than a sample per frame
-// at 8 dB: W = 3, eight of 32).
-constexpr int wo_park_halfwidth(int Ts) { return Ts >= 32 ? 3 : 1; }
+// at 8 dB: W = 4, ten of 32 -- round 3 ran W = 3; W = 2 .. 7 measured in round 4: 58.1 / 55.4 / 54.5 / 54.4 / 54.7 / 54.9 ms per 1024 captures x 2 s).
+#ifndef WO_PARK_W32
+#define WO_PARK_W32 4                 // (round 4: measured 2..7 at config 4, profiles/r04_park_w32.txt; development: tools/variant_build.sh ... -DWO_PARK_W32=<W> for demod_oct demod_oct_sliced wenet_rx)
+#endif
+constexpr int wo_park_halfwidth(int Ts) { return Ts >= 32 ? WO_PARK_W32 : 1; }
 struct WoLayout { int FB, FW, TP, FE, CK, CT, PW, PK, stride, ntw, TW, HANN, DPHI, SRC, BACK, tab, nhb; };
 constexpr int wo_align16(int x) { return (x + 15) & ~15; }
 // hlp: the mix stage of ONE capture on M wavefronts (a tone each: the single-stream form of the large geometry): per-tone power rows and the

@@ -1192,7 +1192,7 @@ static DemodChoice choose_demod(wenet_rx *rx, int n_sel, int fmt) {
     WrDemodCfg oct_cfg;
     bool use_oct = false;
     if (oct_caps > 0) {
-        if (getenv("WENET_RX_OCT_ND") && c.M == 4) oct_nd = atoi(getenv("WENET_RX_OCT_ND")) == 2 ? 2 : 1;
+        if (getenv("WENET_RX_OCT_ND") && (c.M == 4 || getenv("WENET_RX_OCT") != nullptr)) oct_nd = atoi(getenv("WENET_RX_OCT_ND")) == 2 ? 2 : 1;      // (small geometries: only in a -DWO_SMALL_ND2 development build)
         if (getenv("WENET_RX_OCT_HLP")) oct_hlp = atoi(getenv("WENET_RX_OCT_HLP")) != 0;
         oct_cfg = rx->tab.oct_cfg(oct_caps, oct_nd, oct_hlp);
         use_oct = oct_cfg.o_ok != 0 && fmt == WENET_FMT_CU8;
