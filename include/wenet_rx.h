@@ -92,6 +92,8 @@ void wenet_fsk_enable_stats(wenet_fsk *fsk, long first, long period);
  * which a snapshot was kept (with wenet_fsk_enable_stats(fsk, 0, 1): after the frame the last fsk_demod / fsk_demod_sd call
  * processed, as in the reference).  All zeros before the first snapshot. */
 void wenet_fsk_get_demod_stats(wenet_fsk *fsk, wenet_modem_stats *stats);
+/* fsk->EbNodB (src/fsk.h:77, src/fsk.c:1009) of the last demodulated frame; needs wenet_fsk_enable_stats */
+float wenet_fsk_last_ebnodb(wenet_fsk *fsk);
 /* Stats snapshots produced by the last wenet_fsk_demod_stream call; returns how many were copied. */
 int wenet_fsk_get_stats(wenet_fsk *fsk, wenet_modem_stats *out, int cap);
 

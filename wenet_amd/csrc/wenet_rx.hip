@@ -627,6 +627,7 @@ struct wenet_fsk {
     long long frames_total = 0;
     long stats_first = -1, stats_period = 0;
     float snr_est = 0.f;           // fsk->stats->snr_est recursion (fsk.c:1021), host side
+    float ebnodb_last = 0.f;       // fsk->EbNodB of the last demodulated frame (fsk.c:1009)
     float f_est_last[4] = {0, 0, 0, 0};
     std::vector<wenet_modem_stats> stats_out;
     wenet_modem_stats last_stats;  // most recent snapshot (wenet_fsk_get_demod_stats)
@@ -767,6 +768,7 @@ extern "C" long wenet_fsk_demod_stream(wenet_fsk *f, int fmt, const void *raw, l
             if (meanebno == meanebno) {                                 // (NaN: the reference returned before fsk.c:1009/1021 on this frame)
                 const float EbNodB = -6 + (20 * log10f((float)((1e-6 + meanebno) / (1e-6 + stdebno))));
                 f->snr_est = (float)(.5 * f->snr_est + .5 * EbNodB);
+                f->ebnodb_last = EbNodB;
             }
             for (int m = 0; m < 4; m++) f->f_est_last[m] = t[WR_TR_FEST + m];
             if (di < got && k == next_dump) {
@@ -809,6 +811,8 @@ extern "C" void wenet_fsk_get_demod_stats(wenet_fsk *f, wenet_modem_stats *stats
     if (!stats) return;
     if (f && f->have_last_stats) *stats = f->last_stats; else memset(stats, 0, sizeof(*stats));
 }
+
+extern "C" float wenet_fsk_last_ebnodb(wenet_fsk *f) { return f ? f->ebnodb_last : 0.f; }
 
 extern "C" int wenet_fsk_get_stats(wenet_fsk *f, wenet_modem_stats *out, int cap) {
     if (!f) return 0;

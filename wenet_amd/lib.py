@@ -28,7 +28,7 @@ EXPORTS = [
     "wenet_rx_enable_trace", "wenet_rx_get_trace", "wenet_rx_enable_llr_dump", "wenet_rx_get_llrs",
     "wenet_rx_last_ms", "wenet_rx_device_info", "wenet_rx_version", "wenet_rx_last_kernel", "wenet_rx_get_device", "wenet_rx_channel_counter", "wenet_rx_set_cf32_quantise",
     "wenet_packet_type_class", "wenet_ssdv_packet_info", "wenet_rx_get_packets_of_class", "wenet_rx_ssdv_images",
-    "wenet_phi0_eval", "wenet_rx_source_id", "wenet_rx_push", "wenet_rx_flush",
+    "wenet_phi0_eval", "wenet_rx_source_id", "wenet_rx_push", "wenet_rx_flush", "wenet_fsk_last_ebnodb",
 ]
 # every symbol include/wenet_tx.h declares
 EXPORTS_TX = [
@@ -89,6 +89,7 @@ def load():
     L.wenet_fsk_enable_stats.argtypes = [vp, l, l]
     L.wenet_fsk_get_stats.argtypes = [vp, C.POINTER(ModemStats), i]
     L.wenet_fsk_get_demod_stats.argtypes = [vp, C.POINTER(ModemStats)]
+    L.wenet_fsk_last_ebnodb.restype = f; L.wenet_fsk_last_ebnodb.argtypes = [vp]
     L.wenet_run_ldpc_decoder.argtypes = [C.POINTER(LdpcStruct), vp, vp, C.POINTER(i)]
     L.wenet_sd_to_llr.argtypes = [vp, vp, i]
     L.wenet_ldpc_decode_batch.argtypes = [vp, i, i, vp, vp, vp]
