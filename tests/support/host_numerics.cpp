@@ -7,6 +7,7 @@
 #include <cstring>
 #include "../../wenet_amd/csrc/glibc_atan2f.h"
 #include "../../wenet_amd/csrc/x87emu.h"
+#include "../../wenet_amd/csrc/ldpc_host_tables.h"
 
 static inline uint64_t splitmix(uint64_t &s) {
     uint64_t z = (s += 0x9e3779b97f4a7c15ULL);
@@ -92,4 +93,20 @@ long check_x87(long n, uint64_t seed, double *first_bad) {
     }
     return bad;
 }
+// the decoder's phi0 table (ldpc_host_tables.h) against the reference form (phi0.c:13-218 with x86 cast semantics) on EVERY integer and half-integer
+// argument up to 1.1e6 / 65536, every threshold's neighbours and the special values; 1 = all equal.  The library checks a 61st of these at start-up.
+int check_phi0_table_exhaustive(void) {
+    std::vector<uint32_t> lut;
+    return phi0_build_lut(lut, true) ? 1 : 0;
 }
+// the shipped placement of the variables on the decoder's threads: valid, and what the search of ldpc_host_tables.h finds today (1 = both)
+int check_shipped_placement(void) {
+    std::vector<uint16_t> vedge, vpos;
+    if (!ldpc_build_vedge(vedge) || !ldpc_vpos_valid(kVposShipped)) return 0;
+    int c0 = 0, c1 = 0;
+    place_variables(vpos, [&](int v, int k) { return vedge[v * 3 + k] & 31; }, &c0, &c1);
+    for (int p = 0; p < WR_NCODE; p++) if (vpos[p] != kVposShipped[p]) return 0;
+    return 1;
+}
+}
+

@@ -18,6 +18,8 @@ def hn(tmp_path_factory):
     L.check_atanf.restype = C.c_long; L.check_atanf.argtypes = [C.c_long, C.POINTER(C.c_long)]
     L.check_atan2f.restype = C.c_long; L.check_atan2f.argtypes = [C.c_long, C.c_uint64, C.POINTER(C.c_uint32)]
     L.check_x87.restype = C.c_long; L.check_x87.argtypes = [C.c_long, C.c_uint64, C.POINTER(C.c_double)]
+    L.check_phi0_table_exhaustive.restype = C.c_int
+    L.check_shipped_placement.restype = C.c_int
     return L
 
 
@@ -34,3 +36,15 @@ def test_atan2f_matches_host_libm(hn):
 def test_x87_emulation_matches_long_double(hn):
     fb = (C.c_double * 2)()
     assert hn.check_x87(10_000_000, 99, fb) == 0, (fb[0], fb[1])
+
+
+def test_phi0_table_equals_the_reference_form_exhaustively(hn):
+    """the decoder's keyed phi0 table (wenet_amd/csrc/ldpc_host_tables.h) on every integer and half-integer fixed-point argument, every threshold's
+    neighbours and the special values, against phi0.c:13-218 with x86 cast semantics (the library itself checks a 61st of them at every start)"""
+    assert hn.check_phi0_table_exhaustive() == 1
+
+
+def test_shipped_variable_placement_is_valid_and_reproducible(hn):
+    """tables/ldpc_vpos.inc is a permutation of the data variables over the data positions (parity variables in place) and equals what tools/gen_vpos.cpp's
+    search produces from the code tables"""
+    assert hn.check_shipped_placement() == 1

@@ -1,0 +1,49 @@
+# Round-4 measurement set on the GPU box (outputs under gpurun_out/, copied into profiles/ afterwards): headline profile round, BASELINE config 4 (batch + single
+# stream), v1, batch sizes (multiples of a round and not), live channels (in the headline line), host feed (pinned and pageable), CLI timings, config 3 at scale, soaks.
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
+bash tools/gpu_profile_round.sh 3584 r04 > gpurun_out/r04_round.log 2>&1
+cd $GRAFT_REPO_ROOT
+bash tools/gpu_profile_round.sh 1024 r04c4 --config 4fsk --max-iter 50 > gpurun_out/r04c4_round.log 2>&1
+cd $GRAFT_REPO_ROOT
+python bench.py --config v1 --captures 3584 --no-extras 2>/dev/null | tail -1 > gpurun_out/r04_bench_v1_b3584.json
+python bench.py --config 4fsk --captures 1 --max-iter 50 --no-extras 2>/dev/null | tail -1 > gpurun_out/r04_bench_config4_b1.json
+for B in 16 256 768 1536 2048 3600 4000 5000 7168; do
+  python bench.py --captures $B --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > gpurun_out/r04_bench_b$B.json
+done
+python bench.py --captures 3584 --ppm 100 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > gpurun_out/r04_bench_b3584_100ppm.json
+{
+  echo "# one 10 s v2 capture through the command lines (VERDICT r03 item 5): tools/cli_pipe.py and tools/cli_fused_time.py on the GPU box, reference binaries beside them"
+  python tools/cli_pipe.py 10 2>&1 | grep -v amdgpu.ids
+  python tools/cli_fused_time.py 10 2>&1 | grep -v amdgpu.ids
+} > gpurun_out/r04_cli_times.txt 2>&1
+{
+  for k in pinned pageable; do python tools/host_feed.py 768 10 $k 2>&1 | grep -v amdgpu.ids; python tools/host_feed.py 256 10 $k 2>&1 | grep -v amdgpu.ids; done
+  python tools/host_feed.py 3584 10 pinned 2>&1 | grep -v amdgpu.ids
+} > gpurun_out/r04_host_feed.txt 2>&1
+{
+  echo "# Parity soak, round 4 (tools/soak.py, tools/soak_short.py): random captures (Eb/N0 3-15 dB, clock error 0 or +-1500 ppm, 1-13 packets) through the GPU chain,"
+  echo "# soft decisions and packets compared bit for bit with the CPU oracle."
+  echo "## batch demodulator, 7 captures per workgroup, v2 + v1, host-fed time slices of 20 000 samples"
+  WENET_RX_OCT=7 WENET_RX_SLICE_SAMPLES=20000 python tools/soak.py 500 41 2>&1 | tail -2
+  echo "## batch demodulator, 4 per workgroup, one launch per capture set"
+  WENET_RX_OCT=4 WENET_RX_NO_SLICES=1 python tools/soak.py 400 42 2>&1 | tail -2
+  echo "## default kernel choice (pipelined kernels), slices of 50 000 samples"
+  WENET_RX_SLICE_SAMPLES=50000 python tools/soak.py 200 43 2>&1 | tail -2
+  echo "## 4-FSK Ts 32: four captures + chain wave + sum wave per workgroup; the single-stream form"
+  WENET_RX_OCT=4 WENET_RX_OCT_ND=2 python tools/soak.py 120 44 4fsk 2>&1 | tail -2
+  WENET_RX_OCT=1 WENET_RX_OCT_ND=2 WENET_RX_OCT_HLP=1 WENET_RX_SLICE_SAMPLES=300000 python tools/soak.py 80 46 4fsk 2>&1 | tail -2
+  echo "## captures of 0..6 frames"
+  WENET_RX_OCT=7 python tools/soak_short.py 2>&1 | tail -1
+} > gpurun_out/r04_soak.txt 2>&1
+python tools/sweep.py --config v2 --n 3584 --bins 17 --check-cpu 6 > gpurun_out/r04_config3_sweep3584_v2.md 2>&1
+python tools/gpu_allout.py v2 3584 2 8 > gpurun_out/r04_allout.txt 2>&1; python tools/gpu_allout.py 4fsk 1024 2 8 >> gpurun_out/r04_allout.txt 2>&1
+python - <<'PY'
+import json, glob
+for f in sorted(glob.glob("gpurun_out/r04*_bench_*.json")):
+    try:
+        d = json.load(open(f))
+        print(f, d["value"], d["kernel_ms"], d["roofline"]["kernel"], d["roofline"].get("frac"), d["roofline"].get("traffic"), (d.get("cpu_baseline") or {}).get("value"))
+    except Exception as e:
+        print(f, "ERR", e)
+PY
+cat gpurun_out/r04_soak.txt; cat gpurun_out/r04_host_feed.txt; cat gpurun_out/r04_allout.txt; cat gpurun_out/r04_cli_times.txt

@@ -1,0 +1,172 @@
+// ldpc_host_tables.h -- host-side construction of the decoder's tables (plain C++, no HIP): the graph's variable side, the placement of the variables on the
+// threads, the phi0 table.  Included by wenet_rx.hip (the library), tools/gen_vpos.cpp (writes tables/ldpc_vpos.inc) and tests/support/host_numerics.cpp
+// (the exhaustive phi0 check, tests/test_host_numerics.py).
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#if !defined(__HIPCC__) && !defined(WR_HOST_VECTOR_TYPES)          // (plain g++ builds of the generator and the test harness: the two HIP vector types wenet_internal.h names)
+#define WR_HOST_VECTOR_TYPES
+struct float2 { float x, y; };
+struct uint4 { unsigned x, y, z, w; };
+#endif
+#include "wenet_internal.h"
+
+namespace {
+
+const uint16_t kHRows[WR_NPAR * WR_ROWW] = {
+#include "tables/ldpc_h2064_516_rows.inc"
+};
+const uint8_t kScramble[125] = {
+#include "tables/scramble_v2_bits.inc"
+};
+
+inline int si16(float f) { return (int32_t)(f * (1 << 16)); }           // phi0.c:10
+float phi0_linear_int(int x) {                                          // phi0.c:13-218 on the fixed-point argument
+    if (x >= si16(10.0f)) return 0.0f;
+    if (x >= si16(5.0f)) return WR_PHI0_5_10[19 - (x >> 15)];
+    if (x >= si16(1.0f)) return WR_PHI0_1_5[79 - (x >> 12)];
+    for (int k = 0; k < 27; k++) if (x > si16(WR_PHI0_LT1_T[k])) return WR_PHI0_LT1_V[k];
+    return 10.0f;
+}
+inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+float phi0_lut_eval(const uint32_t *lut, float xf) {                    // host twin of phi0_dev
+    int32_t b; memcpy(&b, &xf, 4);
+    int key = (b >> 18) - WR_PHI0_KEY_BIAS;
+    key = key < 0 ? 0 : (key > WR_PHI0_LUT_ENTRIES - 1 ? WR_PHI0_LUT_ENTRIES - 1 : key);
+    const uint32_t *e = lut + key * 4;
+    const uint32_t u = (b >= (int32_t)e[0]) ? e[2] : e[1];
+    float f; memcpy(&f, &u, 4); return f;
+}
+float phi0_x86(float xf) {                                              // phi0.c:13-15 with cvttss2si semantics of the cast
+    const float y = xf * 65536.0f;
+    const int x = (y >= -2147483648.0f && y < 2147483648.0f) ? (int)y : INT32_MIN;
+    return phi0_linear_int(x);
+}
+
+// Which variable does thread tid handle as its t-th (position tid + 512 t)?  The variable pass reads and writes one message per lane and instruction
+// at an address given by the graph; with the variables in natural order the 64 addresses of a wavefront hit the 32 LDS banks unevenly (the fullest
+// bank serves ~5 of them where 2 would do).  The graph is static, so the data variables are dealt to the positions once such that every
+// (wavefront, t, socket) instruction loads each bank as evenly as a local search finds (deterministic: fixed seed).  Parity variables keep their
+// places: their edge addresses are consecutive already.  bank(v, k) = LDS bank of socket k of data variable v in the layout at hand.
+template <class BankFn>
+static void place_variables(std::vector<uint16_t> &vpos, BankFn bank, int *cost0, int *cost1) {
+    vpos.resize(WR_NCODE);
+    for (int v = 0; v < WR_NCODE; v++) vpos[v] = (uint16_t)v;
+    const int NG = (WR_NDATA + 63) / 64;                        // instruction groups of 64 positions (the last one has 16)
+    std::vector<int> cnt((size_t)NG * 3 * 32, 0);
+    auto over = [](int c) { return c > 2 ? (c - 2) * (c - 2) : 0; };
+    long cost = 0;
+    for (int p = 0; p < WR_NDATA; p++) for (int k = 0; k < 3; k++) cnt[((size_t)(p / 64) * 3 + k) * 32 + bank(vpos[p], k)]++;
+    for (size_t i = 0; i < cnt.size(); i++) cost += over(cnt[i]);
+    *cost0 = (int)cost;
+    uint64_t rng = 0x9E3779B97F4A7C15ull;
+    auto next = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return rng; };
+    for (long it = 0; it < 3000000 && cost > 0; it++) {
+        const int p = (int)(next() % WR_NDATA), q = (int)(next() % WR_NDATA);
+        const int gp = p / 64, gq = q / 64;
+        if (gp == gq) continue;
+        const int vp = vpos[p], vq = vpos[q];
+        long d = 0;
+        for (int k = 0; k < 3; k++) {
+            const int bp = bank(vp, k), bq = bank(vq, k);
+            if (bp == bq) continue;
+            int *cp = &cnt[((size_t)gp * 3 + k) * 32], *cq = &cnt[((size_t)gq * 3 + k) * 32];
+            d += over(cp[bp] - 1) - over(cp[bp]) + over(cp[bq] + 1) - over(cp[bq]);
+            d += over(cq[bq] - 1) - over(cq[bq]) + over(cq[bp] + 1) - over(cq[bp]);
+        }
+        if (d > 0) continue;
+        for (int k = 0; k < 3; k++) {
+            const int bp = bank(vp, k), bq = bank(vq, k);
+            cnt[((size_t)gp * 3 + k) * 32 + bp]--; cnt[((size_t)gp * 3 + k) * 32 + bq]++;
+            cnt[((size_t)gq * 3 + k) * 32 + bq]--; cnt[((size_t)gq * 3 + k) * 32 + bp]++;
+        }
+        vpos[p] = (uint16_t)vq; vpos[q] = (uint16_t)vp;
+        cost += d;
+    }
+    *cost1 = (int)cost;
+    if (getenv("WENET_RX_NO_PLACE")) for (int v = 0; v < WR_NCODE; v++) vpos[v] = (uint16_t)v;     // development: natural order
+}
+
+
+// variable side of the graph (mpdecode_core.c:286-360): data bit v takes part in the checks that list it, in ascending check order (= H_cols);
+// socket = its position in that check's row; edge address slot * 516 + check (the decoder's slot-major message array)
+inline bool ldpc_build_vedge(std::vector<uint16_t> &vedge) {
+    vedge.assign(WR_NDATA * 3, 0);
+    std::vector<int> deg(WR_NDATA, 0);
+    for (int c = 0; c < WR_NPAR; c++)
+        for (int j = 0; j < WR_ROWW; j++) {
+            const int v = kHRows[c * WR_ROWW + j];
+            if (v >= WR_NDATA || deg[v] >= 3) { fprintf(stderr, "libwenet_rx: bad code table\n"); return false; }
+            vedge[v * 3 + deg[v]++] = (uint16_t)(j * WR_NPAR + c);
+        }
+    for (int v = 0; v < WR_NDATA; v++) if (deg[v] != 3) { fprintf(stderr, "libwenet_rx: code table: column weight != 3\n"); return false; }
+    return true;
+}
+
+// phi0 as a table keyed by the float bits of the argument (wenet_internal.h): lut[4 k] = threshold bits, [4 k + 1] value below, [4 k + 2] value at / above.
+// exhaustive: check against the reference form on every integer and half-integer y up to 1.1e6 (2.2 M evaluations: tests/test_host_numerics.py);
+// the library checks every 61st at start-up, plus the cells' edges and the special values.
+inline bool phi0_build_lut(std::vector<uint32_t> &lut, bool exhaustive) {
+    lut.assign(WR_PHI0_LUT_ENTRIES * 4, 0);
+    {
+        uint32_t *e0 = &lut[0];
+        e0[0] = 0x7fffffffu; e0[1] = e0[2] = f2u(10.0f);
+        uint32_t *eN = &lut[(WR_PHI0_LUT_ENTRIES - 1) * 4];
+        eN[0] = 0x4f000000u; eN[1] = f2u(0.0f); eN[2] = f2u(10.0f);                 // 2^31
+        for (int k = 1; k <= WR_PHI0_BINADES * WR_PHI0_CELLS; k++) {
+            const int e = (k - 1) / WR_PHI0_CELLS, c = (k - 1) % WR_PHI0_CELLS;
+            const double lo = ldexp(1.0 + (double)c / WR_PHI0_CELLS, e), hi = ldexp(1.0 + (double)(c + 1) / WR_PHI0_CELLS, e);
+            const int x0 = (int)floor(lo), x1 = (int)ceil(hi) - 1;                  // integer parts met inside the cell
+            uint32_t *en = &lut[k * 4];
+            en[0] = 0x7fffffffu; en[1] = en[2] = f2u(phi0_linear_int(x0));
+            int steps = 0;
+            for (int x = x0 + 1; x <= x1; x++)
+                if (f2u(phi0_linear_int(x)) != f2u(phi0_linear_int(x - 1))) { steps++; en[0] = f2u((float)x); en[2] = f2u(phi0_linear_int(x)); }
+            if (steps > 1) { fprintf(stderr, "libwenet_rx: phi0 table: %d steps in cell %d\n", steps, k); return false; }
+        }
+    }
+    // the kernel keys on the bits of xf, not of y = xf * 2^16: move every real threshold by the exponent offset (the keys move through WR_PHI0_KEY_BIAS)
+    for (int k = 0; k < WR_PHI0_LUT_ENTRIES; k++) if (lut[k * 4] != 0x7fffffffu) lut[k * 4] -= 0x08000000u;
+    auto bad = [&](float xf) { return f2u(phi0_lut_eval(lut.data(), xf)) != f2u(phi0_x86(xf)); };
+    for (int x = 0; x <= 1100000; x += exhaustive ? 1 : 61)
+        for (float fr : {0.0f, 0.5f}) {
+            const float y = (float)x + fr;
+            if (bad(y / 65536.0f)) { fprintf(stderr, "libwenet_rx: phi0 table self-check failed at y=%g\n", (double)y); return false; }
+        }
+    for (int k = 0; k < WR_PHI0_LUT_ENTRIES; k++) {                                 // every real threshold: the float below it, itself, the float above it
+        if (lut[k * 4] == 0x7fffffffu) continue;
+        for (int d = -1; d <= 1; d++) {
+            const uint32_t u = lut[k * 4] + (uint32_t)d;
+            float xf; memcpy(&xf, &u, 4);
+            if (bad(xf)) { fprintf(stderr, "libwenet_rx: phi0 table self-check failed at threshold %d\n", k); return false; }
+        }
+    }
+    for (float xf : {-0.0f, -1.0f, -1e30f, 1e-30f, 1.5e-5f, 16.0f, 32767.0f, 32767.99f, 32768.0f, 1e9f, 3e38f, INFINITY, -INFINITY, NAN, -NAN})
+        if (bad(xf)) { fprintf(stderr, "libwenet_rx: phi0 table self-check failed at xf=%g\n", (double)xf); return false; }
+    return true;
+}
+
+// the placement the library ships (tools/gen_vpos.cpp wrote it with place_variables() above): valid = a permutation of the data variables over the data
+// positions, parity variables in their places
+#ifndef WR_GEN_VPOS
+const uint16_t kVposShipped[WR_NCODE] = {
+#include "tables/ldpc_vpos.inc"
+};
+#endif
+inline bool ldpc_vpos_valid(const uint16_t *vpos) {
+    std::vector<char> seen(WR_NCODE, 0);
+    for (int p = 0; p < WR_NCODE; p++) {
+        const int v = vpos[p];
+        if (v >= WR_NCODE || seen[v] || (p >= WR_NDATA) != (v >= WR_NDATA) || (p >= WR_NDATA && v != p)) return false;
+        seen[v] = 1;
+    }
+    return true;
+}
+
+}  // namespace
