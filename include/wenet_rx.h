@@ -174,7 +174,8 @@ int wenet_rx_collect(wenet_rx *rx);
  * soft-decision stream), wenet_rx_get_soft / wenet_rx_get_trace = the frames demodulated in it, wenet_rx_frames = frames since the channel opened.
  * The concatenation of all ticks' outputs equals one run of the reference pipe over the concatenated samples, bit for bit, however the
  * stream was cut.  wenet_rx_flush ends the streams (EOF of the pipes: a partial frame and a packet still in collection are dropped, as the
- * reference drops them) and leaves the handle idle; wenet_rx_process / wenet_rx_enqueue on a handle with open channels end them too. */
+ * reference drops them) and leaves the handle idle; wenet_rx_process / wenet_rx_enqueue on a handle with open channels end them too.  Arguments are
+ * checked before anything is touched (a refused call leaves the streams as they were); a device or allocation failure later in a tick ends the streams. */
 long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *chunk, const long long *nsamples, int fmt);
 int wenet_rx_flush(wenet_rx *rx);
 /* results of the last process/collect */

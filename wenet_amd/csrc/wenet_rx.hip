@@ -1473,10 +1473,14 @@ extern "C" int wenet_rx_flush(wenet_rx *rx) {
 
 extern "C" long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *chunk, const long long *nsamples, int fmt) {
     if (!rx || nchan <= 0 || fmt < 0 || fmt > 3 || !nsamples) return -1;
+    for (int i = 0; i < nchan; i++) if (nsamples[i] < 0 || (nsamples[i] > 0 && (!chunk || !chunk[i]))) return -1;      // (nothing has been touched yet)
     if (rx->pending && wenet_rx_collect(rx) < 0) return -1;
     DeviceGuard dg(rx->device);
     LdpcTables *t = ldpc_tables();
     if (!t) return -1;
+    // From here on a failure ENDS the live streams (the handle goes idle, as after wenet_rx_flush): what the tick has already moved on the device cannot be
+    // taken back, and a repeated tick on half-advanced state would not be the reference's stream any more.
+#define WR_LIVE_CHECK(expr, ret) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fprintf(stderr, "libwenet_rx: wenet_rx_push: %s failed: %s (line %d); the live streams are ended\n", #expr, hipGetErrorString(e_), __LINE__); live_close(rx); return ret; } } while (0)
     const WrDemodCfg &c = rx->tab.cfg;
     const size_t bps = (size_t)kBytesPerSample[fmt];
     const size_t stb = (size_t)c.st_floats * 4;
@@ -1492,10 +1496,10 @@ extern "C" long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *c
         for (int i = 0; i < nchan; i++) memcpy(&rx->h_states[(size_t)i * c.st_floats], st0.data(), stb);
         if (!rx->d_states.reserve(stb * nchan) || !rx->d_dstates.reserve(sizeof(WrDeframeState) * nchan) || !rx->d_live_meta.reserve((sizeof(WrLiveMeta) + 8) * nchan) ||
             !rx->d_chans.reserve(sizeof(WrChan) * nchan) || !rx->d_dchans.reserve(sizeof(WrDeframeChan) * nchan) || !rx->d_census.reserve((size_t)nchan * WR_CENSUS_CLASSES * 4))
-            return -2;
-        WR_CHECK(hipMemcpy(rx->d_states.p, rx->h_states.data(), stb * nchan, hipMemcpyHostToDevice), -3);
-        WR_CHECK(hipMemset(rx->d_dstates.p, 0, sizeof(WrDeframeState) * nchan), -3);
-        WR_CHECK(hipMemset(rx->d_live_meta.p, 0, (sizeof(WrLiveMeta) + 8) * nchan), -3);
+            { live_close(rx); return -2; }
+        WR_LIVE_CHECK(hipMemcpy(rx->d_states.p, rx->h_states.data(), stb * nchan, hipMemcpyHostToDevice), -3);
+        WR_LIVE_CHECK(hipMemset(rx->d_dstates.p, 0, sizeof(WrDeframeState) * nchan), -3);
+        WR_LIVE_CHECK(hipMemset(rx->d_live_meta.p, 0, (sizeof(WrLiveMeta) + 8) * nchan), -3);
     }
     if (nchan != rx->live_n || fmt != rx->live_fmt) {
         fprintf(stderr, "libwenet_rx: wenet_rx_push: %d channels of format %d were opened, the call has %d of format %d (wenet_rx_flush ends the streams)\n",
@@ -1509,14 +1513,13 @@ extern "C" long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *c
     if (rx->live_ticks > 0) {
         hipLaunchKernelGGL(wenet_live_compact_kernel, dim3(nchan), dim3(256), 0, stream, rx->d_live_in.as<char>(), rx->live_in_stride, rx->d_sd.as<float>(),
                            rx->live_sd_stride, rx->d_states.as<float>(), c.st_floats, rx->d_dstates.as<WrDeframeState>(), d_meta, d_newsmp, (int)bps, c.Nbits);
-        WR_CHECK(hipGetLastError(), -4);
+        WR_LIVE_CHECK(hipGetLastError(), -4);
     }
     // (2) room for this tick: carried + new samples per channel, carried + new symbols; growing keeps what is carried
     const long long min_nin = c.N - c.Ts / 2;
     long long need_smp = 0, need_sym = 0, max_pk = 1;
     std::vector<long long> capf(nchan);
     for (int i = 0; i < nchan; i++) {
-        if (nsamples[i] < 0) return -1;
         const long long have = rx->live_carry_smp[i] + nsamples[i];
         capf[i] = have / min_nin + 1;
         const long long sym = rx->live_carry_sym[i] + capf[i] * c.Nbits;
@@ -1525,17 +1528,17 @@ extern "C" long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *c
     }
     const long long in_stride = (((need_smp + need_smp / 4) * (long long)bps + 255) & ~255LL) + 256, sd_stride = ((need_sym + need_sym / 4 + 63) & ~63LL) + 64;
     if (in_stride > rx->live_in_stride || sd_stride > rx->live_sd_stride) {
-        WR_CHECK(hipStreamSynchronize(stream), -4);
+        WR_LIVE_CHECK(hipStreamSynchronize(stream), -4);
         const long long nis = std::max(in_stride, rx->live_in_stride), nss = std::max(sd_stride, rx->live_sd_stride);
         void *n_in = nullptr, *n_sd = nullptr;
         if (hipMalloc(&n_in, (size_t)nis * nchan + 256) != hipSuccess || hipMalloc(&n_sd, (size_t)nss * nchan * 4 + 256) != hipSuccess) {
             if (n_in) (void)hipFree(n_in);
             fprintf(stderr, "libwenet_rx: wenet_rx_push: hipMalloc failed\n");
-            return -2;
+            { live_close(rx); return -2; }
         }
         for (int i = 0; i < nchan && rx->live_ticks > 0; i++) {
-            if (rx->live_carry_smp[i] > 0) WR_CHECK(hipMemcpy((char *)n_in + (size_t)i * nis, rx->d_live_in.as<char>() + (size_t)i * rx->live_in_stride, (size_t)rx->live_carry_smp[i] * bps, hipMemcpyDeviceToDevice), -3);
-            if (rx->live_carry_sym[i] > 0) WR_CHECK(hipMemcpy((float *)n_sd + (size_t)i * nss, rx->d_sd.as<float>() + (size_t)i * rx->live_sd_stride, (size_t)rx->live_carry_sym[i] * 4, hipMemcpyDeviceToDevice), -3);
+            if (rx->live_carry_smp[i] > 0) WR_LIVE_CHECK(hipMemcpy((char *)n_in + (size_t)i * nis, rx->d_live_in.as<char>() + (size_t)i * rx->live_in_stride, (size_t)rx->live_carry_smp[i] * bps, hipMemcpyDeviceToDevice), -3);
+            if (rx->live_carry_sym[i] > 0) WR_LIVE_CHECK(hipMemcpy((float *)n_sd + (size_t)i * nss, rx->d_sd.as<float>() + (size_t)i * rx->live_sd_stride, (size_t)rx->live_carry_sym[i] * 4, hipMemcpyDeviceToDevice), -3);
         }
         if (rx->d_live_in.p) (void)hipFree(rx->d_live_in.p);
         if (rx->d_sd.p) (void)hipFree(rx->d_sd.p);
@@ -1546,11 +1549,11 @@ extern "C" long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *c
     rx->max_pk = (int)max_pk;
     if (!rx->d_starts.reserve((size_t)nchan * max_pk * 8) || !rx->d_out.reserve((size_t)nchan * max_pk * sizeof(WrPacketOut)) ||
         !rx->d_esn0.reserve(wr_dec_scratch_bytes((size_t)nchan * max_pk)))
-        return -2;
-    if (rx->want_trace && !rx->d_trace.reserve((size_t)nchan * (size_t)(rx->live_sd_stride / c.Nbits + 1) * WR_TRACE_FLOATS * 4)) return -2;
-    if (rx->want_llr && !rx->d_llr.reserve((size_t)nchan * max_pk * WR_NCODE * 4)) return -2;
+        { live_close(rx); return -2; }
+    if (rx->want_trace && !rx->d_trace.reserve((size_t)nchan * (size_t)(rx->live_sd_stride / c.Nbits + 1) * WR_TRACE_FLOATS * 4)) { live_close(rx); return -2; }
+    if (rx->want_llr && !rx->d_llr.reserve((size_t)nchan * max_pk * WR_NCODE * 4)) { live_close(rx); return -2; }
     const size_t oct_scr = (size_t)c.M * c.Ts * 64 * 8 + 64;
-    if (!rx->d_big.reserve((size_t)nchan * (c.big ? (size_t)c.big_bytes : oct_scr))) return -2;
+    if (!rx->d_big.reserve((size_t)nchan * (c.big ? (size_t)c.big_bytes : oct_scr))) { live_close(rx); return -2; }
     rx->profile = false;
     // (3) this tick's samples behind the carried ones; tables
     std::vector<WrChan> chans(nchan);
@@ -1560,8 +1563,7 @@ extern "C" long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *c
     for (int i = 0; i < nchan; i++) {
         char *blk = rx->d_live_in.as<char>() + (size_t)i * rx->live_in_stride;
         if (nsamples[i] > 0) {
-            if (!chunk || !chunk[i]) return -1;
-            WR_CHECK(hipMemcpyAsync(blk + (size_t)rx->live_carry_smp[i] * bps, chunk[i], (size_t)nsamples[i] * bps, hipMemcpyHostToDevice, stream), -3);
+            WR_LIVE_CHECK(hipMemcpyAsync(blk + (size_t)rx->live_carry_smp[i] * bps, chunk[i], (size_t)nsamples[i] * bps, hipMemcpyHostToDevice, stream), -3);
         }
         float *sdb = rx->d_sd.as<float>() + (size_t)i * rx->live_sd_stride;
         WrChan &ch = chans[i];
@@ -1583,22 +1585,22 @@ extern "C" long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *c
         d.starts = rx->d_starts.as<long long>() + (size_t)i * max_pk;
         d.cap_packets = max_pk;
     }
-    WR_CHECK(hipMemcpyAsync(rx->d_chans.p, chans.data(), sizeof(WrChan) * nchan, hipMemcpyHostToDevice, stream), -3);
-    WR_CHECK(hipMemcpyAsync(rx->d_dchans.p, dch.data(), sizeof(WrDeframeChan) * nchan, hipMemcpyHostToDevice, stream), -3);
-    WR_CHECK(hipMemcpyAsync(d_newsmp, nsamples, sizeof(long long) * nchan, hipMemcpyHostToDevice, stream), -3);
-    WR_CHECK(hipMemsetAsync(rx->d_census.p, 0, (size_t)nchan * WR_CENSUS_CLASSES * 4, stream), -3);
+    WR_LIVE_CHECK(hipMemcpyAsync(rx->d_chans.p, chans.data(), sizeof(WrChan) * nchan, hipMemcpyHostToDevice, stream), -3);
+    WR_LIVE_CHECK(hipMemcpyAsync(rx->d_dchans.p, dch.data(), sizeof(WrDeframeChan) * nchan, hipMemcpyHostToDevice, stream), -3);
+    WR_LIVE_CHECK(hipMemcpyAsync(d_newsmp, nsamples, sizeof(long long) * nchan, hipMemcpyHostToDevice, stream), -3);
+    WR_LIVE_CHECK(hipMemsetAsync(rx->d_census.p, 0, (size_t)nchan * WR_CENSUS_CLASSES * 4, stream), -3);
     // (4) demodulate every whole frame, look for unique words in carried + new symbols, decode every packet completed
     rx->nchunks = 1;
-    if (!rx->chunk_events(1)) return -4;
+    if (!rx->chunk_events(1)) { live_close(rx); return -4; }
     wenet_rx::ChunkEv &e = rx->cev[0];
     const DemodChoice dcs = choose_demod(rx, nchan, fmt);
     rx->last_kernel = dcs.use_oct ? "wenet_demod_oct_kernel" : (dcs.launch_cfg.p_tri ? "wenet_demod_tri_kernel" : (dcs.launch_cfg.pipe_ok && !dcs.launch_cfg.big ? "wenet_demod_pipe_kernel" : "wenet_demod_kernel"));
-    WR_CHECK(hipEventRecord(e.ev[0], stream), -4);
-    if (dcs.use_oct) WR_CHECK(wr_launch_demod_oct(&dcs.oct_cfg, rx->d_chans.as<WrChan>(), nchan, stream), -4);
-    else WR_CHECK(wr_launch_demod_ex(&dcs.launch_cfg, rx->d_chans.as<WrChan>(), nchan, stream, 0), -4);
-    WR_CHECK(hipEventRecord(e.ev[1], stream), -4);
-    WR_CHECK(wr_launch_deframe(rx->d_dchans.as<WrDeframeChan>(), nchan, rx->mode, stream), -4);
-    WR_CHECK(hipEventRecord(e.ev[2], stream), -4);
+    WR_LIVE_CHECK(hipEventRecord(e.ev[0], stream), -4);
+    if (dcs.use_oct) WR_LIVE_CHECK(wr_launch_demod_oct(&dcs.oct_cfg, rx->d_chans.as<WrChan>(), nchan, stream), -4);
+    else WR_LIVE_CHECK(wr_launch_demod_ex(&dcs.launch_cfg, rx->d_chans.as<WrChan>(), nchan, stream, 0), -4);
+    WR_LIVE_CHECK(hipEventRecord(e.ev[1], stream), -4);
+    WR_LIVE_CHECK(wr_launch_deframe(rx->d_dchans.as<WrDeframeChan>(), nchan, rx->mode, stream), -4);
+    WR_LIVE_CHECK(hipEventRecord(e.ev[2], stream), -4);
     WrDecodeArgs a;
     memset(&a, 0, sizeof(a));
     a.input_kind = WR_DEC_IN_STREAM; a.mode = rx->mode; a.max_iter = rx->max_iter; a.nchan = nchan; a.max_pk = (int)max_pk;
@@ -1610,27 +1612,27 @@ extern "C" long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *c
     a.census = rx->d_census.as<unsigned>();
     a.llr_out = rx->want_llr ? rx->d_llr.as<float>() : nullptr;
     fill_decode_tables(a, t);
-    WR_CHECK(wr_launch_decode(&a, stream), -4);
-    WR_CHECK(hipEventRecord(e.ev[3], stream), -4);
+    WR_LIVE_CHECK(wr_launch_decode(&a, stream), -4);
+    WR_LIVE_CHECK(hipEventRecord(e.ev[3], stream), -4);
     // (5) results: state headers, deframer states, packet slots
     {
         const size_t n_slots = (size_t)nchan * max_pk, out_bytes = n_slots * sizeof(WrPacketOut), st_bytes = n_slots * 8;
-        if (!rx->pin_reserve(out_bytes + st_bytes + 64)) return -2;
+        if (!rx->pin_reserve(out_bytes + st_bytes + 64)) { live_close(rx); return -2; }
         rx->h_out = (WrPacketOut *)rx->h_pin;
         rx->h_starts = (long long *)((char *)rx->h_pin + ((out_bytes + 63) & ~(size_t)63));
         rx->h_dstates.resize(nchan);
         rx->h_census.resize((size_t)nchan * WR_CENSUS_CLASSES);
-        WR_CHECK(hipMemcpyAsync(rx->h_states.data(), rx->d_states.p, stb * nchan, hipMemcpyDeviceToHost, stream), -3);
-        WR_CHECK(hipMemcpyAsync(rx->h_dstates.data(), rx->d_dstates.p, sizeof(WrDeframeState) * nchan, hipMemcpyDeviceToHost, stream), -3);
-        WR_CHECK(hipMemcpyAsync(rx->h_census.data(), rx->d_census.p, rx->h_census.size() * 4, hipMemcpyDeviceToHost, stream), -3);
-        WR_CHECK(hipStreamSynchronize(stream), -4);
+        WR_LIVE_CHECK(hipMemcpyAsync(rx->h_states.data(), rx->d_states.p, stb * nchan, hipMemcpyDeviceToHost, stream), -3);
+        WR_LIVE_CHECK(hipMemcpyAsync(rx->h_dstates.data(), rx->d_dstates.p, sizeof(WrDeframeState) * nchan, hipMemcpyDeviceToHost, stream), -3);
+        WR_LIVE_CHECK(hipMemcpyAsync(rx->h_census.data(), rx->d_census.p, rx->h_census.size() * 4, hipMemcpyDeviceToHost, stream), -3);
+        WR_LIVE_CHECK(hipStreamSynchronize(stream), -4);
         long long total = 0;
         size_t used_slots = 0;
         for (int i = 0; i < nchan; i++) if (rx->h_dstates[i].npackets > 0) used_slots = (size_t)(i + 1) * max_pk;
         if (used_slots > 0) {
-            WR_CHECK(hipMemcpyAsync(rx->h_out, rx->d_out.p, used_slots * sizeof(WrPacketOut), hipMemcpyDeviceToHost, stream), -3);
-            WR_CHECK(hipMemcpyAsync(rx->h_starts, rx->d_starts.p, used_slots * 8, hipMemcpyDeviceToHost, stream), -3);
-            WR_CHECK(hipStreamSynchronize(stream), -4);
+            WR_LIVE_CHECK(hipMemcpyAsync(rx->h_out, rx->d_out.p, used_slots * sizeof(WrPacketOut), hipMemcpyDeviceToHost, stream), -3);
+            WR_LIVE_CHECK(hipMemcpyAsync(rx->h_starts, rx->d_starts.p, used_slots * 8, hipMemcpyDeviceToHost, stream), -3);
+            WR_LIVE_CHECK(hipStreamSynchronize(stream), -4);
         }
         // (6) the host's mirror of what stays on the device for the next tick (wenet_live_compact_kernel computes the same from the same words)
         long long fr = 0, sl = 0;
@@ -1651,6 +1653,7 @@ extern "C" long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *c
         return total;
     }
 }
+#undef WR_LIVE_CHECK
 
 extern "C" int wenet_rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw, const long long *nsamples, int fmt, void *stream_v) {
     return rx_enqueue(rx, nchan, raw, nsamples, fmt, stream_v, nullptr);
