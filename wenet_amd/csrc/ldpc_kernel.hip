@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256) void wenet_crc_kernel(WrDecodeArgs A) {
 // threads' variable placement once and then takes packet slots from a shared counter until none is left -- the per-packet set-up
 // (10 KB of table through L2, 18 edge addresses per thread) was a third of a packet's time at ~6 iterations.  (Round 1 tried a FIXED
 // four packets per workgroup: slower, because iteration counts differ; the counter has no such imbalance.)
-__global__ __launch_bounds__(WR_DEC_THREADS, 8) void wenet_decode_kernel(WrDecodeArgs A) {      // (8 waves per SIMD = four workgroups per CU: 64 VGPRs)
+__global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_decode_kernel(WrDecodeArgs A) {      // (8 waves per SIMD = four workgroups per CU: 64 VGPRs)
     const int tid = threadIdx.x;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // float msg[14*516] | uint4 lut[642] | bit/byte staging
@@ -337,11 +337,12 @@ __global__ __launch_bounds__(WR_DEC_THREADS, 8) void wenet_decode_kernel(WrDecod
 #pragma unroll
         for (int k = 0; k < 3; k++) ea[t][k] = (k < deg[t]) ? var_edge(v, k, A.vedge) : 0;
     }
-    const bool data4 = var_at(4) < WR_NDATA;                                      // position t = 4 holds a data bit (positions t < 4 always do, t = 5 never)
+    const bool data4 = var_at(WR_VARS_ALLDATA) < WR_NDATA;                                      // position t = 4 holds a data bit (positions t < 4 always do, t = 5 never)
     // Where this thread's six soft symbols sit in a stored packet, and which of them the v2 scrambler negates: functions of the thread's variables alone,
     // so they are formed once here -- the per-packet prologue is then six loads issued together and six products (round 3 walked, per packet and variable,
     // the chain placement table -> symbol -> scramble byte: a dozen dependent global loads, ~10 us per packet = two iterations' worth).
-    unsigned soff[3] = {0u, 0u, 0u}, sneg = 0u, svalid = 0u;              // 16-bit offsets packed in pairs; bit t: negate / position holds a variable
+    unsigned soff[(WR_VARS_PER_THREAD + 1) / 2], sneg = 0u, svalid = 0u;
+    for (int i = 0; i < (WR_VARS_PER_THREAD + 1) / 2; i++) soff[i] = 0u;              // 16-bit offsets packed in pairs; bit t: negate / position holds a variable
     {
         const bool stream = A.input_kind == WR_DEC_IN_STREAM;
 #pragma unroll
@@ -476,8 +477,9 @@ __global__ __launch_bounds__(WR_DEC_THREADS, 8) void wenet_decode_kernel(WrDecod
         // ---- update r: thread = check (mpdecode_core.c:414-436).  All 14 slots are processed for every check:
         //      the phantom 14th edge of check 0 adds +0.0 LAST to phi_sum (no change) and contributes no sign.
         int ok = 0;
-        {
-            const int chk = tid;                                // checks 0..511: one per thread
+#pragma unroll
+        for (int cj = 0; cj < WR_DEC_CHECKS_PER_THREAD; cj++) {
+            const int chk = tid + cj * WR_DEC_THREADS;          // the whole checks: one per thread (512 threads; two with -DWR_DEC_THREADS=256)
             // messages stay signed in their registers: |m| is a free source modifier of the adds, the parity of the signs is the
             // top bit of the XOR of the raw words, and an edge's new sign is its own sign XOR that parity
             float mr[14];
@@ -502,8 +504,8 @@ __global__ __launch_bounds__(WR_DEC_THREADS, 8) void wenet_decode_kernel(WrDecod
         // checks 512..515: not a second trip of four lanes through the whole pass (it would make one wavefront the straggler of every
         // iteration) but edge-parallel on 56 lanes of the last wavefront: every lane of a check's group adds the 14 magnitudes
         // itself, in order, and then updates only its own edge -- a quarter of the instructions, the same values.
-        if (tid >= WR_DEC_THREADS - 64 && tid < WR_DEC_THREADS - 64 + (WR_NPAR - WR_DEC_THREADS) * 14) {
-            const int l = tid - (WR_DEC_THREADS - 64), g = l / 14, k = l - g * 14, chk = WR_DEC_THREADS + g;
+        if (tid >= WR_DEC_THREADS - 64 && tid < WR_DEC_THREADS - 64 + (WR_NPAR - WR_DEC_CHECKS_PER_THREAD * WR_DEC_THREADS) * 14) {
+            const int l = tid - (WR_DEC_THREADS - 64), g = l / 14, k = l - g * 14, chk = WR_DEC_CHECKS_PER_THREAD * WR_DEC_THREADS + g;
             unsigned px = 0;
             float phi_sum = 0.f;
 #pragma unroll
@@ -523,7 +525,7 @@ __global__ __launch_bounds__(WR_DEC_THREADS, 8) void wenet_decode_kernel(WrDecod
         // cleared for the next iteration.  (__syncthreads_count / __syncthreads_or cost three barriers each.)
         const int par = iter & 1;
         {
-            const unsigned long long bal = __ballot(ok & 1), bal2 = __ballot(ok & 2);     // ok = number of satisfied checks of this thread (0..2)
+            const unsigned long long bal = __ballot(ok & 1), bal2 = __ballot(ok & 2);     // ok = number of satisfied checks of this thread (0..3)
             if ((tid & 63) == 0 && (bal | bal2)) atomicAdd(&red[par * 2 + 0], __popcll(bal) + 2 * __popcll(bal2));
         }
         __syncthreads();
@@ -546,7 +548,7 @@ __global__ __launch_bounds__(WR_DEC_THREADS, 8) void wenet_decode_kernel(WrDecod
                 }
                 const int b = Qi < 0.f;
                 bits |= (unsigned)b << t;
-                if (b && (t < WR_VARS_ALLDATA || (t == 4 && data4))) any_data = 1;
+                if (b && (t < WR_VARS_ALLDATA || (t == WR_VARS_ALLDATA && data4))) any_data = 1;
 #pragma unroll
                 for (int k = 0; k < 3; k++) {
                     if (t < WR_VARS_ALLDATA || k < deg[t]) {
@@ -587,12 +589,12 @@ __global__ __launch_bounds__(WR_DEC_THREADS, 8) void wenet_decode_kernel(WrDecod
     }
     __syncthreads();
     uint8_t *bytes = bitbuf + 2592;
-    if (tid < 258) {
+    for (int bi = tid; bi < 258; bi += WR_DEC_THREADS) {
         unsigned a = 0;
 #pragma unroll
-        for (int j = 0; j < 8; j++) a |= (unsigned)bitbuf[8 * tid + j] << (7 - j);
-        bytes[tid] = (uint8_t)a;
-        if (out) out->bytes[tid] = (uint8_t)a;
+        for (int j = 0; j < 8; j++) a |= (unsigned)bitbuf[8 * bi + j] << (7 - j);
+        bytes[bi] = (uint8_t)a;
+        if (out) out->bytes[bi] = (uint8_t)a;
     }
     if (tid == 0 && out) {                                  // crc_ok/done are set by wenet_crc_kernel
         out->iter = result;

@@ -208,9 +208,13 @@ struct WrDeframeChan {
 #define WR_NDATA  2064
 #define WR_NCODE  2580
 #define WR_ROWW   12
-#define WR_DEC_THREADS 512          // eight wavefronts: four workgroups per CU = all 32 wave slots (576 threads: three workgroups, 27)
-#define WR_VARS_PER_THREAD 6   // ceil(2580/512)
-#define WR_VARS_ALLDATA 4      // variables tid + 512 t, t < 4, are data bits (degree 3) for every thread: 4 * 512 <= 2064
+#ifndef WR_DEC_THREADS
+#define WR_DEC_THREADS 512          // eight wavefronts: four workgroups per CU = all 32 wave slots at 64 VGPRs (576 threads: three workgroups, 27; 256 threads at
+#endif                              // 128 VGPRs, two checks per thread: measured in round 4, tools/experiments/README.md)
+#define WR_DEC_CHECKS_PER_THREAD (WR_NPAR / WR_DEC_THREADS)                          // whole checks per thread (the 516 - that many * threads left over: edge-parallel on the last wave)
+#define WR_VARS_PER_THREAD ((WR_NCODE + WR_DEC_THREADS - 1) / WR_DEC_THREADS)          // 6 at 512 threads
+#define WR_VARS_ALLDATA (WR_NDATA / WR_DEC_THREADS)                                  // positions t < this hold data bits (degree 3) for every thread: 4 at 512 threads
+#define WR_DEC_WAVES_PER_EU (WR_DEC_THREADS == 512 ? 8 : 4)
 
 struct WrPacketOut {            // one per packet slot
     uint8_t bytes[258];         // 256 payload + 2 CRC bytes as decoded (drs232_ldpc.c:234-239)

@@ -788,7 +788,7 @@ extern "C" int wenet_run_ldpc_decoder(struct wenet_ldpc *ldpc, uint8_t out_char[
 }
 
 extern "C" void wenet_sd_to_llr(float llr[], double sd[], int n) {
-    if (n <= 0 || n > WR_DEC_THREADS * WR_VARS_PER_THREAD) { fprintf(stderr, "libwenet_rx: wenet_sd_to_llr: n=%d unsupported\n", n); return; }
+    if (n <= 0 || n > 2880) { fprintf(stderr, "libwenet_rx: wenet_sd_to_llr: n=%d unsupported\n", n); return; }
     (void)run_dense(WR_DEC_IN_SD64, sd, 1, n, 0, 0, 1, nullptr, llr);
 }
 
