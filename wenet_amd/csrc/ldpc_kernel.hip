@@ -471,6 +471,7 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
     __syncthreads();
 
     DSTAMP(1);                                                                     // [1] initial messages + two barriers
+    const int wave_base4 = __builtin_amdgcn_readfirstlane((tid & ~63) * 4);     // byte offset of this wavefront's lane 0 in a row of the message array
     int result = A.max_iter, pcc = 0, pcc_written = 0;
     unsigned bits = 0;                                          // bit t = hard decision of variable tid+t*512
     for (int iter = 0; iter < A.max_iter; iter++) {
@@ -497,9 +498,17 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
 #pragma unroll
             for (int k = 0; k < 14; k++) {
                 const float r = phi0_dev(phi_sum - fabsf(mr[k]), lut);
-                msg[k * WR_NPAR + chk] = __uint_as_float(__float_as_uint(r) | ((__float_as_uint(mr[k]) ^ par_bit) & 0x80000000u));
+                const float rs = __uint_as_float(__float_as_uint(r) | ((__float_as_uint(mr[k]) ^ par_bit) & 0x80000000u));
+#ifndef WR_DEC_NO_ADDTID
+                // the check pass stores lane-linearly (check = thread): ds_write_addtid_b32 -- address = M0 + offset + 4 lane, no address register -- costs the LDS
+                // two cycles where ds_write_b32 costs four (the address VGPR's transfer).  (s_nop: a write of M0 needs a wait state before an add-TID LDS instruction, and
+                // the compiler's hazard recogniser does not look into an asm block)
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:%2" : : "v"(rs), "s"(wave_base4 + cj * WR_DEC_THREADS * 4), "n"(k * WR_NPAR * 4) : "memory", "m0");
+#else
+                msg[k * WR_NPAR + chk] = rs;
+#endif
             }
-            if (chk == 0) msg[13 * WR_NPAR] = 0.f;
+            if (chk == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); msg[13 * WR_NPAR] = 0.f; }
         }
         // checks 512..515: not a second trip of four lanes through the whole pass (it would make one wavefront the straggler of every
         // iteration) but edge-parallel on 56 lanes of the last wavefront: every lane of a check's group adds the 14 magnitudes
