@@ -178,6 +178,9 @@ int wenet_rx_collect(wenet_rx *rx);
  * checked before anything is touched (a refused call leaves the streams as they were); a device or allocation failure later in a tick ends the streams. */
 long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *chunk, const long long *nsamples, int fmt);
 int wenet_rx_flush(wenet_rx *rx);
+/* How many of the last tick's chunks the GPU read from the caller's buffers itself (one gather kernel over PCIe instead of one copy per channel):
+ * every chunk in PINNED host memory (hipHostMalloc / hipHostRegister; torch pin_memory) goes that way, pageable ones are copied as before. */
+int wenet_rx_live_gathered(wenet_rx *rx);
 /* results of the last process/collect */
 long long wenet_rx_frames(wenet_rx *rx, int ch);            /* modem frames demodulated */
 long long wenet_rx_packets(wenet_rx *rx, int ch);           /* packets completed (valid or not) */

@@ -14,7 +14,16 @@ from wenet_amd.rx import RxBatch
 pytestmark = pytest.mark.gpu
 
 
-def _run_live(cfg, caps, fmt, cuts, want_llr=False, max_iter=10):
+def _pinned_copy(b, shift):
+    """the bytes of b in PINNED host memory, `shift` bytes behind the start of the allocation (any alignment of the chunks)"""
+    import torch
+    t = torch.empty(b.size + shift + 16, dtype=torch.uint8).pin_memory()
+    a = t.numpy()[shift:shift + b.size]
+    a[:] = b
+    return a, t
+
+
+def _run_live(cfg, caps, fmt, cuts, want_llr=False, max_iter=10, pinned=False):
     """push every channel's capture in the ticks `cuts[ch]` gives (sample counts per tick, 0 allowed); returns per channel the concatenated results"""
     n = len(caps)
     bps = BYTES_PER_SAMPLE[fmt]
@@ -22,6 +31,11 @@ def _run_live(cfg, caps, fmt, cuts, want_llr=False, max_iter=10):
     if want_llr:
         rx.enable_llr_dump()
     raw = [ol.raw_bytes(c) for c in caps]
+    keep = []
+    if pinned:                                                            # channel ch's buffer starts ch bytes into its allocation: every source alignment
+        for ch in range(n):
+            raw[ch], t = _pinned_copy(raw[ch], ch % 16)
+            keep.append(t)
     pos = [0] * n
     out = [dict(sd=[], bytes=[], iter=[], ok=[], start=[], llr=[]) for _ in range(n)]
     nt = max(len(c) for c in cuts)
@@ -33,6 +47,7 @@ def _run_live(cfg, caps, fmt, cuts, want_llr=False, max_iter=10):
             chunks.append(raw[ch][pos[ch] * bps:(pos[ch] + k) * bps])
             pos[ch] += k
         got = rx.push(chunks, fmt)
+        assert rx.live_gathered() == (sum(1 for c in chunks if c.size) if pinned else 0)
         tick_pk = 0
         for ch in range(n):
             out[ch]["sd"].append(rx.soft(ch).copy())
@@ -106,6 +121,20 @@ def test_live_formats_framings_and_tiny_ticks(name, fmt, mean):
     bps = BYTES_PER_SAMPLE[fmt]
     cuts = [_ragged_cuts(rng, ol.raw_bytes(c).size // bps, mean) for c in caps]
     out, frames, _ = _run_live(cfg, caps, fmt, cuts)
+    assert _check(cfg, caps, fmt, out, frames) > 0
+
+
+@pytest.mark.parametrize("name,fmt,mean", [("v2", "cu8", 20000), ("v1", "cs16", 700), ("v2", "cf32", 30001)])
+def test_live_pinned_buffers_are_read_by_the_gpu_itself(name, fmt, mean):
+    """chunks in pinned host memory are gathered by ONE kernel over PCIe (no copy per channel): every alignment of source (the buffers start 0..15 bytes
+    into their allocations, the ticks cut them anywhere) and destination (behind whatever the last tick left), tiny and empty chunks; same results"""
+    cfg = siggen.CONFIGS[name]()
+    rng = np.random.default_rng(abs(hash((name, fmt, "pin"))) % 1000)
+    nch = 19
+    caps = [siggen.make_capture(cfg, 3, 9.0, seed=1900 + ch, fmt=fmt, ppm=(120.0 if ch == 2 else 0.0))[0] for ch in range(nch)]
+    bps = BYTES_PER_SAMPLE[fmt]
+    cuts = [_ragged_cuts(rng, ol.raw_bytes(c).size // bps, mean) for c in caps]
+    out, frames, _ = _run_live(cfg, caps, fmt, cuts, pinned=True)
     assert _check(cfg, caps, fmt, out, frames) > 0
 
 

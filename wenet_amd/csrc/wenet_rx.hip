@@ -946,6 +946,8 @@ struct wenet_rx {
     std::vector<WrDeframeState> h_dstates;
     // results land in ONE pinned host block with two async copies (states | deframer states, then packet slots | starts)
     void *h_pin = nullptr; size_t h_pin_cap = 0;
+    DevBuf d_live_gather;                   // live ticks: the gather list (chunks in pinned host memory)
+    int live_gathered = 0;                  // chunks of the last tick the device read itself
     WrPacketOut *h_out = nullptr;
     long long *h_starts = nullptr;
     bool pin_reserve(size_t bytes) {
@@ -1461,6 +1463,44 @@ __global__ __launch_bounds__(256) void wenet_live_compact_kernel(char *in_base, 
     }
     if (tid == 0) { meta[ch].carry_smp = have - used; meta[ch].carry_sym = nsym - res; }
 }
+// A tick's uploads when the caller's buffers are PINNED host memory (hipHostMalloc / hipHostRegister: the device can read them): one kernel copies every
+// channel's chunk over PCIe into its input block -- N hipMemcpyAsync calls cost the host ~10 us each, 1.3 ms of a 3.8 ms tick at 128 channels.  Any alignment
+// of source and destination: whole 16-byte units of the DESTINATION, the source read in aligned dwords and shifted into place; heads and tails bytewise.
+// (A 4-aligned dword that holds at least one byte of the chunk lies in a page of the chunk: the reads around the ends touch nothing else.)
+struct WrGather { const char *src; char *dst; long long bytes; };
+__global__ __launch_bounds__(256) void wenet_live_gather_kernel(const WrGather *list) {
+    const WrGather g = list[blockIdx.y];
+    const long long n = g.bytes;
+    if (n <= 0) return;
+    const long long head = min(n, (long long)((16u - (unsigned)((uintptr_t)g.dst & 15u)) & 15u));
+    if (blockIdx.x == 0 && (long long)threadIdx.x < head) g.dst[threadIdx.x] = g.src[threadIdx.x];
+    const long long body = (n - head) >> 4;
+    const char *s0 = g.src + head;
+    uint4 *d0 = (uint4 *)(g.dst + head);
+    const unsigned a = (unsigned)((uintptr_t)s0 & 3u);
+    const unsigned *sw = (const unsigned *)(s0 - a);
+    for (long long u = (long long)blockIdx.x * 256 + threadIdx.x; u < body; u += (long long)gridDim.x * 256) {
+        const unsigned *q = sw + 4 * u;
+        uint4 o;
+        if (a == 0) {
+            o = (((uintptr_t)q & 15u) == 0) ? *(const uint4 *)q : make_uint4(q[0], q[1], q[2], q[3]);
+        } else {
+            const unsigned w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3], w4 = q[4];
+            o = make_uint4(__builtin_amdgcn_alignbyte(w1, w0, a), __builtin_amdgcn_alignbyte(w2, w1, a), __builtin_amdgcn_alignbyte(w3, w2, a), __builtin_amdgcn_alignbyte(w4, w3, a));
+        }
+        d0[u] = o;
+    }
+    const long long done = head + (body << 4);
+    if (blockIdx.x == 0 && (long long)threadIdx.x < n - done) g.dst[done + threadIdx.x] = g.src[done + threadIdx.x];
+}
+// the address the DEVICE reads a host buffer at, or nullptr if it cannot (pageable memory)
+const char *device_view_of_host(const void *p) {
+    hipPointerAttribute_t at;
+    memset(&at, 0, sizeof(at));
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (at.type != hipMemoryTypeHost || at.devicePointer == nullptr) return nullptr;
+    return (const char *)at.devicePointer;
+}
 }  // namespace
 
 static void live_close(wenet_rx *rx) { rx->live_n = 0; rx->live_fmt = -1; rx->live_ticks = 0; }
@@ -1470,6 +1510,8 @@ extern "C" int wenet_rx_flush(wenet_rx *rx) {
     live_close(rx);                                                     // (EOF of the reference pipes: a partial frame and a packet in collection are dropped)
     return 0;
 }
+
+extern "C" int wenet_rx_live_gathered(wenet_rx *rx) { return rx ? rx->live_gathered : -1; }
 
 extern "C" long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *chunk, const long long *nsamples, int fmt) {
     if (!rx || nchan <= 0 || fmt < 0 || fmt > 3 || !nsamples) return -1;
@@ -1555,15 +1597,28 @@ extern "C" long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *c
     const size_t oct_scr = (size_t)c.M * c.Ts * 64 * 8 + 64;
     if (!rx->d_big.reserve((size_t)nchan * (c.big ? (size_t)c.big_bytes : oct_scr))) { live_close(rx); return -2; }
     rx->profile = false;
-    // (3) this tick's samples behind the carried ones; tables
-    std::vector<WrChan> chans(nchan);
-    std::vector<WrDeframeChan> dch(nchan);
+    // (3) this tick's samples behind the carried ones; tables.  Everything the host hands over or takes back in a tick except the samples themselves lives in ONE pinned
+    //     block (the copies are real DMA, none is staged by the runtime): packet slots | start offsets | state headers | deframer states | census || tables in
+    const size_t n_slots = (size_t)nchan * max_pk, out_bytes = n_slots * sizeof(WrPacketOut), st_bytes = n_slots * 8;
+    auto al64 = [](size_t x) { return (x + 63) & ~(size_t)63; };
+    const size_t o_starts = al64(out_bytes), o_hdr = al64(o_starts + st_bytes), o_dst = al64(o_hdr + sizeof(WrChanHdr) * nchan), o_cen = al64(o_dst + sizeof(WrDeframeState) * nchan),
+                 o_chans = al64(o_cen + (size_t)nchan * WR_CENSUS_CLASSES * 4), o_dch = al64(o_chans + sizeof(WrChan) * nchan), o_new = al64(o_dch + sizeof(WrDeframeChan) * nchan),
+                 o_gl = al64(o_new + 8 * (size_t)nchan), pin_total = o_gl + sizeof(WrGather) * nchan + 64;
+    if (!rx->pin_reserve(pin_total)) { live_close(rx); return -2; }
+    char *hp = (char *)rx->h_pin;
+    WrChan *chans = (WrChan *)(hp + o_chans);
+    WrDeframeChan *dch = (WrDeframeChan *)(hp + o_dch);
+    WrGather *gl = (WrGather *)(hp + o_gl);                              // chunks the device reads itself (pinned host memory): one kernel instead of a copy per channel
+    size_t ngl = 0;
     rx->sd_off.assign(nchan + 1, 0);
     rx->cap_frames = capf;
+    const bool try_gather = getenv("WENET_RX_NO_GATHER") == nullptr;
     for (int i = 0; i < nchan; i++) {
         char *blk = rx->d_live_in.as<char>() + (size_t)i * rx->live_in_stride;
         if (nsamples[i] > 0) {
-            WR_LIVE_CHECK(hipMemcpyAsync(blk + (size_t)rx->live_carry_smp[i] * bps, chunk[i], (size_t)nsamples[i] * bps, hipMemcpyHostToDevice, stream), -3);
+            const char *dv = try_gather ? device_view_of_host(chunk[i]) : nullptr;
+            if (dv) gl[ngl++] = WrGather{dv, blk + (size_t)rx->live_carry_smp[i] * bps, (long long)((size_t)nsamples[i] * bps)};
+            else WR_LIVE_CHECK(hipMemcpyAsync(blk + (size_t)rx->live_carry_smp[i] * bps, chunk[i], (size_t)nsamples[i] * bps, hipMemcpyHostToDevice, stream), -3);
         }
         float *sdb = rx->d_sd.as<float>() + (size_t)i * rx->live_sd_stride;
         WrChan &ch = chans[i];
@@ -1585,9 +1640,20 @@ extern "C" long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *c
         d.starts = rx->d_starts.as<long long>() + (size_t)i * max_pk;
         d.cap_packets = max_pk;
     }
-    WR_LIVE_CHECK(hipMemcpyAsync(rx->d_chans.p, chans.data(), sizeof(WrChan) * nchan, hipMemcpyHostToDevice, stream), -3);
-    WR_LIVE_CHECK(hipMemcpyAsync(rx->d_dchans.p, dch.data(), sizeof(WrDeframeChan) * nchan, hipMemcpyHostToDevice, stream), -3);
-    WR_LIVE_CHECK(hipMemcpyAsync(d_newsmp, nsamples, sizeof(long long) * nchan, hipMemcpyHostToDevice, stream), -3);
+    rx->live_gathered = (int)ngl;
+    if (ngl > 0) {
+        if (!rx->d_live_gather.reserve(sizeof(WrGather) * (size_t)nchan)) { live_close(rx); return -2; }
+        WR_LIVE_CHECK(hipMemcpyAsync(rx->d_live_gather.p, gl, sizeof(WrGather) * ngl, hipMemcpyHostToDevice, stream), -3);
+        long long mx = 0;
+        for (size_t k = 0; k < ngl; k++) mx = std::max(mx, gl[k].bytes);
+        const unsigned pieces = (unsigned)std::min<long long>(16, std::max<long long>(1, mx / 16384));        // >= 16 KB of a chunk per workgroup
+        hipLaunchKernelGGL(wenet_live_gather_kernel, dim3(pieces, (unsigned)ngl), dim3(256), 0, stream, rx->d_live_gather.as<WrGather>());
+        WR_LIVE_CHECK(hipGetLastError(), -4);
+    }
+    memcpy(hp + o_new, nsamples, 8 * (size_t)nchan);
+    WR_LIVE_CHECK(hipMemcpyAsync(rx->d_chans.p, chans, sizeof(WrChan) * nchan, hipMemcpyHostToDevice, stream), -3);
+    WR_LIVE_CHECK(hipMemcpyAsync(rx->d_dchans.p, dch, sizeof(WrDeframeChan) * nchan, hipMemcpyHostToDevice, stream), -3);
+    WR_LIVE_CHECK(hipMemcpyAsync(d_newsmp, hp + o_new, sizeof(long long) * nchan, hipMemcpyHostToDevice, stream), -3);
     WR_LIVE_CHECK(hipMemsetAsync(rx->d_census.p, 0, (size_t)nchan * WR_CENSUS_CLASSES * 4, stream), -3);
     // (4) demodulate every whole frame, look for unique words in carried + new symbols, decode every packet completed
     rx->nchunks = 1;
@@ -1616,24 +1682,21 @@ extern "C" long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *c
     WR_LIVE_CHECK(hipEventRecord(e.ev[3], stream), -4);
     // (5) results: state headers, deframer states, packet slots
     {
-        const size_t n_slots = (size_t)nchan * max_pk, out_bytes = n_slots * sizeof(WrPacketOut), st_bytes = n_slots * 8;
-        if (!rx->pin_reserve(out_bytes + st_bytes + 64)) { live_close(rx); return -2; }
-        rx->h_out = (WrPacketOut *)rx->h_pin;
-        rx->h_starts = (long long *)((char *)rx->h_pin + ((out_bytes + 63) & ~(size_t)63));
+        rx->h_out = (WrPacketOut *)hp;
+        rx->h_starts = (long long *)(hp + o_starts);
         rx->h_dstates.resize(nchan);
         rx->h_census.resize((size_t)nchan * WR_CENSUS_CLASSES);
-        WR_LIVE_CHECK(hipMemcpyAsync(rx->h_states.data(), rx->d_states.p, stb * nchan, hipMemcpyDeviceToHost, stream), -3);
-        WR_LIVE_CHECK(hipMemcpyAsync(rx->h_dstates.data(), rx->d_dstates.p, sizeof(WrDeframeState) * nchan, hipMemcpyDeviceToHost, stream), -3);
-        WR_LIVE_CHECK(hipMemcpyAsync(rx->h_census.data(), rx->d_census.p, rx->h_census.size() * 4, hipMemcpyDeviceToHost, stream), -3);
+        // (the host reads the HEADERS of the state blocks only: one strided copy; every slot of the tick comes back with them -- a few per channel -- and ONE wait ends the tick)
+        WR_LIVE_CHECK(hipMemcpy2DAsync(hp + o_hdr, sizeof(WrChanHdr), rx->d_states.p, stb, sizeof(WrChanHdr), (size_t)nchan, hipMemcpyDeviceToHost, stream), -3);
+        WR_LIVE_CHECK(hipMemcpyAsync(hp + o_dst, rx->d_dstates.p, sizeof(WrDeframeState) * nchan, hipMemcpyDeviceToHost, stream), -3);
+        WR_LIVE_CHECK(hipMemcpyAsync(hp + o_cen, rx->d_census.p, rx->h_census.size() * 4, hipMemcpyDeviceToHost, stream), -3);
+        WR_LIVE_CHECK(hipMemcpyAsync(rx->h_out, rx->d_out.p, out_bytes, hipMemcpyDeviceToHost, stream), -3);
+        WR_LIVE_CHECK(hipMemcpyAsync(rx->h_starts, rx->d_starts.p, st_bytes, hipMemcpyDeviceToHost, stream), -3);
         WR_LIVE_CHECK(hipStreamSynchronize(stream), -4);
+        for (int i = 0; i < nchan; i++) memcpy(&rx->h_states[(size_t)i * c.st_floats], hp + o_hdr + sizeof(WrChanHdr) * (size_t)i, sizeof(WrChanHdr));
+        memcpy(rx->h_dstates.data(), hp + o_dst, sizeof(WrDeframeState) * nchan);
+        memcpy(rx->h_census.data(), hp + o_cen, rx->h_census.size() * 4);
         long long total = 0;
-        size_t used_slots = 0;
-        for (int i = 0; i < nchan; i++) if (rx->h_dstates[i].npackets > 0) used_slots = (size_t)(i + 1) * max_pk;
-        if (used_slots > 0) {
-            WR_LIVE_CHECK(hipMemcpyAsync(rx->h_out, rx->d_out.p, used_slots * sizeof(WrPacketOut), hipMemcpyDeviceToHost, stream), -3);
-            WR_LIVE_CHECK(hipMemcpyAsync(rx->h_starts, rx->d_starts.p, used_slots * 8, hipMemcpyDeviceToHost, stream), -3);
-            WR_LIVE_CHECK(hipStreamSynchronize(stream), -4);
-        }
         // (6) the host's mirror of what stays on the device for the next tick (wenet_live_compact_kernel computes the same from the same words)
         long long fr = 0, sl = 0;
         for (int i = 0; i < nchan; i++) {

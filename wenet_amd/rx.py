@@ -92,6 +92,10 @@ class RxBatch:
         self.nchan = n
         return rc
 
+    def live_gathered(self):
+        """chunks of the last tick that the GPU read from the caller's (pinned) buffers itself"""
+        return int(self._L.wenet_rx_live_gathered(self._h))
+
     def flush(self):
         """end of the live streams (what is left undone is dropped, as the reference pipe drops it at EOF)"""
         if self._L.wenet_rx_flush(self._h) < 0:
