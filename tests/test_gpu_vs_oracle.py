@@ -133,7 +133,19 @@ def test_illegal_parameters_rejected():
         Fsk(960000, 96000, 10, 3)
 
 
-def test_sd_to_llr_corners():
+STATS_KERNELS = [pytest.param(None, id="stats-workgroup-per-packet"), pytest.param("0", id="stats-lane-per-packet")]
+
+
+def _pick_stats_kernel(monkeypatch, small_slots):
+    """the LLR statistics run in one of two kernels by batch size (ldpc_kernel.hip: a workgroup per packet up to 32 768 slots, a lane per packet beyond): small tests
+    would only ever see the first, so the ones that pin the statistics run with both"""
+    if small_slots is not None:
+        monkeypatch.setenv("WENET_RX_SMALL_STATS_SLOTS", small_slots)
+
+
+@pytest.mark.parametrize("small_slots", STATS_KERNELS)
+def test_sd_to_llr_corners(small_slots, monkeypatch):
+    _pick_stats_kernel(monkeypatch, small_slots)
     O = ol.oracle()
     rng = np.random.default_rng(8)
     cases = [rng.standard_normal(2580), np.full(2580, 0.25), np.zeros(2580),
@@ -182,8 +194,10 @@ def test_ldpc_many_noisy_codewords():
     assert len(set(iters.tolist())) > 3          # the sample really spans easy and hard packets
 
 
-def test_deframer_false_uw_and_back_to_back():
+@pytest.mark.parametrize("small_slots", STATS_KERNELS)
+def test_deframer_false_uw_and_back_to_back(small_slots, monkeypatch):
     """UW hits inside noise, a detection right after a packet (stale window), EOF inside a packet."""
+    _pick_stats_kernel(monkeypatch, small_slots)
     rng = np.random.default_rng(11)
     for mode in (1, 2):
         cfg = siggen.config_v1() if mode == 1 else siggen.config_v2()
@@ -199,7 +213,9 @@ def test_deframer_false_uw_and_back_to_back():
         d.close()
 
 
-def test_batch_ragged_and_slot_invariance():
+@pytest.mark.parametrize("small_slots", STATS_KERNELS)
+def test_batch_ragged_and_slot_invariance(small_slots, monkeypatch):
+    _pick_stats_kernel(monkeypatch, small_slots)
     cfg = siggen.config_v2()
     caps = [siggen.make_capture(cfg, n, eb, seed=200 + n)[0] for n, eb in ((3, 8.0), (1, 20.0), (5, 6.0), (2, 9.0))]
     caps.append(np.zeros(0, np.uint8))                      # an empty capture in the batch

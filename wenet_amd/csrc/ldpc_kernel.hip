@@ -268,6 +268,81 @@ __global__ __launch_bounds__(64) void wenet_llr_stats_kernel(WrDecodeArgs A) {
     }
 }
 
+// The same statistics for FEW packets (a live tick, one capture): there the kernel above is all latency -- a wavefront walks 2 x 81 chunks with one chunk in flight, ~1.8 us of
+// memory latency each, 0.6 ms however few packets there are (a third of a 128-channel tick).  Here a WORKGROUP takes one packet: all of its symbols are loaded at once (one memory
+// round trip), the divisions of the second pass run on all threads, and only what the reference's arithmetic makes serial stays serial -- the three ordered double sums, on one lane
+// each (the second pass's two on different wavefronts, side by side).  Same expressions in the same order: same bits.  ~25 us per packet and workgroup; wr_launch_decode takes this
+// kernel up to WR_ST_SMALL_SLOTS packet slots (beyond that the throughput of one LANE per packet wins).
+#define WR_ST_SMALL_SLOTS 32768
+template <bool SD64>
+__global__ __launch_bounds__(256) void wenet_llr_stats_small_kernel(WrDecodeArgs A) {
+    typedef typename std::conditional<SD64, double, float>::type elt;
+    __shared__ double xs[3072];
+    __shared__ double red[4];
+    const int tid = threadIdx.x;
+    const long long slot = blockIdx.x;
+    const int n = SD64 ? A.n_sd : WR_NCODE;
+    bool live = true;
+    unsigned long long base = 0;
+    {
+        const int ch = (int)(slot / A.max_pk), pk = (int)(slot - (long long)ch * A.max_pk);
+        if (A.input_kind == WR_DEC_IN_STREAM) {
+            const WrDeframeChan D = A.dchans[ch];
+            live = pk < D.state->npackets;
+            if (live) base = (unsigned long long)(uintptr_t)(D.sd + D.starts[pk]);
+        } else {
+            live = pk < A.npk_direct[ch];
+            if (live) base = (unsigned long long)(uintptr_t)(A.sd64 + slot * n);
+        }
+    }
+    if (tid == 0) A.pbase[slot] = live ? base : 0ull;
+    if (!live) return;
+    const __attribute__((address_space(1))) elt *src = (const __attribute__((address_space(1))) elt *)base;
+    for (int i = tid; i < n; i += 256) {
+        long long off = i;
+        if (!SD64 && A.mode == 1) off = 10 * (i >> 3) + 8 - (i & 7);          // RS232 strip: out[8b+j] = in[10b + 8 - j] (drs232_ldpc.c:220-225)
+        elt v = src[off];
+        if (!SD64 && A.mode == 2) {                                             // symbol * scramble_code[ind % 1000] (wenet_ldpc.c:207)
+            const int kb = i % 1000;
+            if ((A.scramble[kb >> 3] >> (7 - (kb & 7))) & 1) v = v * (elt)-1;
+        }
+        xs[i] = (double)v;
+    }
+    __syncthreads();
+    if (tid == 0) {                                                             // mpdecode_core.c:575-579
+        double sum = 0.0;
+#pragma unroll 8
+        for (int i = 0; i < n; i++) sum += fabs(xs[i]);
+        red[0] = sum / n;
+    }
+    __syncthreads();
+    const double mean = red[0];
+    for (int i = tid; i < n; i += 256) {                                        // mpdecode_core.c:583-587: x = sd/mean - sign(sd)
+        const double s = xs[i];
+        const double sign = (double)((s > 0.0) - (s < 0.0));
+        xs[i] = s / mean - sign;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double sum = 0.0;
+#pragma unroll 8
+        for (int i = 0; i < n; i++) sum += xs[i];
+        red[1] = sum;
+    }
+    if (tid == 64) {
+        double sumsq = 0.0;
+#pragma unroll 8
+        for (int i = 0; i < n; i++) { const double x = xs[i]; sumsq += x * x; }
+        red[2] = sumsq;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const double sum = red[1], sumsq = red[2];
+        const double estvar = (n * sumsq - sum * sum) / (n * (n - 1));
+        A.esn0[slot] = wx_est_esn0(estvar);                                      // 1.0/(2.0L*estvar + 1E-3), x87 rounding
+    }
+}
+
 // CRC-16/CCITT-FALSE gate (drs232_ldpc.c:91-102, 243-254): byte-serial, one thread per packet
 __global__ __launch_bounds__(256) void wenet_crc_kernel(WrDecodeArgs A) {
     const long long slot = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -650,9 +725,16 @@ extern "C" hipError_t wr_launch_decode(const WrDecodeArgs *args, hipStream_t str
     const unsigned blocks = (unsigned)((slots + 255) / 256);
     if (args->input_kind != WR_DEC_IN_LLR && args->phase != 2)
     {
-        const dim3 sgrid((unsigned)((slots + 63) / 64));
-        if (args->input_kind == WR_DEC_IN_SD64) hipLaunchKernelGGL(wenet_llr_stats_kernel<true>, sgrid, dim3(64), 0, stream, *args);
-        else hipLaunchKernelGGL(wenet_llr_stats_kernel<false>, sgrid, dim3(64), 0, stream, *args);
+        const char *ev = getenv("WENET_RX_SMALL_STATS_SLOTS");                                  // (tests: 0 = the one-lane-per-packet kernel for every batch)
+        const long long small_max = ev ? atoll(ev) : (long long)WR_ST_SMALL_SLOTS;
+        if (slots <= small_max) {
+            if (args->input_kind == WR_DEC_IN_SD64) hipLaunchKernelGGL(wenet_llr_stats_small_kernel<true>, dim3((unsigned)slots), dim3(256), 0, stream, *args);
+            else hipLaunchKernelGGL(wenet_llr_stats_small_kernel<false>, dim3((unsigned)slots), dim3(256), 0, stream, *args);
+        } else {
+            const dim3 sgrid((unsigned)((slots + 63) / 64));
+            if (args->input_kind == WR_DEC_IN_SD64) hipLaunchKernelGGL(wenet_llr_stats_kernel<true>, sgrid, dim3(64), 0, stream, *args);
+            else hipLaunchKernelGGL(wenet_llr_stats_kernel<false>, sgrid, dim3(64), 0, stream, *args);
+        }
     }
     if (args->phase == 1) return hipGetLastError();
     const int lds = WR_DEC_LDS_BYTES;
