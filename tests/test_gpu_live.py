@@ -46,7 +46,10 @@ def _run_live(cfg, caps, fmt, cuts, want_llr=False, max_iter=10, pinned=False):
             k = cuts[ch][t] if t < len(cuts[ch]) else 0
             chunks.append(raw[ch][pos[ch] * bps:(pos[ch] + k) * bps])
             pos[ch] += k
-        got = rx.push(chunks, fmt)
+        if pinned and t % 2:                                              # the address form of the same call (RxBatch.push_ptrs)
+            got = rx.push_ptrs(np.array([c.ctypes.data if c.size else 0 for c in chunks], np.uint64), np.array([c.size // bps for c in chunks], np.int64), fmt)
+        else:
+            got = rx.push(chunks, fmt)
         assert rx.live_gathered() == (sum(1 for c in chunks if c.size) if pinned else 0)
         tick_pk = 0
         for ch in range(n):

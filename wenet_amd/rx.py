@@ -92,6 +92,20 @@ class RxBatch:
         self.nchan = n
         return rc
 
+    def push_ptrs(self, ptrs, nsamples, fmt):
+        """the same tick from ADDRESSES: ptrs = uint64 array of the channels' chunk addresses in host memory (0 where nothing arrived), nsamples = int64 array.  For callers
+        that keep per-channel rings (pinned, so that the GPU reads them itself) and form a tick's addresses with one vector operation -- no per-channel Python work."""
+        ptrs = np.ascontiguousarray(ptrs, np.uint64)
+        ns = np.ascontiguousarray(nsamples, np.int64)
+        n = int(ptrs.size)
+        if ns.size != n:
+            raise ValueError("one sample count per channel")
+        rc = int(self._L.wenet_rx_push(self._h, n, ptrs.ctypes.data_as(C.c_void_p), ns.ctypes.data_as(C.c_void_p), FMT[fmt]))
+        if rc < 0:
+            raise RuntimeError(f"wenet_rx_push failed ({rc})")
+        self.nchan = n
+        return rc
+
     def live_gathered(self):
         """chunks of the last tick that the GPU read from the caller's (pinned) buffers itself"""
         return int(self._L.wenet_rx_live_gathered(self._h))
