@@ -493,7 +493,7 @@ def main():
                     rl.flush()
                     rl.close()
                     live[kind] = {"x_realtime_sustained": round(nsamp / cfg.Fs / sum(lat), 1), "msamples_per_s": round(nl * nsamp / sum(lat) / 1e6, 1),
-                                  "tick_latency_ms": {"mean": round(1e3 * sum(lat) / len(lat), 3), "worst": round(1e3 * max(lat), 3), "best": round(1e3 * min(lat), 3)},
+                                  "tick_latency_ms": {"mean": round(1e3 * sum(lat) / len(lat), 3), "median": round(1e3 * float(np.median(lat)), 3), "worst": round(1e3 * max(lat), 3), "best": round(1e3 * min(lat), 3)},
                                   "kernel_ms_per_tick": {"demod": round(kms[0] / len(lat), 3), "deframe": round(kms[1] / len(lat), 3), "decode": round(kms[2] / len(lat), 3)},
                                   "packets_completed": npk_l, "chunks_read_by_the_gpu_itself_last_tick": gathered}
                 other["live_128"] = {"channels": nl, "tick_ms": 100.0, "ticks": len(lat), "kernel": lk,
