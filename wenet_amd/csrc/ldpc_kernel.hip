@@ -177,10 +177,7 @@ __device__ __forceinline__ double packet_symbol(const WrDecodeArgs &A, unsigned 
 // LDS with coalesced loads (two packets x 128 B per instruction, the next chunk in flight while this one is
 // summed) and the lanes then read their column conflict-free.
 // Output: estEsN0 per packet slot, with the reference's x87 rounding (x87emu.h).
-#ifndef WR_ST_CHUNK
 #define WR_ST_CHUNK 32
-#endif
-#define WR_ST_PPI (64 / WR_ST_CHUNK)                              // packets per load instruction (lanes 0..CHUNK-1 the first, ...)
 #define WR_ST_PITCH 65                                           // row pitch in elements: the transposing writes spread over the banks
 template <bool SD64>                                             // SD64: double input of the sd_to_llr API; else the float sd stream
 __global__ __launch_bounds__(64) void wenet_llr_stats_kernel(WrDecodeArgs A) {
@@ -212,9 +209,9 @@ __global__ __launch_bounds__(64) void wenet_llr_stats_kernel(WrDecodeArgs A) {
     if (!SD64 && A.mode == 2) { scr[lane] = A.scramble[lane]; if (lane + 64 < 125) scr[lane + 64] = A.scramble[lane + 64]; }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    const int sub = lane / WR_ST_CHUNK, col = lane % WR_ST_CHUNK;    // load phase: lanes 0-31 fetch packet 2g, lanes 32-63 packet 2g+1
+    const int sub = lane >> 5, col = lane & 31;                  // load phase: lanes 0-31 fetch packet 2g, lanes 32-63 packet 2g+1
     const int nchunks = (n + WR_ST_CHUNK - 1) / WR_ST_CHUNK;
-    elt pre[64 / WR_ST_PPI];
+    elt pre[32];
     // raw loads only (nothing here waits for them): pre[g] = stored symbol of packet 2g+sub that becomes symbol c*32+col
     auto fetch = [&](int c) {
         const int i = c * WR_ST_CHUNK + col;
@@ -222,8 +219,8 @@ __global__ __launch_bounds__(64) void wenet_llr_stats_kernel(WrDecodeArgs A) {
         if (SD64 || A.mode != 1) off = i;
         else off = 10 * (i >> 3) + 8 - (i & 7);                  // RS232 strip: out[8b+j] = in[10b + 8 - j] (drs232_ldpc.c:220-225)
 #pragma unroll
-        for (int g = 0; g < 64 / WR_ST_PPI; g++) {
-            const unsigned long long pb = pbase[WR_ST_PPI * g + sub];
+        for (int g = 0; g < 32; g++) {
+            const unsigned long long pb = pbase[2 * g + sub];
             elt v = 0;
             // (global address space: a FLAT load would count on lgkmcnt too, and the wait for the LDS writes below would wait for it)
             if (pb != 0ull && i < n) v = ((const __attribute__((address_space(1))) elt *)pb)[off];
@@ -237,7 +234,7 @@ __global__ __launch_bounds__(64) void wenet_llr_stats_kernel(WrDecodeArgs A) {
             if ((scr[kb >> 3] >> (7 - (kb & 7))) & 1) sg = -1;
         }
 #pragma unroll
-        for (int g = 0; g < 64 / WR_ST_PPI; g++) buf[c & 1][col * WR_ST_PITCH + WR_ST_PPI * g + sub] = pre[g] * sg;
+        for (int g = 0; g < 32; g++) buf[c & 1][col * WR_ST_PITCH + 2 * g + sub] = pre[g] * sg;
     };
     double mean = 0.0, sum = 0.0, sumsq = 0.0;
     for (int pass = 0; pass < 2; pass++) {
