@@ -1,9 +1,9 @@
 # development aid: LDS activity / bank-conflict counters of our kernels at the bench workload -> gpurun_out/<tag>_lds_counters.txt
 # usage: gpu_pmc_lds.sh [captures] [tag]
 cd /tmp && export TMPDIR=/tmp
-B=${1:-3584}; TAG=${2:-r04}
+B=${1:-3584}; TAG=${2:-r04}; shift; shift
 mkdir -p $GRAFT_REPO_ROOT/gpurun_out
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_lds -o s -- python $GRAFT_REPO_ROOT/bench.py --captures $B --steps 1 --warmup 0 --no-cpu-baseline --no-extras > /tmp/pmc_lds.log 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_lds -o s -- python $GRAFT_REPO_ROOT/bench.py --captures $B --steps 1 --warmup 0 --no-cpu-baseline --no-extras "$@" > /tmp/pmc_lds.log 2>&1
 python - $B <<'PY' | tee $GRAFT_REPO_ROOT/gpurun_out/${TAG}_lds_counters.txt
 import csv, glob, sys
 print("# rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE -- python bench.py --captures %s --steps 1 (tools/gpu_pmc_lds.sh)" % sys.argv[1])
