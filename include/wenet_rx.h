@@ -181,6 +181,10 @@ int wenet_rx_flush(wenet_rx *rx);
 /* How many of the last tick's chunks the GPU read from the caller's buffers itself (one gather kernel over PCIe instead of one copy per channel):
  * every chunk in PINNED host memory (hipHostMalloc / hipHostRegister; torch pin_memory) goes that way, pageable ones are copied as before. */
 int wenet_rx_live_gathered(wenet_rx *rx);
+/* Pin a host buffer the caller already owns (a per-channel ring, a numpy array) so that chunks inside it go the gather way: hipHostRegister / hipHostUnregister
+ * for callers that do not link HIP themselves.  Once per buffer, not per tick (registration costs about a millisecond per 20 MB).  0, or < 0 on error. */
+int wenet_rx_pin_host(void *p, size_t bytes);
+int wenet_rx_unpin_host(void *p);
 /* results of the last process/collect */
 long long wenet_rx_frames(wenet_rx *rx, int ch);            /* modem frames demodulated */
 long long wenet_rx_packets(wenet_rx *rx, int ch);           /* packets completed (valid or not) */

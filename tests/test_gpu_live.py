@@ -35,7 +35,10 @@ def _run_live(cfg, caps, fmt, cuts, want_llr=False, max_iter=10, pinned=False):
     is_pinned = [bool(pinned) and (pinned != "mixed" or ch % 2 == 0) for ch in range(n)]      # "mixed": every other channel stays in pageable memory
     if pinned:                                                            # channel ch's buffer starts ch bytes into its allocation: every source alignment
         for ch in range(n):
-            if is_pinned[ch]:
+            if is_pinned[ch] and pinned == "registered":                  # the caller's own (pageable) array, pinned through the library (wenet_rx_pin_host)
+                raw[ch] = raw[ch].copy()
+                rx.pin(raw[ch])
+            elif is_pinned[ch]:
                 raw[ch], t = _pinned_copy(raw[ch], ch % 16)
                 keep.append(t)
     pos = [0] * n
@@ -68,6 +71,9 @@ def _run_live(cfg, caps, fmt, cuts, want_llr=False, max_iter=10, pinned=False):
         assert pos[ch] * bps == raw[ch].size, "the cuts must cover the capture"
     frames = [rx.frames(ch) for ch in range(n)]
     rx.flush()
+    if pinned == "registered":
+        for ch in range(n):
+            rx.unpin(raw[ch])
     rx.close()
     return out, frames, reported
 
@@ -129,7 +135,7 @@ def test_live_formats_framings_and_tiny_ticks(name, fmt, mean):
     assert _check(cfg, caps, fmt, out, frames) > 0
 
 
-@pytest.mark.parametrize("name,fmt,mean,pinned", [("v2", "cu8", 20000, True), ("v1", "cs16", 700, True), ("v2", "cf32", 30001, True), ("v2", "cu8", 12000, "mixed")])
+@pytest.mark.parametrize("name,fmt,mean,pinned", [("v2", "cu8", 20000, True), ("v1", "cs16", 700, True), ("v2", "cf32", 30001, True), ("v2", "cu8", 12000, "mixed"), ("v2", "cu8", 15000, "registered")])
 def test_live_pinned_buffers_are_read_by_the_gpu_itself(name, fmt, mean, pinned):
     """chunks in pinned host memory are gathered by ONE kernel over PCIe (no copy per channel): every alignment of source (the buffers start 0..15 bytes
     into their allocations, the ticks cut them anywhere) and destination (behind whatever the last tick left), tiny and empty chunks; same results"""

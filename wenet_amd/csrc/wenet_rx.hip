@@ -1513,6 +1513,18 @@ extern "C" int wenet_rx_flush(wenet_rx *rx) {
 }
 
 extern "C" int wenet_rx_live_gathered(wenet_rx *rx) { return rx ? rx->live_gathered : -1; }
+extern "C" int wenet_rx_pin_host(void *p, size_t bytes) {
+    if (!p || bytes == 0 || !device_ready()) return -1;
+    const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterPortable | hipHostRegisterMapped);
+    if (e != hipSuccess) { (void)hipGetLastError(); fprintf(stderr, "libwenet_rx: wenet_rx_pin_host: %s\n", hipGetErrorString(e)); return -3; }
+    return 0;
+}
+extern "C" int wenet_rx_unpin_host(void *p) {
+    if (!p || !device_ready()) return -1;
+    const hipError_t e = hipHostUnregister(p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return -3; }
+    return 0;
+}
 
 extern "C" long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *chunk, const long long *nsamples, int fmt) {
     if (!rx || nchan <= 0 || fmt < 0 || fmt > 3 || !nsamples) return -1;

@@ -28,7 +28,7 @@ EXPORTS = [
     "wenet_rx_enable_trace", "wenet_rx_get_trace", "wenet_rx_enable_llr_dump", "wenet_rx_get_llrs",
     "wenet_rx_last_ms", "wenet_rx_device_info", "wenet_rx_version", "wenet_rx_last_kernel", "wenet_rx_get_device", "wenet_rx_channel_counter", "wenet_rx_set_cf32_quantise",
     "wenet_packet_type_class", "wenet_ssdv_packet_info", "wenet_rx_get_packets_of_class", "wenet_rx_ssdv_images",
-    "wenet_phi0_eval", "wenet_rx_source_id", "wenet_rx_push", "wenet_rx_flush", "wenet_rx_live_gathered", "wenet_fsk_last_ebnodb",
+    "wenet_phi0_eval", "wenet_rx_source_id", "wenet_rx_push", "wenet_rx_flush", "wenet_rx_live_gathered", "wenet_rx_pin_host", "wenet_rx_unpin_host", "wenet_fsk_last_ebnodb",
 ]
 # every symbol include/wenet_tx.h declares
 EXPORTS_TX = [
@@ -104,6 +104,8 @@ def load():
     L.wenet_rx_push.restype = ll; L.wenet_rx_push.argtypes = [vp, i, vp, vp, i]
     L.wenet_rx_flush.argtypes = [vp]
     L.wenet_rx_live_gathered.argtypes = [vp]
+    L.wenet_rx_pin_host.argtypes = [vp, C.c_size_t]
+    L.wenet_rx_unpin_host.argtypes = [vp]
     L.wenet_rx_frames.restype = ll; L.wenet_rx_frames.argtypes = [vp, i]
     L.wenet_rx_packets.restype = ll; L.wenet_rx_packets.argtypes = [vp, i]
     L.wenet_rx_get_packets.restype = ll; L.wenet_rx_get_packets.argtypes = [vp, i, vp, vp, ll]

@@ -106,6 +106,16 @@ class RxBatch:
         self.nchan = n
         return rc
 
+    def pin(self, array):
+        """pin a numpy array the caller keeps (a channel's ring): chunks inside it are then read by the GPU itself.  Once per buffer; unpin() before freeing it."""
+        a = np.asarray(array)
+        if self._L.wenet_rx_pin_host(C.c_void_p(a.ctypes.data), a.nbytes) < 0:
+            raise RuntimeError("wenet_rx_pin_host failed")
+
+    def unpin(self, array):
+        if self._L.wenet_rx_unpin_host(C.c_void_p(np.asarray(array).ctypes.data)) < 0:
+            raise RuntimeError("wenet_rx_unpin_host failed")
+
     def live_gathered(self):
         """chunks of the last tick that the GPU read from the caller's (pinned) buffers itself"""
         return int(self._L.wenet_rx_live_gathered(self._h))
