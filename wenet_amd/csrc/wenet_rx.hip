@@ -1660,8 +1660,10 @@ extern "C" long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *c
         long long mx = 0;
         for (size_t k = 0; k < ngl; k++) mx = std::max(mx, gl[k].bytes);
         const unsigned pieces = (unsigned)std::min<long long>(16, std::max<long long>(1, mx / 16384));        // >= 16 KB of a chunk per workgroup
-        hipLaunchKernelGGL(wenet_live_gather_kernel, dim3(pieces, (unsigned)ngl), dim3(256), 0, stream, rx->d_live_gather.as<WrGather>());
-        WR_LIVE_CHECK(hipGetLastError(), -4);
+        for (size_t g0 = 0; g0 < ngl; g0 += 65535) {                     // (grid y <= 65535)
+            hipLaunchKernelGGL(wenet_live_gather_kernel, dim3(pieces, (unsigned)std::min<size_t>(65535, ngl - g0)), dim3(256), 0, stream, rx->d_live_gather.as<WrGather>() + g0);
+            WR_LIVE_CHECK(hipGetLastError(), -4);
+        }
     }
     memcpy(hp + o_new, nsamples, 8 * (size_t)nchan);
     WR_LIVE_CHECK(hipMemcpyAsync(rx->d_chans.p, chans, sizeof(WrChan) * nchan, hipMemcpyHostToDevice, stream), -3);
