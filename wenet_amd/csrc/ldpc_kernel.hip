@@ -612,6 +612,11 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
             const unsigned long long bal = __ballot(ok & 1), bal2 = __ballot(ok & 2);     // ok = number of satisfied checks of this thread (0..3)
             if ((tid & 63) == 0 && (bal | bal2)) atomicAdd(&red[par * 2 + 0], __popcll(bal) + 2 * __popcll(bal2));
         }
+#ifndef WR_DEC_NO_ADDTID
+        // the add-TID stores above sit in asm blocks: the compiler's wait-count bookkeeping does not know they are in flight and puts a wait for them in front of the barrier
+        // only if some LDS access of its own happens to be pending there (it is, today) -- the barrier's wait is therefore written out
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
         __syncthreads();
         const int ssum = red[par * 2 + 0];
         if (tid == 0) { red[(par ^ 1) * 2 + 0] = 0; red[(par ^ 1) * 2 + 1] = 0; }
