@@ -482,12 +482,17 @@ def main():
                     rl.flush()
                     lat, npk_l, kms = [], 0, np.zeros(3)
                     base_l = np.array([h.ctypes.data for h in hostl], np.uint64)         # the channels' buffers as addresses: a tick is base + offset (RxBatch.push_ptrs)
+                    # (the legs before this one pinned and dropped ~15 GB of host memory: let the interpreter and the runtime finish with it now, not inside a tick -- a
+                    #  garbage-collection pass that unpins such a block stalls the device for tens of milliseconds; the collector then rests while the ticks are timed)
+                    import gc
+                    gc.collect(); torch.cuda.synchronize(); gc.disable()
                     for k in range(0, nsamp, tick):
                         nk = min(tick, nsamp - k)
                         tl = time.perf_counter()
                         npk_l += rl.push_ptrs(base_l + np.uint64(2 * k), np.full(nl, nk, np.int64), "cu8")
                         lat.append(time.perf_counter() - tl)
                         kms += [rl.last_ms(i) for i in range(3)]
+                    gc.enable()
                     lk = rl.last_kernel()
                     gathered = rl.live_gathered()
                     rl.flush()
