@@ -249,6 +249,12 @@ const char *wenet_rx_version(void);
  * a measurement is attributed to the sources only when the two agree, i.e. the library is not a stale build) */
 const char *wenet_rx_source_id(void);
 
+/* The decoder's agreement guard (no counterpart in the reference: src/mpdecode_core.c:385-489 is one thread).  The eight wavefronts that decode a packet
+ * each leave the iteration loop on what they read from a shared counter; a packet on which they did not leave together is not trusted -- it is decoded
+ * again before any result is handed over.  This returns how many packets that happened to: for the batches and ticks of one handle, or process-wide
+ * (rx == NULL: the handle-less entry points included).  0 in every run seen with the shipped decoder; results are bit-identical either way. */
+long long wenet_rx_decoder_repeats(wenet_rx *rx);
+
 /* self-test: phi0 (src/phi0.c:13-218) exactly as the decode kernel evaluates it on the device (keyed LDS tables), y[i] = phi0(x[i]) for n
  * host floats.  0 on success.  (The library also checks the tables on the host against the reference form when it builds them.) */
 int wenet_phi0_eval(const float *x, float *y, long n);

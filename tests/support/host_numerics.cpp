@@ -95,6 +95,12 @@ long check_x87(long n, uint64_t seed, double *first_bad) {
 }
 // the decoder's phi0 table (ldpc_host_tables.h) against the reference form (phi0.c:13-218 with x86 cast semantics) on EVERY integer and half-integer
 // argument up to 1.1e6 / 65536, every threshold's neighbours and the special values; 1 = all equal.  The library checks a 61st of these at start-up.
+// the one-read table of round 5 (WR_PHI0_FORM 4: keyed by the top 16 bits of the argument, fourteen marked cells settled by a second table) against the same reference
+// form on EVERY float from 2^-17 to 32 and a 4099-stride sweep of all 2^32 bit patterns (a few seconds)
+int check_phi0_t7_exhaustive(void) {
+    std::vector<uint32_t> blob;
+    return phi0_build_t7(blob, true) ? 1 : 0;
+}
 int check_phi0_table_exhaustive(void) {
     std::vector<uint32_t> lut;
     return phi0_build_lut(lut, true) ? 1 : 0;

@@ -1,0 +1,99 @@
+"""GPU: the decoder's agreement guard (include/wenet_rx.h: wenet_rx_decoder_repeats; ldpc_kernel.hip).  The eight wavefronts that decode a packet must leave the iteration loop
+together; a packet on which they did not is decoded again before results are handed over.  Round 5 found builds of the decoder in which one wavefront in ~10^7 packets stayed in
+the loop (tools/experiments/README.md); here the same is provoked on purpose (WENET_RX_DBG_DESYNC: wavefront 3 of every workgroup ignores the stop of its n-th packet) and the
+results must equal the undisturbed run's, packet for packet, with the repeats counted."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(B=96, secs=0.5):
+    import torch
+    from wenet_amd import siggen
+    from wenet_amd.tx import Tx
+    cfg = siggen.config_v2()
+    dev = torch.device("cuda:0")
+    nsamp = int(secs * cfg.Fs)
+    nsym = nsamp // (cfg.Fs // cfg.Rs)
+    tx = Tx.from_config(cfg)
+    spp = tx.symbols_per_packet
+    nfr = nsym // spp + 1
+    g = torch.Generator(device=dev)
+    g.manual_seed(515)
+    payloads = torch.randint(0, 256, (B * nfr, 256), dtype=torch.uint8, device=dev, generator=g)
+    symbols = torch.empty(B * nfr * spp, dtype=torch.uint8, device=dev)
+    tx.frame_packets_device(payloads.data_ptr(), B * nfr, symbols.data_ptr())
+    caps = [torch.empty(2 * nsamp, dtype=torch.uint8, device=dev) for _ in range(B)]
+    tx.modulate_device([symbols.data_ptr() + i * nfr * spp for i in range(B)], [nsym] * B, [c.data_ptr() for c in caps],
+                       [7.0 + 3.0 * (i % 8) / 7.0 for i in range(B)], seeds=[31 + i for i in range(B)])
+    torch.cuda.synchronize()
+    return cfg, caps, nsamp
+
+
+def _run(cfg, caps, nsamp):
+    from wenet_amd.rx import RxBatch
+    rx = RxBatch(cfg.Fs, cfg.Rs, cfg.M, framing=cfg.mode)
+    rx.enqueue_device([int(c.data_ptr()) for c in caps], [nsamp] * len(caps), "cu8")
+    rx.collect()
+    out = []
+    for ch in range(len(caps)):
+        p = rx.packets(ch)
+        out.append((p["bytes"].copy(), p["iter"].copy(), p["crc_ok"].copy(), p["start"].copy(), np.array(rx.census(ch))))
+    rep = rx.decoder_repeats()
+    rx.close()
+    return out, rep
+
+
+@pytest.mark.parametrize("nth,B", [(1, 96), (2, 96), (3, 1280), (5, 96), (8, 512)])
+def test_a_wavefront_that_stays_in_the_loop_is_caught_and_the_packets_are_decoded_again(nth, B):
+    cfg, caps, nsamp = _batch(B=B)
+    os.environ.pop("WENET_RX_DBG_DESYNC", None)
+    ref, rep0 = _run(cfg, caps, nsamp)
+    assert rep0 <= 2           # (the undisturbed decoder: a wavefront reads another count than its siblings about twice in a million packets -- harmless unless the count is 516)
+    assert sum(len(r[1]) for r in ref) > 5 * len(caps) and sum(int(r[2].sum()) for r in ref) > 0
+    os.environ["WENET_RX_DBG_DESYNC"] = str(nth)
+    try:
+        got, rep = _run(cfg, caps, nsamp)
+    finally:
+        os.environ.pop("WENET_RX_DBG_DESYNC", None)
+    assert rep > 0, "the provoked wavefront was not noticed"
+    for ch, (a, b) in enumerate(zip(ref, got)):
+        for x, y in zip(a, b):
+            assert x.shape == y.shape and (x == y).all(), f"capture {ch}: results differ from the undisturbed run although {rep} packets were decoded again"
+
+
+def test_guard_off_shows_what_it_guards_against():
+    """the same provocation with the guard switched off (WENET_RX_NO_GUARD) does corrupt packets -- the test above is not vacuous"""
+    cfg, caps, nsamp = _batch(B=48)
+    ref, _ = _run(cfg, caps, nsamp)
+    os.environ["WENET_RX_DBG_DESYNC"] = "2"
+    os.environ["WENET_RX_NO_GUARD"] = "1"
+    try:
+        got, rep = _run(cfg, caps, nsamp)
+    finally:
+        os.environ.pop("WENET_RX_DBG_DESYNC", None)
+        os.environ.pop("WENET_RX_NO_GUARD", None)
+    assert rep == 0
+    differ = sum(int(((a[0] != b[0]).any(axis=1) | (a[1] != b[1])).sum()) for a, b in zip(ref, got) if a[0].shape == b[0].shape)
+    assert differ > 0
+
+
+def test_dense_entry_point_and_live_ticks_are_guarded_too():
+    from wenet_amd import lib as _lib, ldpc
+    L = _lib.load()
+    before = int(L.wenet_rx_decoder_repeats(None))
+    rng = np.random.default_rng(5)
+    # noisy all-zero codewords through the dense-LLR entry point (wenet_ldpc_decode_batch): 64 packets, several per workgroup only if the grid is smaller -- provoke the first
+    llr = (4.0 + 3.0 * rng.standard_normal((64, 2580))).astype(np.float32)
+    ref = ldpc.ldpc_decode_batch(llr, max_iter=10)
+    os.environ["WENET_RX_DBG_DESYNC"] = "1"
+    try:
+        got = ldpc.ldpc_decode_batch(llr, max_iter=10)
+    finally:
+        os.environ.pop("WENET_RX_DBG_DESYNC", None)
+    for a, b in zip(ref, got):
+        assert (np.asarray(a) == np.asarray(b)).all()
+    assert int(L.wenet_rx_decoder_repeats(None)) >= before

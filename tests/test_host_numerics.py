@@ -19,6 +19,7 @@ def hn(tmp_path_factory):
     L.check_atan2f.restype = C.c_long; L.check_atan2f.argtypes = [C.c_long, C.c_uint64, C.POINTER(C.c_uint32)]
     L.check_x87.restype = C.c_long; L.check_x87.argtypes = [C.c_long, C.c_uint64, C.POINTER(C.c_double)]
     L.check_phi0_table_exhaustive.restype = C.c_int
+    L.check_phi0_t7_exhaustive.restype = C.c_int
     L.check_shipped_placement.restype = C.c_int
     return L
 
@@ -36,6 +37,12 @@ def test_atan2f_matches_host_libm(hn):
 def test_x87_emulation_matches_long_double(hn):
     fb = (C.c_double * 2)()
     assert hn.check_x87(10_000_000, 99, fb) == 0, (fb[0], fb[1])
+
+
+def test_phi0_one_read_table_equals_the_reference_form_exhaustively(hn):
+    """the decoder's one-read phi0 table (round 5; wenet_amd/csrc/ldpc_host_tables.h: phi0_build_t7) on every float from 2^-17 to 32 and a stride of all bit patterns,
+    against phi0.c:13-218 with x86 cast semantics"""
+    assert hn.check_phi0_t7_exhaustive() == 1
 
 
 def test_phi0_table_equals_the_reference_form_exhaustively(hn):

@@ -30,21 +30,19 @@ def code_objects(obj, td):
 
 
 def kernel_meta(co):
+    """per kernel: the fields of its `amdhsa.kernels` entry in the code object's metadata note.  (The note is YAML and a kernel's keys are sorted: `.group_segment_fixed_size`
+    comes BEFORE `.name` -- the line-by-line reader of rounds 3-4 attached it to the previous kernel, so the LDS column of those summaries is shifted by one row.)"""
+    import yaml
     txt = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", co], stdout=subprocess.PIPE, text=True, check=False).stdout
-    out, cur = {}, None
-    for line in txt.splitlines():
-        m = re.match(r"\s*-?\s*\.?(\w+):\s*(.*)$", line.strip())
-        if not m:
+    out = {}
+    for doc in re.findall(r"^\s*---\n(.*?)^\s*\.\.\.", txt, flags=re.S | re.M):
+        try:
+            y = yaml.safe_load(doc)
+        except yaml.YAMLError:
             continue
-        k, v = m.group(1), m.group(2).strip().strip("'")
-        if k == "name" and not v.startswith("cfg") and ("wenet" in v or v.startswith("_Z")):
-            cur = out.setdefault(v, {})
-        elif cur is not None and k in ("vgpr_count", "sgpr_count", "vgpr_spill_count", "sgpr_spill_count", "group_segment_fixed_size",
-                                       "private_segment_fixed_size", "agpr_count", "max_flat_workgroup_size"):
-            try:
-                cur[k] = int(v)
-            except ValueError:
-                pass
+        for k in (y or {}).get("amdhsa.kernels", []):
+            name = k.get(".name", "")
+            out[name] = {f.lstrip("."): v for f, v in k.items() if isinstance(v, int)}
     return {k: v for k, v in out.items() if "vgpr_count" in v}
 
 
@@ -91,8 +89,10 @@ def kernel_mix(co):
 
 
 def demangle(names):
+    if not names:
+        return {}
     try:
-        out = subprocess.run(["c++filt"] + list(names), stdout=subprocess.PIPE, text=True, check=True).stdout.splitlines()
+        out = subprocess.run(["c++filt"] + list(names), stdout=subprocess.PIPE, stdin=subprocess.DEVNULL, text=True, check=True).stdout.splitlines()
         return dict(zip(names, out))
     except Exception:
         return {n: n for n in names}

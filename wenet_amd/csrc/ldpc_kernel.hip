@@ -114,6 +114,81 @@ namespace {
 #ifndef WR_PHI0_FORM
 #define WR_PHI0_FORM 1
 #endif
+// WR_PHI0_FORM 4 (the product since round 5): ONE 4-byte LDS read per evaluation from a table keyed by the top 16 bits of the argument (every step of phi0 then sits on a cell edge
+// except fourteen: below x = 1 the reference compares the TRUNCATED fixed-point argument strictly, so those steps sit one integer above a power of two or a truncated power of
+// sqrt 2); the fourteen cells hold a NaN whose low bits index a second table of {threshold, value below, value above}, read only by the lanes that met one (a wavefront in three).
+// Built in round 4 and kept out because "some builds were not reproducible"; round 5 found the cause elsewhere (WR_LDS_BARRIER below) -- the 96- or 128-bit width of the second
+// read never mattered (the round-4 note about ds_read_b96 was wrong).  The second table is read as 16 bytes (measured equal to 12); the unused word passes through an empty asm.
+#ifdef WR_PHI0_T7_B96                                                        // (diagnosis: let the compiler narrow the read to ds_read_b96)
+#define T2_KEEP128(e) do { } while (0)
+#else
+#define T2_KEEP128(e) asm volatile("" :: "v"((e).w))
+#endif
+#if WR_PHI0_FORM == 4
+// (wenet_internal.h) one read; a wavefront in which some lane read a marked cell -- one in three -- settles those lanes with the threshold comparison of the earlier form.
+// NO rule for x >= 32768 / +Inf / +NaN here (the callers': phi0_dev below compares, the iterations know their arguments stay below)
+__device__ __forceinline__ float phi0_t7(int b, const uint4 *lut) {
+    const float *t1 = (const float *)lut;
+    const int k = min(max(b >> 16, WR_PHI0_T7_KLO), WR_PHI0_T7_KHI) - WR_PHI0_T7_KLO;
+    float v = t1[k];
+#ifdef WR_PHI0_T7_BRANCHFREE                                                 // (diagnosis: every lane reads the second table)
+    {
+        const bool mk = v != v;
+        const uint4 e = ((const uint4 *)((const char *)lut + WR_PHI0_T7_BYTES))[mk ? (__float_as_uint(v) & 15u) : 0u];
+        T2_KEEP128(e);
+        const float w = __uint_as_float(b >= (int)e.x ? e.z : e.y);
+        v = mk ? w : v;
+    }
+#else
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(v != v) != 0ull, 0)) {
+        if (v != v) {
+            const uint4 e = ((const uint4 *)((const char *)lut + WR_PHI0_T7_BYTES))[__float_as_uint(v) & 15u];
+            T2_KEEP128(e);
+            v = __uint_as_float(b >= (int)e.x ? e.z : e.y);
+        }
+    }
+#endif
+    return v;
+}
+__device__ __forceinline__ float phi0_dev(float xf, const uint4 *lut) {     // the whole function (phi0.c:13-218 with x86 cast semantics)
+    const int b = __float_as_int(xf);
+    const float v = phi0_t7(b, lut);
+    return b >= WR_PHI0_BIG_BITS ? 10.0f : v;
+}
+// inside the iterations: `big` (wave-uniform, per packet) says whether an argument >= 32768 is possible at all
+__device__ __forceinline__ float phi0_iter(float xf, const uint4 *lut, bool big) {
+    const int b = __float_as_int(xf);
+    float v = phi0_t7(b, lut);
+    if (__builtin_expect(big, 0)) v = b >= WR_PHI0_BIG_BITS ? 10.0f : v;
+    return v;
+}
+// N evaluations with their table reads in flight TOGETHER (one LDS round trip instead of N: a result costs one register, so the batch fits the 64-register budget the
+// three-word results of the earlier form did not), one test for marked cells over the batch
+template <int N>
+__device__ __forceinline__ void phi0_iter_n(const float (&x)[N], float (&v)[N], const uint4 *lut, bool big) {
+    const float *t1 = (const float *)lut;
+#pragma unroll
+    for (int j = 0; j < N; j++) v[j] = t1[min(max(__float_as_int(x[j]) >> 16, WR_PHI0_T7_KLO), WR_PHI0_T7_KHI) - WR_PHI0_T7_KLO];
+    bool mk = false;
+#pragma unroll
+    for (int j = 0; j < N; j++) mk = mk || (v[j] != v[j]);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(mk) != 0ull, 0)) {
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            if (v[j] != v[j]) {
+                const uint4 e = ((const uint4 *)((const char *)lut + WR_PHI0_T7_BYTES))[__float_as_uint(v[j]) & 15u];
+                T2_KEEP128(e);
+                v[j] = __uint_as_float(__float_as_int(x[j]) >= (int)e.x ? e.z : e.y);
+            }
+        }
+    }
+    if (__builtin_expect(big, 0)) {
+#pragma unroll
+        for (int j = 0; j < N; j++) v[j] = __float_as_int(x[j]) >= WR_PHI0_BIG_BITS ? 10.0f : v[j];
+    }
+}
+#endif
+#if WR_PHI0_FORM != 4
 __device__ __forceinline__ float phi0_dev(float xf, const uint4 *lut) {
     const int b = __float_as_int(xf);
     const int key = min(max(b >> 18, WR_PHI0_KEY_BIAS), WR_PHI0_KEY_BIAS + WR_PHI0_LUT_ENTRIES - 1) - WR_PHI0_KEY_BIAS;
@@ -131,6 +206,7 @@ __device__ __forceinline__ float phi0_dev(float xf, const uint4 *lut) {
     return b >= t ? v.y : v.x;
 #endif
 }
+#endif
 
 // the whole of wx_llr (x87emu.h) -- the integer emulation of the 80-bit product included -- as a real call: it is needed for one symbol in 2^29
 __device__ __attribute__((noinline)) float llr_exact(double estEsN0, double sd) { return wx_llr(estEsN0, sd); }
@@ -344,9 +420,13 @@ __global__ __launch_bounds__(256) void wenet_llr_stats_small_kernel(WrDecodeArgs
 }
 
 // CRC-16/CCITT-FALSE gate (drs232_ldpc.c:91-102, 243-254): byte-serial, one thread per packet
+// Agreement guard: the eight wavefronts of a packet's workgroup must have left the iteration loop at the same iteration of the same packet.  (Round 5: in some builds of the
+// decoder one wavefront in ~10^7 packets read another count from the workgroup's LDS cell than its seven siblings, stayed in the loop and decoded the next packet out of step --
+// tools/experiments/README.md.  Never seen in the product form; whatever the cause, a packet whose records differ is not trusted: it is listed and decoded again.)
 __global__ __launch_bounds__(256) void wenet_crc_kernel(WrDecodeArgs A) {
-    const long long slot = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (slot >= (long long)A.nchan * A.max_pk) return;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (A.redo_in ? (long long)A.redo_n : (long long)A.nchan * A.max_pk)) return;
+    const long long slot = A.redo_in ? (long long)A.redo_in[idx] : idx;
     const int ch = (int)(slot / A.max_pk), pk = (int)(slot - (long long)ch * A.max_pk);
     const long long npk = (A.input_kind == WR_DEC_IN_STREAM) ? A.dchans[ch].state->npackets : A.npk_direct[ch];
     if (pk >= npk) return;
@@ -366,6 +446,20 @@ __global__ __launch_bounds__(256) void wenet_crc_kernel(WrDecodeArgs A) {
         } else tail = v;
     }
     const unsigned tx = tail & 0xffffu;                 // packet[256] | packet[257] << 8
+    if (A.agree) {
+        // a record = a hash of every (count, flag) pair the wavefront read from the workgroup's cells during the packet, the slot it believed it decoded, the iteration at
+        // which it left: eight equal records = eight wavefronts that went through the packet in step
+        const unsigned want = A.agree[slot * (WR_DEC_THREADS / 64)];
+        bool same = (want & 0xffu) == (0x80u | ((unsigned)out->iter & 0x7fu));
+        for (int wv = 1; wv < WR_DEC_THREADS / 64; wv++) same = same && A.agree[slot * (WR_DEC_THREADS / 64) + wv] == want;
+        if (!same) {
+            for (int wv = 0; wv < WR_DEC_THREADS / 64; wv++) A.agree[slot * (WR_DEC_THREADS / 64) + wv] = 0u;
+            const unsigned at = atomicAdd(&A.redo[0], 1u);
+            if (at < WR_REDO_CAP) A.redo[1 + at] = (unsigned)slot;
+            out->crc_ok = 0; out->done = 2;               // (2: listed for another decode)
+            return;
+        }
+    }
     out->crc_ok = (uint8_t)(crc == tx);
     out->done = 1;
     if (A.census && crc == tx) {                        // what rx_ssdv.py:195-224 dispatches on, counted where the packet is
@@ -379,9 +473,39 @@ __global__ __launch_bounds__(256) void wenet_crc_kernel(WrDecodeArgs A) {
 // threads' variable placement once and then takes packet slots from a shared counter until none is left -- the per-packet set-up
 // (10 KB of table through L2, 18 edge addresses per thread) was a third of a packet's time at ~6 iterations.  (Round 1 tried a FIXED
 // four packets per workgroup: slower, because iteration counts differ; the counter has no such imbalance.)
+// A workgroup barrier that PUBLISHES LDS data: the wavefront's LDS stores have completed before it arrives.  hipcc 7.2's __syncthreads() is fence(release, workgroup, "local") +
+// s_barrier + fence(acquire): for an LDS-only fence the AMDGPU backend emits NO s_waitcnt in front of the s_barrier ("LDS operations for all waves are executed in a total global
+// ordering", SIMemoryLegalizer), so a store issued just before the barrier may still be in flight when another wavefront, released, reads the cell.  On gfx950 that read can
+// overtake the store (round 5, tools/experiments/README.md: thread 0's claim of the next packet slot on the empty-slot path -- ds_write_b32, s_branch, s_barrier -- was read
+// stale by the second or fourth wavefront of the workgroup about once in 10^6 packets; that wavefront then took another path through the barriers than its siblings and the
+// workgroup decoded out of step).  The wait is written out.
+#ifdef WR_DEC_CANARY
+#define WR_BARRIER_COUNT cn_bar++
+#else
+#define WR_BARRIER_COUNT (void)0
+#endif
+#define WR_LDS_BARRIER_W() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __syncthreads(); WR_BARRIER_COUNT; } while (0)
+#define WR_LDS_BARRIER_N() do { __syncthreads(); WR_BARRIER_COUNT; } while (0)
+#ifndef WR_DEC_LDS_WAIT_SITES                                             // (diagnosis: 3 = everywhere (product), 0 nowhere, 1 only the packet loop's top barrier, 2 everywhere but there)
+#define WR_DEC_LDS_WAIT_SITES 3
+#endif
+#if WR_DEC_LDS_WAIT_SITES & 2
+#define WR_LDS_BARRIER() WR_LDS_BARRIER_W()
+#else
+#define WR_LDS_BARRIER() WR_LDS_BARRIER_N()
+#endif
+#if WR_DEC_LDS_WAIT_SITES & 1
+#define WR_LDS_BARRIER_TOP() WR_LDS_BARRIER_W()
+#else
+#define WR_LDS_BARRIER_TOP() WR_LDS_BARRIER_N()
+#endif
 __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_decode_kernel(WrDecodeArgs A) {      // (8 waves per SIMD = four workgroups per CU: 64 VGPRs)
     const int tid = threadIdx.x;
+#ifdef WR_DEC_STATIC_LDS                                                   // (diagnosis: the block as a static array -- addresses fold into the instructions)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[WR_DEC_LDS_BYTES];
+#else
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#endif
     // float msg[14*516] | uint4 lut[642] | bit/byte staging
     float    *msg  = (float *)smem;
     uint4    *lut  = (uint4 *)(smem + WR_DEC_OFF_LUT);
@@ -391,15 +515,20 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
     // decoded (thread 0: the atomic at the packet's start, its value into LDS behind the last iteration), so the atomic's latency is not on a packet's path.
     int *claim = (int *)(smem + WR_DEC_OFF_CLAIM);                                 // [2] (plain LDS words: the workgroup barriers order them)
     const long long nslots = (long long)A.nchan * A.max_pk;
+    const long long nwork = A.redo_in ? (long long)A.redo_n : nslots;                 // work items: every slot, or (a repeat launch of the agreement guard) the listed ones
     // ---- once per workgroup: phi0 LUT into LDS; this thread's variables (LdpcTables::place_variables: the data variables are dealt
     //      to the positions tid + 512 t so that the variable pass loads the LDS banks evenly) and their edge addresses into registers.
     //      Positions t = 0..3 hold data bits (degree 3) for every thread; t = 4 straddles the data/parity boundary, t = 5 is parity or nothing.
+#if WR_PHI0_FORM == 4
+    for (int i = tid; i < WR_PHI0_LDS_BYTES / 16; i += WR_DEC_THREADS) lut[i] = A.phi0_lut[i];
+#else
     for (int i = tid; i < WR_PHI0_LUT_ENTRIES; i += WR_DEC_THREADS) {
         const uint4 e = A.phi0_lut[i];
         int *thr = (int *)lut;
         unsigned *val = (unsigned *)(thr + WR_PHI0_LUT_ENTRIES + 2);
         thr[i] = (int)e.x; val[2 * i] = e.y; val[2 * i + 1] = e.z;
     }
+#endif
 
     int ea[WR_VARS_PER_THREAD][3], deg[WR_VARS_PER_THREAD];
     // (the variable numbers themselves are needed twice per packet only -- LLR in, bit out -- and are re-read there: six registers
@@ -436,7 +565,7 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
             soff[t >> 1] |= o << (16 * (t & 1));
         }
     }
-    if (tid == 0) { const unsigned s0 = atomicAdd(A.work, 1u); claim[0] = (long long)s0 < nslots ? (int)s0 : -1; }     // the first packet: taken here, synchronously
+    if (tid == 0) { const unsigned s0 = atomicAdd(A.work, 1u); claim[0] = (long long)s0 < nwork ? (A.redo_in ? (int)A.redo_in[s0] : (int)s0) : -1; }     // the first packet: taken here, synchronously
     int cur = 0;
 
 #ifdef WR_DEC_STAMPS
@@ -445,18 +574,31 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
 #else
 #define DSTAMP(k) do { } while (0)
 #endif
+#ifdef WR_DEC_CANARY
+    // development (tools/gpu_repro.py --canary): every wavefront leaves a record per packet -- where it ran, which slot it believed it was decoding, at which iteration it
+    // left the loop and how many workgroup barriers it passed -- so that the host can tell a wavefront that went out of step from one that computed something else
+    unsigned cn_bar = 0, cn_seq = 0;
+#endif
+  int inj_seq = 0;
   for (;; cur ^= 1) {
-    __syncthreads();
+    WR_LDS_BARRIER_TOP();
+    inj_seq++;
+#ifdef WR_DEC_CANARY
+    cn_bar = 0;
+#if WR_DEC_CANARY == 3 || WR_DEC_CANARY == 4 || defined(WR_DEC_ASMCMP)
+    unsigned long long cn_hist = 0, cn_dmask = 0, cn_amask = 0; unsigned cn_any = 0;
+#endif
+#endif
 #ifdef WR_DEC_STAMPS
     if (st_t) DSTAMP(5);                                                           // [5] end of the previous packet -> everyone at the top
     st_t = (long long)__builtin_readcyclecounter();
 #endif                                                               // (the previous packet's staging is read out; LUT and this packet's claim are in place)
     const int slot_i = __builtin_amdgcn_readfirstlane(claim[cur]);
-    if (slot_i < 0) break;
+    if (slot_i < 0 || (long long)slot_i >= nslots) break;                // (>= nslots: never written by thread 0 -- a wavefront that reads that is better gone; the agreement guard lists what it leaves undone)
     const long long slot = slot_i;
     unsigned nxt = 0;
     if (tid == 0) nxt = atomicAdd(A.work, 1u);                                     // the NEXT packet's slot: the value is not waited for here
-    auto put_claim = [&]() __attribute__((always_inline)) { if (tid == 0) claim[cur ^ 1] = (long long)nxt < nslots ? (int)nxt : -1; };
+    auto put_claim = [&]() __attribute__((always_inline)) { if (tid == 0) claim[cur ^ 1] = (long long)nxt < nwork ? (A.redo_in ? (int)A.redo_in[nxt] : (int)nxt) : -1; };
     // the slot's record from the statistics kernel -- where the packet's first stored symbol is (0: no packet in this slot) and its estEsN0: ONE load
     // (round 3: channel table -> deframer state -> start offset, three dependent ones)
     unsigned long long base = 0ull;
@@ -468,6 +610,9 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
         base = (unsigned long long)uni64((long long)A.pbase[slot]);
         estEsN0 = __longlong_as_double(uni64(__double_as_longlong(A.esn0[slot])));
     }
+#ifdef WR_DEC_WAIT_EMPTY_PATH                                                     // (diagnosis: the wait only where an empty slot's claim is written)
+    if (base == 0ull) { put_claim(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); continue; }
+#endif
     if (base == 0ull) { put_claim(); continue; }                                   // nothing in this slot
     const int n = (A.input_kind == WR_DEC_IN_SD64) ? A.n_sd : WR_NCODE;
 
@@ -529,11 +674,22 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
             }
         }
     }
+    // can a variable-pass argument of phi0 reach 32768 (where the reference's cast overflows: phi0.c:15)?  |Qi - r| <= |llr| + 40: not while every LLR of the packet is below
+    // 30 000 -- one wave-uniform flag per packet instead of a comparison per evaluation (a NaN or infinite LLR sets it)
+#if WR_PHI0_FORM == 4
+    bool big_llr;
+    {
+        bool bl = false;
+#pragma unroll
+        for (int t = 0; t < WR_VARS_PER_THREAD; t++) bl = bl || !(fabsf(llr[t]) < 30000.f);
+        big_llr = __builtin_amdgcn_ballot_w64(bl) != 0ull;
+    }
+#endif
     DSTAMP(0);                                                                     // [0] claim, record, symbol loads, LLRs
     if (A.stop_after_llr) { put_claim(); continue; }
 
     if (tid == 0) msg[13 * WR_NPAR] = 0.f;                      // check 0 has 13 edges: its 14th slot stays a neutral +0
-    __syncthreads();
+    WR_LDS_BARRIER();
 
     // ---- initial variable->check messages: phi0(|llr|), sign = llr<0 (mpdecode_core.c:353-359)
 #pragma unroll
@@ -543,16 +699,49 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
         for (int k = 0; k < 3; k++) if (t < WR_VARS_ALLDATA || k < deg[t]) msg[ea[t][k]] = m0;
     }
     if (tid < 4) red[tid] = 0;
-    __syncthreads();
+    WR_LDS_BARRIER();
 
     DSTAMP(1);                                                                     // [1] initial messages + two barriers
     const int wave_base4 = __builtin_amdgcn_readfirstlane((tid & ~63) * 4);     // byte offset of this wavefront's lane 0 in a row of the message array
     int result = A.max_iter, pcc = 0, pcc_written = 0;
+    unsigned seen = 0u;
+#ifdef WR_GUARD_DEBUG
+    unsigned seen2 = 0u;
+#endif
     unsigned bits = 0;                                          // bit t = hard decision of variable tid+t*512
     for (int iter = 0; iter < A.max_iter; iter++) {
         // ---- update r: thread = check (mpdecode_core.c:414-436).  All 14 slots are processed for every check:
         //      the phantom 14th edge of check 0 adds +0.0 LAST to phi_sum (no change) and contributes no sign.
         int ok = 0;
+#if defined(WR_DEC_CANARY) && WR_DEC_CANARY == 10                 // (far from the decision: the cell of the previous iteration is still intact here -- read it AGAIN and compare with what was carried)
+        if (iter > 0 && pcc_written) {
+            const int again = red[((iter - 1) & 1) * 2 + 0];
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(pcc != again);
+            if (m != 0ull && A.dbg) {
+                unsigned *r = (unsigned *)A.dbg + (size_t)nslots * 64 + ((size_t)slot * 8 + (tid >> 6)) * 80;
+                if ((tid & 63) == 0) { r[64] = (unsigned)m; r[65] = (unsigned)(m >> 32); r[66] = (unsigned)iter; r[67] = 0xAAAAu; r[68] = (unsigned)pcc; r[69] = (unsigned)again; r[70] = (unsigned)red[((iter - 1) & 1) * 2 + 1]; r[71] = (unsigned)red[(iter & 1) * 2 + 0]; }
+            }
+        }
+#endif
+#if defined(WR_DEC_CANARY) && WR_DEC_CANARY == 9                  // (far from the decision: the carried count into an LDS history, copied out with the packet's record)
+        if (iter > 0 && (tid & 63) == 0) ((unsigned *)(smem + WR_DEC_LDS_BYTES))[(tid >> 6) * 10 + iter] = (unsigned)pcc | ((unsigned)pcc_written << 16) | 0x80000000u;
+#endif
+#if defined(WR_DEC_CANARY) && WR_DEC_CANARY == 8                  // (far from the decision: the count every wavefront carried out of the previous iteration)
+        if (iter > 0 && A.dbg && (tid & 63) == 0) {
+            unsigned *r = (unsigned *)A.dbg + (size_t)nslots * 64 + ((size_t)slot * 8 + (tid >> 6)) * 80;
+            r[iter] = (unsigned)pcc | ((unsigned)pcc_written << 16) | 0x80000000u;
+        }
+#endif
+#if defined(WR_DEC_CANARY) && WR_DEC_CANARY == 7                  // (far from the decision: a wavefront that went on although its count, as carried in pcc, says 516 on some or all lanes)
+        if (iter > 0 && pcc_written) {
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(pcc != WR_NPAR);
+            if (m != ~0ull && A.dbg) {
+                unsigned *r = (unsigned *)A.dbg + (size_t)nslots * 64 + ((size_t)slot * 8 + (tid >> 6)) * 80;
+                r[tid & 63] = (unsigned)pcc;
+                if ((tid & 63) == 0) { r[64] = (unsigned)m; r[65] = (unsigned)(m >> 32); r[66] = (unsigned)iter; r[67] = 0x7777u; }
+            }
+        }
+#endif
 #pragma unroll
         for (int cj = 0; cj < WR_DEC_CHECKS_PER_THREAD; cj++) {
             const int chk = tid + cj * WR_DEC_THREADS;          // the whole checks: one per thread (512 threads; two with -DWR_DEC_THREADS=256)
@@ -570,6 +759,36 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
 #pragma unroll
             for (int k = 1; k < 14; k++) phi_sum = phi_sum + fabsf(mr[k]);
             ok += (par_bit == 0) ? 1 : 0;
+#if WR_PHI0_FORM == 4
+#ifndef WR_DEC_CHK_BATCH
+#define WR_DEC_CHK_BATCH 2                  // (measured 1 / 2 / 3 / 4 / 7 with the three of a variable together: 10.92 / 10.85 / 10.98 / slower / slower ms per 244 k packets)
+#endif
+#ifndef WR_ADDTID_PRE
+#define WR_ADDTID_PRE ""
+#endif
+#pragma unroll
+            for (int k0 = 0; k0 < 14; k0 += WR_DEC_CHK_BATCH) {
+              float xa[WR_DEC_CHK_BATCH], ra[WR_DEC_CHK_BATCH];
+#pragma unroll
+              for (int j = 0; j < WR_DEC_CHK_BATCH; j++) xa[j] = phi_sum - fabsf(mr[k0 + j < 14 ? k0 + j : 13]);    // (a sum of table values minus one of them: 0 .. 140)
+              phi0_iter_n<WR_DEC_CHK_BATCH>(xa, ra, lut, false);
+#pragma unroll
+              for (int j = 0; j < WR_DEC_CHK_BATCH; j++) {
+                const int k = k0 + j;
+                if (k >= 14) continue;
+                const float r = ra[j];
+                const float rs = __uint_as_float(__float_as_uint(r) | ((__float_as_uint(mr[k]) ^ par_bit) & 0x80000000u));
+#ifndef WR_DEC_NO_ADDTID
+                // the check pass stores lane-linearly (check = thread): ds_write_addtid_b32 -- address = M0 + offset + 4 lane, no address register -- costs the LDS
+                // two cycles where ds_write_b32 costs four (the address VGPR's transfer).  (s_nop: a write of M0 needs a wait state before an add-TID LDS instruction, and
+                // the compiler's hazard recogniser does not look into an asm block)
+                asm volatile(WR_ADDTID_PRE "s_mov_b32 m0, %1\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:%2" : : "v"(rs), "s"(wave_base4 + cj * WR_DEC_THREADS * 4), "n"(k * WR_NPAR * 4) : "memory", "m0");
+#else
+                msg[k * WR_NPAR + chk] = rs;
+#endif
+              }
+            }
+#else
 #pragma unroll
             for (int k = 0; k < 14; k++) {
                 const float r = phi0_dev(phi_sum - fabsf(mr[k]), lut);
@@ -583,6 +802,7 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
                 msg[k * WR_NPAR + chk] = rs;
 #endif
             }
+#endif
             if (chk == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); msg[13 * WR_NPAR] = 0.f; }
         }
         // checks 512..515: not a second trip of four lanes through the whole pass (it would make one wavefront the straggler of every
@@ -601,7 +821,11 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
             const unsigned par_bit = px & 0x80000000u;
             if (k == 0) ok += (par_bit == 0) ? 1 : 0;
             const float mine = msg[k * WR_NPAR + chk];
+            #if WR_PHI0_FORM == 4
+            const float r = phi0_iter(phi_sum - fabsf(mine), lut, false);
+#else
             const float r = phi0_dev(phi_sum - fabsf(mine), lut);
+#endif
             msg[k * WR_NPAR + chk] = __uint_as_float(__float_as_uint(r) | ((__float_as_uint(mine) ^ par_bit) & 0x80000000u));
         }
         // Two workgroup barriers per iteration (check pass | variable pass); the two counts ride on them: every wave adds its ballot
@@ -617,9 +841,20 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
         // only if some LDS access of its own happens to be pending there (it is, today) -- the barrier's wait is therefore written out
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
-        __syncthreads();
+        WR_LDS_BARRIER();
+#if defined(WR_DEC_FIX) && WR_DEC_FIX == 2                          // (diagnosis: the count is read behind the SECOND barrier, next to the flag -- not held in a register through the variable pass)
+        if (tid == 0) { red[(par ^ 1) * 2 + 0] = 0; red[(par ^ 1) * 2 + 1] = 0; }
+#elif defined(WR_DEC_FIX) && WR_DEC_FIX == 1                        // (diagnosis: the decision on lane 0's copy)
+        const int ssum = __builtin_amdgcn_readfirstlane(red[par * 2 + 0]);
+        if (tid == 0) { red[(par ^ 1) * 2 + 0] = 0; red[(par ^ 1) * 2 + 1] = 0; }
+#elif defined(WR_DEC_PIN_V1)                                          // (diagnosis: the count held in v1, as in the builds that deviate)
+        int ssum = red[par * 2 + 0];
+        asm volatile("; ssum in %0" : "+{v1}"(ssum));
+        if (tid == 0) { red[(par ^ 1) * 2 + 0] = 0; red[(par ^ 1) * 2 + 1] = 0; }
+#else
         const int ssum = red[par * 2 + 0];
         if (tid == 0) { red[(par ^ 1) * 2 + 0] = 0; red[(par ^ 1) * 2 + 1] = 0; }
+#endif
         // ---- update q: thread = variable (mpdecode_core.c:439-464) ---------------------------
         int any_data = 0;
         bits = 0;
@@ -638,23 +873,106 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
                 const int b = Qi < 0.f;
                 bits |= (unsigned)b << t;
                 if (b && (t < WR_VARS_ALLDATA || (t == WR_VARS_ALLDATA && data4))) any_data = 1;
+#if WR_PHI0_FORM == 4 && !defined(WR_DEC_NO_VAR_BATCH)
+                {
+                    float ts[3], xa[3], ma[3];
+#pragma unroll
+                    for (int k = 0; k < 3; k++) { ts[k] = Qi - cm[k]; xa[k] = fabsf(ts[k]); }
+                    phi0_iter_n<3>(xa, ma, lut, big_llr);
+#pragma unroll
+                    for (int k = 0; k < 3; k++) if (t < WR_VARS_ALLDATA || k < deg[t]) msg[ea[t][k]] = with_sign(ma[k], !(ts[k] > 0.f));
+                }
+#else
 #pragma unroll
                 for (int k = 0; k < 3; k++) {
                     if (t < WR_VARS_ALLDATA || k < deg[t]) {
                         const float temp_sum = Qi - cm[k];
+#if WR_PHI0_FORM == 4
+                        const float mag = phi0_iter(fabsf(temp_sum), lut, big_llr);
+#else
                         const float mag = phi0_dev(fabsf(temp_sum), lut);
+#endif
                         msg[ea[t][k]] = with_sign(mag, !(temp_sum > 0.f));
                     }
                 }
+#endif
             }
         }
         if (__ballot(any_data) && (tid & 63) == 0) red[par * 2 + 1] = 1;
-        __syncthreads();
+        WR_LDS_BARRIER();
         const int any = red[par * 2 + 1];
+#ifdef WR_DEC_PIN_V1
+        asm volatile("; ssum still in %0" : "+{v1}"(ssum));
+#endif
+#if defined(WR_DEC_FIX) && WR_DEC_FIX == 2
+        const int ssum = red[par * 2 + 0];
+#endif
+#if defined(WR_DEC_CANARY) && WR_DEC_CANARY == 6                  // (cold path only: when SOME lanes of the wavefront hold another count than the others, every lane writes down what it holds)
+        {
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(ssum != WR_NPAR);
+            if (m != 0ull && m != ~0ull && A.dbg) {
+                unsigned *r = (unsigned *)A.dbg + (size_t)nslots * 64 + ((size_t)slot * 8 + (tid >> 6)) * 80;
+                r[tid & 63] = (unsigned)ssum;
+                if ((tid & 63) == 0) { r[64] = (unsigned)m; r[65] = (unsigned)(m >> 32); r[66] = (unsigned)iter + 1u; r[67] = (unsigned)any; }
+            }
+        }
+#endif
+#if defined(WR_DEC_CANARY) && WR_DEC_CANARY == 4                  // (lightest: only scalar work on the comparison the loop makes anyway)
+        {
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(ssum != WR_NPAR), ma = __builtin_amdgcn_ballot_w64(any != 0);
+            if (m != 0ull && m != ~0ull) { cn_dmask = m; cn_any = (unsigned)iter + 1u; }
+            if (ma != 0ull && ma != ~0ull) { cn_amask = ma; cn_hist = (unsigned long long)iter + 1ull; }
+        }
+#endif
+#if defined(WR_DEC_CANARY) && WR_DEC_CANARY == 3                  // (lighter: the history stays in scalar registers until the packet's record is written)
+        {
+            const int s0 = __builtin_amdgcn_readfirstlane(ssum);
+            cn_hist = (cn_hist << 10) | (unsigned long long)(s0 & 0x3ff);
+            cn_dmask |= __builtin_amdgcn_ballot_w64(ssum != s0);
+            cn_any = (cn_any << 1) | (unsigned)(__builtin_amdgcn_readfirstlane(any) != 0);
+            cn_amask |= __builtin_amdgcn_ballot_w64(any != __builtin_amdgcn_readfirstlane(any));
+        }
+#endif
+#if defined(WR_DEC_CANARY) && WR_DEC_CANARY == 2
+        if (A.dbg && iter < 10) {                                // what this wavefront saw when it decided: the two cells as lane 0 read them, the lanes that read something else
+            const int s0 = __builtin_amdgcn_readfirstlane(ssum), a0 = __builtin_amdgcn_readfirstlane(any);
+            const unsigned long long ds = __builtin_amdgcn_ballot_w64(ssum != s0), da = __builtin_amdgcn_ballot_w64(any != a0), ex = __builtin_amdgcn_ballot_w64(true);
+            if ((tid & 63) == 0) {
+                unsigned *r = (unsigned *)A.dbg + (size_t)nslots * 64 + (((size_t)slot * 8 + (tid >> 6)) * 10 + iter) * 8;
+                r[0] = (unsigned)s0 | 0x80000000u; r[1] = (unsigned)ds; r[2] = (unsigned)(ds >> 32); r[3] = (unsigned)a0; r[4] = (unsigned)da; r[5] = (unsigned)(da >> 32);
+                r[6] = (unsigned)ex; r[7] = (unsigned)(ex >> 32);
+            }
+        }
+#endif
+        seen = seen * 33u + (unsigned)ssum * 2u + (unsigned)(any != 0);          // agreement guard: what this wavefront read, iteration by iteration
+#ifdef WR_GUARD_DEBUG                                                     // (development: one more word per wavefront -- the sum of the counts it read, in front of how many flags were set)
+        seen2 += (unsigned)ssum + ((unsigned)(any != 0) << 20);
+#endif
+#if defined(WR_DEC_CANARY) && WR_DEC_CANARY == 12                         // (development: the pairs themselves, per wavefront, copied out with the packet's record)
+        if ((tid & 63) == 0 && iter < 10) ((unsigned *)(smem + WR_DEC_LDS_BYTES))[(tid >> 6) * 10 + iter] = (unsigned)ssum | ((unsigned)(any != 0) << 16) | 0x80000000u | ((__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) & 0x3fu) << 20);
+#endif
         // ---- stop rules (mpdecode_core.c:466-483) --------------------------------------------
         if (!any) { result = iter + 1; break; }                 // "zero bit errors" against the all-zero data[]
         pcc = ssum; pcc_written = 1;
-        if (ssum == WR_NPAR) { result = iter + 1; break; }
+#ifdef WR_DEC_ASMCMP                                                     // (diagnosis: the comparison as written-out instructions, with or without wait states behind it)
+        {
+            unsigned long long ne;
+#if WR_DEC_ASMCMP == 3                                                   // (and the count as lane 0 holds it into a scalar history: six iterations x 10 bits)
+            unsigned t32, h0 = (unsigned)cn_hist, h1 = (unsigned)(cn_hist >> 32);
+            asm volatile("v_cmp_ne_u32_e64 %0, %4, %5\n\ts_lshl_b32 %2, %2, 10\n\ts_lshr_b32 %3, %1, 20\n\ts_or_b32 %2, %2, %3\n\ts_lshl_b32 %1, %1, 10\n\ts_and_b32 %1, %1, 0x3fffffff\n\t"
+                         "v_readfirstlane_b32 %3, %5\n\ts_and_b32 %3, %3, 0x3ff\n\ts_or_b32 %1, %1, %3"
+                         : "=s"(ne), "+s"(h0), "+s"(h1), "=&s"(t32) : "s"(WR_NPAR), "v"(ssum));
+            cn_hist = ((unsigned long long)h1 << 32) | h0;
+#elif WR_DEC_ASMCMP == 1
+            asm volatile("v_cmp_ne_u32_e64 %0, %1, %2" : "=s"(ne) : "s"(WR_NPAR), "v"(ssum));
+#else
+            asm volatile("v_cmp_ne_u32_e64 %0, %1, %2\n\ts_nop 7\n\ts_nop 7" : "=s"(ne) : "s"(WR_NPAR), "v"(ssum));
+#endif
+            if (ne == 0ull) { result = iter + 1; break; }
+        }
+#else
+        if (ssum == WR_NPAR && !(A.dbg_inject && (tid >> 6) == 3 && inj_seq == A.dbg_inject)) { result = iter + 1; break; }     // (dbg_inject: tests of the agreement guard)
+#endif
     }
 
     DSTAMP(2);                                                      // [2] the iterations
@@ -667,7 +985,7 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
     continue;
 #endif
     // ---- pack MSB-first, CRC-16/CCITT-FALSE gate (drs232_ldpc.c:234-257) ----------------------
-    __syncthreads();
+    WR_LDS_BARRIER();
 #pragma unroll
     for (int t = 0; t < WR_VARS_PER_THREAD; t++) {
         const int v = var_at(t);
@@ -676,7 +994,7 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
             if (A.bits_out) A.bits_out[(long long)slot * WR_NCODE + v] = (uint8_t)((bits >> t) & 1u);
         }
     }
-    __syncthreads();
+    WR_LDS_BARRIER();
     uint8_t *bytes = bitbuf + 2592;
     for (int bi = tid; bi < 258; bi += WR_DEC_THREADS) {
         unsigned a = 0;
@@ -690,7 +1008,43 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
         out->pcc = pcc;
         out->pcc_written = pcc_written;
     }
+#ifdef WR_GUARD_DEBUG
+    if ((tid & 63) == 0 && A.dbg) {
+        unsigned *g2 = (unsigned *)A.dbg + ((size_t)slot * 8 + (tid >> 6)) * 4;
+        g2[0] = seen2 | 0x80000000u; g2[1] = (unsigned)result | ((unsigned)pcc << 8); g2[2] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)); g2[3] = (unsigned)__builtin_readcyclecounter();
+    }
+#endif
+    if ((tid & 63) == 0 && A.agree) A.agree[slot * (WR_DEC_THREADS / 64) + (tid >> 6)] = (((seen * 0x9E3779B1u) ^ ((unsigned)slot_i << 8)) & 0xffffff00u) | 0x80u | ((unsigned)result & 0x7fu);      // agreement guard (wenet_crc_kernel)
+#ifdef WR_DEC_CANARY
+    if ((tid & 63) == 0 && A.dbg) {
+        unsigned *rec = (unsigned *)A.dbg + ((size_t)slot * 8 + (tid >> 6)) * 8;
+        rec[0] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));       // HW_REG_HW_ID
+        rec[1] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));      // HW_REG_XCC_ID
+        rec[2] = (unsigned)slot_i; rec[3] = (unsigned)result; rec[4] = cn_bar; rec[5] = (blockIdx.x << 12) | (cn_seq & 0xfffu);
+#if defined(WR_DEC_ASMCMP) && WR_DEC_ASMCMP == 3
+        rec[6] = (unsigned)cn_hist; rec[7] = (unsigned)(cn_hist >> 32);
+#else
+        rec[6] = (unsigned)pcc; rec[7] = (unsigned)__builtin_readcyclecounter();
+#endif
+#if WR_DEC_CANARY == 12
+        { unsigned *r9 = (unsigned *)A.dbg + (size_t)nslots * 64 + ((size_t)slot * 8 + (tid >> 6)) * 80; unsigned *h9 = (unsigned *)(smem + WR_DEC_LDS_BYTES) + (tid >> 6) * 10;
+          for (int q = 0; q < 10; q++) { r9[q] = h9[q]; h9[q] = 0u; } r9[10] = (unsigned)__builtin_readcyclecounter(); }
+#endif
+#if WR_DEC_CANARY == 9
+        { unsigned *r9 = (unsigned *)A.dbg + (size_t)nslots * 64 + ((size_t)slot * 8 + (tid >> 6)) * 80; unsigned *h9 = (unsigned *)(smem + WR_DEC_LDS_BYTES) + (tid >> 6) * 10;
+          for (int q = 1; q < 10; q++) { r9[q] = h9[q]; h9[q] = 0u; } }
+#endif
+#if WR_DEC_CANARY == 3 || WR_DEC_CANARY == 4
+        unsigned *r = (unsigned *)A.dbg + (size_t)nslots * 64 + ((size_t)slot * 8 + (tid >> 6)) * 80;
+        r[0] = (unsigned)cn_hist; r[1] = (unsigned)(cn_hist >> 32); r[2] = (unsigned)cn_dmask; r[3] = (unsigned)(cn_dmask >> 32); r[4] = cn_any; r[5] = (unsigned)cn_amask; r[6] = (unsigned)(cn_amask >> 32);
+#endif
+    }
+    cn_seq++;
+#endif
     DSTAMP(3);                                              // [3] bits -> bytes -> packet slot
+#ifdef WR_DEC_WAIT_EPILOGUE                                                         // (diagnosis: the wait only behind the byte staging's stores)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
   }
 #ifdef WR_DEC_STAMPS
   if (tid == 0 && A.dbg) for (int k = 0; k < 8; k++) atomicAdd((unsigned long long *)&A.dbg[k], (unsigned long long)st_acc[k]);
@@ -701,13 +1055,17 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
 
 // self-test entry (wenet_phi0_eval, include/wenet_rx.h): the device phi0 of the decoder on n arguments, through the same LDS tables
 __global__ __launch_bounds__(256) void wenet_phi0_kernel(const uint4 *lut_g, const float *x, float *y, long long n) {
-    __shared__ __attribute__((aligned(16))) uint4 lut[WR_PHI0_LUT_ENTRIES];
+    __shared__ __attribute__((aligned(16))) uint4 lut[WR_PHI0_LDS_BYTES / 16];
+#if WR_PHI0_FORM == 4
+    for (int i = threadIdx.x; i < WR_PHI0_LDS_BYTES / 16; i += 256) lut[i] = lut_g[i];
+#else
     for (int i = threadIdx.x; i < WR_PHI0_LUT_ENTRIES; i += 256) {
         const uint4 e = lut_g[i];
         int *thr = (int *)lut;
         unsigned *val = (unsigned *)(thr + WR_PHI0_LUT_ENTRIES + 2);
         thr[i] = (int)e.x; val[2 * i] = e.y; val[2 * i + 1] = e.z;
     }
+#endif
     __syncthreads();
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] = phi0_dev(x[i], lut);
 }
@@ -727,7 +1085,6 @@ extern "C" hipError_t wr_launch_deframe(const WrDeframeChan *d_chans, int nchan,
 extern "C" hipError_t wr_launch_decode(const WrDecodeArgs *args, hipStream_t stream) {
     if (args->nchan <= 0 || args->max_pk <= 0) return hipSuccess;
     const long long slots = (long long)args->nchan * args->max_pk;
-    const unsigned blocks = (unsigned)((slots + 255) / 256);
     if (args->input_kind != WR_DEC_IN_LLR && args->phase != 2)
     {
         const char *ev = getenv("WENET_RX_SMALL_STATS_SLOTS");                                  // (tests: 0 = the one-lane-per-packet kernel for every batch)
@@ -742,16 +1099,57 @@ extern "C" hipError_t wr_launch_decode(const WrDecodeArgs *args, hipStream_t str
         }
     }
     if (args->phase == 1) return hipGetLastError();
+#ifdef WR_DEC_STATIC_LDS
+    const int lds = 0;
+#else
+#if defined(WR_DEC_CANARY) && (WR_DEC_CANARY == 9 || WR_DEC_CANARY == 12)
+    const int lds = WR_DEC_LDS_BYTES + 320;
+#else
     const int lds = WR_DEC_LDS_BYTES;
+#endif
     wr_attr_ok(hipFuncSetAttribute((const void *)wenet_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+#endif
     static int ncu = 0;
     if (ncu == 0) { hipDeviceProp_t p; int dev = 0; (void)hipGetDevice(&dev); ncu = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }
     const long long want = (long long)4 * ncu;                       // four workgroups (32 wavefronts) per CU fill it; they loop over the packet slots
     const unsigned grid = (unsigned)(slots < want ? slots : want);
     hipError_t e = hipMemsetAsync(args->work, 0, sizeof(unsigned), stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(wenet_decode_kernel, dim3(grid), dim3(WR_DEC_THREADS), lds, stream, *args);
+    if (args->agree && !args->redo_in) {                             // agreement guard: no records, no packets listed (a repeat launch: the CRC kernel cleared the listed packets' records)
+        e = hipMemsetAsync(args->agree, 0, (size_t)slots * (WR_DEC_THREADS / 64) * sizeof(unsigned), stream);
+        if (e == hipSuccess) e = hipMemsetAsync(args->redo, 0, sizeof(unsigned), stream);
+        if (e != hipSuccess) return e;
+    }
+    const long long items = args->redo_in ? (long long)args->redo_n : slots;
+    hipLaunchKernelGGL(wenet_decode_kernel, dim3((unsigned)(items < (long long)grid ? items : (long long)grid)), dim3(WR_DEC_THREADS), lds, stream, *args);
     if (!args->stop_after_llr && args->out)
-        hipLaunchKernelGGL(wenet_crc_kernel, dim3(blocks), dim3(256), 0, stream, *args);
+        hipLaunchKernelGGL(wenet_crc_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream, *args);
     return hipGetLastError();
+}
+
+// Agreement guard, host side: after the launch(es) of `args` have FINISHED -- how many packets did the CRC kernel list, and decode them again until none is listed.
+// Returns the number of packets that were decoded again (0 in every run seen with the product form), < 0 on errors (-5: no agreement after four rounds).
+extern "C" int wr_decode_settle(const WrDecodeArgs *args, hipStream_t stream) {
+    if (!args->agree || !args->redo || args->stop_after_llr || !args->out) return 0;
+    if (getenv("WENET_RX_NO_SETTLE")) return 0;                      // development: listed packets stay as they are (done == 2)
+    int total = 0;
+    for (int round = 0; round < 4; round++) {
+        unsigned count = 0;
+        if (hipMemcpyAsync(&count, args->redo, sizeof(unsigned), hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) return -3;
+        if (count == 0) return total;
+        total += (int)count;
+        WrDecodeArgs r = *args;
+        r.phase = 2;                                                 // (the statistics stand)
+        r.dbg_inject = 0;
+        unsigned *list = args->redo + 1024;                          // the second list of the scratch block
+        if (count > WR_REDO_CAP) return -6;                          // (more than a list holds: something else is wrong with this launch)
+        if (hipMemcpyAsync(list, args->redo + 1, count * sizeof(unsigned), hipMemcpyDeviceToDevice, stream) != hipSuccess) return -3;
+        r.redo_in = list; r.redo_n = (int)count;
+        if (hipMemsetAsync(args->redo, 0, sizeof(unsigned), stream) != hipSuccess) return -3;
+        const hipError_t e = wr_launch_decode(&r, stream);
+        if (e != hipSuccess) return -4;
+    }
+    unsigned count = 0;
+    if (hipMemcpyAsync(&count, args->redo, sizeof(unsigned), hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) return -3;
+    return count == 0 ? total : -5;
 }

@@ -227,8 +227,10 @@ struct WrPacketOut {            // one per packet slot
 };
 
 enum { WR_DEC_IN_STREAM = 0, WR_DEC_IN_SD64 = 1, WR_DEC_IN_LLR = 2 };
-// per-launch scratch of the decoder behind one allocation: estEsN0[nslots] | 4096 bytes of work counters | packet addresses [nslots]
-static inline size_t wr_dec_scratch_bytes(size_t nslots) { return nslots * 16 + 4096; }
+// per-launch scratch of the decoder behind one allocation: estEsN0[nslots] | 4096 bytes of work counters | packet addresses [nslots] | the wavefronts' exit records
+// [nslots][8] | two lists of packet slots to decode again (the one the CRC kernel fills, the one a repeat launch reads)
+#define WR_REDO_CAP 1023                                            // slots per list (+ the count in front: 4 KB)
+static inline size_t wr_dec_scratch_bytes(size_t nslots) { return nslots * 48 + 4096 + 2 * 4096; }
 // packet type classes (first payload byte, rx/WenetPackets.py:28-35): 0x00 text, 0x01 GPS, 0x02 orientation,
 // 0x03 secondary payload, 0x54 image telemetry, 0x55 SSDV, 0x56 idle, anything else
 #define WR_CENSUS_CLASSES 8
@@ -262,6 +264,13 @@ struct WrDecodeArgs {
     int             phase;              // wr_launch_decode: 0 = everything, 1 = LLR statistics only, 2 = decode + CRC only (statistics done by an earlier call)
     const uint8_t  *scramble;           // [125]
     long long      *dbg;                // development (-DWR_DEC_STAMPS builds only): cycle totals of the decode kernel's per-packet phases
+    // the agreement guard (ldpc_kernel.hip "agreement guard"): every wavefront of a packet's workgroup leaves (slot << 8 | 0x80 | iteration at which it left the loop); the CRC
+    // kernel lists the packets whose eight records differ, and the host decodes those again (wr_decode_settle)
+    unsigned       *agree;              // [nchan*max_pk][8], or null: guard off
+    unsigned       *redo;               // [0]: packets listed, [1..WR_REDO_CAP]: their slots (the count goes on beyond the capacity: then every slot is decoded again)
+    const unsigned *redo_in;            // a repeat launch: the slots to decode (the work items), else null
+    int             redo_n;
+    int             dbg_inject;         // tests: wavefront 3 of every workgroup ignores the "all checks satisfied" stop of its (dbg_inject)-th packet (0 = off)
 };
 
 // ---- phi0 (reference src/phi0.c:13-218) as data ---------------------------------------------
@@ -297,9 +306,26 @@ static const float WR_PHI0_LT1_V[27] = {  // value when x > T[k] (and x <= T[k-1
                                                          // then moved by the exponent offset of the factor 2^16 (0x08000000 = 512 << 18), so the kernel reads
                                                          // the bits of xf itself: no multiply (exact for every xf whose y is a normal float; zero, denormals,
                                                          // negatives, Inf and NaN land in the two catch-all entries either way)
+// WR_PHI0_FORM 4 (the product since round 5; 1 = the two-read form of rounds 2-4): ONE 4-byte LDS read per evaluation, a second one only for the fourteen cells that hold a step (NaN markers -> second table)
+#define WR_PHI0_T7_CELLS 128
+#define WR_PHI0_T7_ENTRIES (WR_PHI0_BINADES * WR_PHI0_T7_CELLS + 2)
+#define WR_PHI0_T7_KLO ((0x37800000 >> 16) - 1)
+#define WR_PHI0_T7_KHI (WR_PHI0_T7_KLO + WR_PHI0_T7_ENTRIES - 1)
+#define WR_PHI0_T7_BYTES ((WR_PHI0_T7_ENTRIES * 4 + 15) & ~15)
+#define WR_PHI0_T7_SPECIALS 16
+#define WR_PHI0_T7_MARK 0x7fc00000u
+#define WR_PHI0_BIG_BITS 0x47000000
+#ifndef WR_PHI0_FORM
+#define WR_PHI0_FORM 4
+#endif
+#if WR_PHI0_FORM == 4
+#define WR_PHI0_LDS_BYTES (WR_PHI0_T7_BYTES + WR_PHI0_T7_SPECIALS * 16)
+#else
+#define WR_PHI0_LDS_BYTES (WR_PHI0_LUT_ENTRIES * 16)
+#endif
 // LDS carve-up of wenet_decode_kernel: float msg[14][516] | uint4 lut[] | bits[2592] + bytes[272]
 #define WR_DEC_OFF_LUT  (14 * WR_NPAR * 4)
 #define WR_DEC_OFF_BITS 0                                                   // bit / byte staging overlays the messages (dead after the last iteration)
-#define WR_DEC_OFF_RED  (WR_DEC_OFF_LUT + WR_PHI0_LUT_ENTRIES * 16)                 // [2][2] reduction cells: satisfied checks / any data bit set, by iteration parity
+#define WR_DEC_OFF_RED  (WR_DEC_OFF_LUT + WR_PHI0_LDS_BYTES)                 // [2][2] reduction cells: satisfied checks / any data bit set, by iteration parity
 #define WR_DEC_OFF_CLAIM (WR_DEC_OFF_RED + 16)                                       // [2] packet claims {slot, -, address (2 words), estEsN0 (2 words)}: this packet's and the next one's
 #define WR_DEC_LDS_BYTES (WR_DEC_OFF_CLAIM + 64)

@@ -14,6 +14,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <algorithm>
@@ -33,6 +34,7 @@ extern "C" hipError_t wr_launch_demod_oct(const WrDemodCfg *cfg, const WrChan *d
 extern "C" hipError_t wr_launch_demod_oct_sliced(const WrDemodCfg *cfg, WrChan *d_chans, int nchan, WrSliceCtl *d_ctl, int nslices, hipStream_t stream);
 extern "C" hipError_t wr_launch_deframe(const WrDeframeChan *d_chans, int nchan, int mode, hipStream_t stream);
 extern "C" hipError_t wr_launch_decode(const WrDecodeArgs *args, hipStream_t stream);
+extern "C" int wr_decode_settle(const WrDecodeArgs *args, hipStream_t stream);
 extern "C" hipError_t wr_launch_phi0(const uint4 *d_lut, const float *d_x, float *d_y, long long n, hipStream_t stream);
 
 #ifndef M_PI
@@ -468,12 +470,16 @@ struct LdpcTables {
         if (getenv("WENET_RX_PLACE_SEARCH") != nullptr || !ldpc_vpos_valid(vpos.data())) place_variables(vpos, bank, &place_cost0, &place_cost);
         if (getenv("WENET_RX_NO_PLACE")) for (int v = 0; v < WR_NCODE; v++) vpos[v] = (uint16_t)v;     // development: natural order
         std::vector<uint32_t> lut;
+#if WR_PHI0_FORM == 4
+        if (!phi0_build_t7(lut, false)) return false;
+#else
         if (!phi0_build_lut(lut, false)) return false;
-        size_t a_v = 0, a_l = (WR_NDATA * 3 * 2 + 255) & ~255, a_s = a_l + ((WR_PHI0_LUT_ENTRIES * 16 + 255) & ~255), a_p = a_s + 256;
+#endif
+        size_t a_v = 0, a_l = (WR_NDATA * 3 * 2 + 255) & ~255, a_s = a_l + ((WR_PHI0_LDS_BYTES + 255) & ~255), a_p = a_s + 256;
         if (!blob.reserve(a_p + WR_NCODE * 2 + 256)) return false;
         char *base = blob.as<char>();
         WR_CHECK(hipMemcpy(base + a_v, vedge.data(), WR_NDATA * 3 * 2, hipMemcpyHostToDevice), false);
-        WR_CHECK(hipMemcpy(base + a_l, lut.data(), WR_PHI0_LUT_ENTRIES * 16, hipMemcpyHostToDevice), false);
+        WR_CHECK(hipMemcpy(base + a_l, lut.data(), WR_PHI0_LDS_BYTES, hipMemcpyHostToDevice), false);
         WR_CHECK(hipMemcpy(base + a_s, kScramble, 125, hipMemcpyHostToDevice), false);
         WR_CHECK(hipMemcpy(base + a_p, vpos.data(), WR_NCODE * 2, hipMemcpyHostToDevice), false);
         d_vpos = (const uint16_t *)(base + a_p);
@@ -502,6 +508,16 @@ LdpcTables *ldpc_tables() {                                            // the co
 void fill_decode_tables(WrDecodeArgs &a, const LdpcTables *t) {
     a.vedge = t->d_vedge; a.vpos = t->d_vpos; a.phi0_lut = t->d_lut; a.scramble = t->d_scramble;
 }
+// the decoder's scratch block (wr_dec_scratch_bytes): estimates | work counters | packet addresses | exit records | two repeat lists
+void carve_decode_scratch(WrDecodeArgs &a, char *base, size_t nslots) {
+    a.esn0 = (double *)base;
+    a.work = (unsigned *)(base + nslots * 8);
+    a.pbase = (unsigned long long *)(base + nslots * 8 + 4096);
+    a.agree = getenv("WENET_RX_NO_GUARD") ? nullptr : (unsigned *)(base + nslots * 16 + 4096);
+    a.redo = (unsigned *)(base + nslots * 48 + 4096);
+    if (const char *e = getenv("WENET_RX_DBG_DESYNC")) a.dbg_inject = atoi(e);                // tests: a wavefront that stays in the iteration loop
+}
+std::atomic<long long> g_decoder_repeats{0};                          // packets the agreement guard decoded again, process-wide (wenet_rx_decoder_repeats)
 
 }  // namespace
 
@@ -748,12 +764,11 @@ int run_dense(int kind, const void *in, int npk, int n, int mode, int max_iter, 
     a.out = g_dec.d_out.as<WrPacketOut>();
     a.llr_out = llr_host ? g_dec.d_llr.as<float>() : nullptr;
     a.bits_out = bits_host ? g_dec.d_bits.as<uint8_t>() : nullptr;
-    a.esn0 = g_dec.d_esn0.as<double>();
-    a.work = (unsigned *)(g_dec.d_esn0.as<double>() + npk);            // (inside the 4096 bytes reserved behind the estimates)
-    a.pbase = (unsigned long long *)(g_dec.d_esn0.as<char>() + (size_t)npk * 8 + 4096);
+    carve_decode_scratch(a, g_dec.d_esn0.as<char>(), (size_t)npk);
     fill_decode_tables(a, t);
     WR_CHECK(wr_launch_decode(&a, 0), -4);
     WR_CHECK(hipDeviceSynchronize(), -4);
+    { const int again = wr_decode_settle(&a, 0); if (again < 0) return again; g_decoder_repeats += again; }
     if (outs) {
         outs->resize(npk);
         WR_CHECK(hipMemcpy(outs->data(), g_dec.d_out.p, (size_t)npk * sizeof(WrPacketOut), hipMemcpyDeviceToHost), -3);
@@ -843,12 +858,11 @@ extern "C" long wenet_deframer_push(wenet_deframer *d, const float *symbols, lon
     a.input_kind = WR_DEC_IN_STREAM; a.mode = d->mode; a.max_iter = d->max_iter; a.nchan = 1; a.max_pk = max_pk;
     a.dchans = d->d_chan.as<WrDeframeChan>();
     a.out = d->d_out.as<WrPacketOut>();
-    a.esn0 = d->d_esn0.as<double>();
-    a.work = (unsigned *)(d->d_esn0.as<double>() + max_pk);
-    a.pbase = (unsigned long long *)(d->d_esn0.as<char>() + (size_t)max_pk * 8 + 4096);
+    carve_decode_scratch(a, d->d_esn0.as<char>(), (size_t)max_pk);
     fill_decode_tables(a, t);
     WR_CHECK(wr_launch_decode(&a, 0), -4);
     WR_CHECK(hipMemcpy(&st, d->d_state.p, sizeof(st), hipMemcpyDeviceToHost), -3);   // synchronises
+    { const int again = wr_decode_settle(&a, 0); if (again < 0) return again; g_decoder_repeats += again; }
     long npk = (long)st.npackets;
     std::vector<WrPacketOut> outs(npk);
     std::vector<long long> starts(npk);
@@ -966,6 +980,11 @@ struct wenet_rx {
     hipStream_t copy_stream = nullptr;      // host-fed batches: H2D of sub-batch k+1 runs under the kernels of sub-batch k
     hipStream_t res_stream = nullptr;       // results: D2H behind each decode launch (its own stream: uploads and result copies must not queue behind each other)
     hipEvent_t copied_all = nullptr;        // the last result copy of the batch in flight
+    DevBuf d_redo;                          // agreement guard: two slot lists per decode launch of the batch (wr_decode_settle)
+    unsigned *h_redo = nullptr;             // pinned: the launches' counts of listed packets, copied back with the results
+    std::vector<WrDecodeArgs> dec_parts;    // the batch's decode launches
+    std::vector<size_t> dec_part_slot0;     // first packet slot of each in d_out / h_out
+    long long repeats = 0;                  // packets decoded again since the handle was made
     std::vector<hipEvent_t> part_ev;        // one per decode launch
     hipEvent_t part_event(int i) {
         while ((int)part_ev.size() <= i) {
@@ -999,6 +1018,7 @@ struct wenet_rx {
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
         if (res_stream) (void)hipStreamDestroy(res_stream);
         if (copied_all) (void)hipEventDestroy(copied_all);
+        if (h_redo) (void)hipHostFree(h_redo);
         for (hipEvent_t ev : part_ev) (void)hipEventDestroy(ev);
         for (hipEvent_t ev : slice_ev) (void)hipEventDestroy(ev);
         if (h_pin) (void)hipHostFree(h_pin);
@@ -1195,13 +1215,21 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw_in, const 
     a.input_kind = WR_DEC_IN_STREAM; a.mode = rx->mode; a.max_iter = rx->max_iter; a.nchan = nchan; a.max_pk = (int)max_pk;
     a.dchans = rx->d_dchans.as<WrDeframeChan>();
     a.out = rx->d_out.as<WrPacketOut>();
-    a.esn0 = rx->d_esn0.as<double>();
-    a.pbase = (unsigned long long *)(rx->d_esn0.as<char>() + (size_t)nchan * max_pk * 8 + 4096);
+    carve_decode_scratch(a, rx->d_esn0.as<char>(), (size_t)nchan * max_pk);
     a.census = rx->d_census.as<unsigned>();
     a.llr_out = rx->want_llr ? rx->d_llr.as<float>() : nullptr;
     fill_decode_tables(a, t);
+    rx->dec_parts.clear(); rx->dec_part_slot0.clear();
+    if (!rx->h_redo) WR_CHECK(hipHostMalloc((void **)&rx->h_redo, 4096, hipHostMallocDefault), -2);
+    memset(rx->h_redo, 0, 4096);
 #ifdef WR_DEC_STAMPS
     if (rx->d_prof.reserve(4096)) { a.dbg = rx->d_prof.as<long long>(); (void)hipMemsetAsync(a.dbg, 0, 64, stream); }
+#endif
+#ifdef WR_GUARD_DEBUG                                                  // development: 8 wavefronts x 4 words per packet slot (ldpc_kernel.hip)
+    if (rx->d_prof.reserve((size_t)nchan * max_pk * 128)) { a.dbg = rx->d_prof.as<long long>(); (void)hipMemsetAsync(a.dbg, 0, (size_t)nchan * max_pk * 128, stream); }
+#endif
+#ifdef WR_DEC_CANARY                                                   // development: 8 wavefronts x 8 words per packet slot (ldpc_kernel.hip)
+    if (rx->d_prof.reserve((size_t)nchan * max_pk * (256 + 2560))) { a.dbg = rx->d_prof.as<long long>(); (void)hipMemsetAsync(a.dbg, 0, (size_t)nchan * max_pk * (256 + 2560), stream); }
 #endif
     const DemodChoice whole = choose_demod(rx, nchan, fmt);
     const bool use_oct = whole.use_oct;
@@ -1313,7 +1341,14 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw_in, const 
         ak.out = a.out + (size_t)lo * max_pk;
         ak.esn0 = a.esn0 + (size_t)lo * max_pk;
         ak.pbase = a.pbase + (size_t)lo * max_pk;
+        if (a.agree) ak.agree = a.agree + (size_t)lo * max_pk * (WR_DEC_THREADS / 64);
         ak.census = a.census + (size_t)lo * WR_CENSUS_CLASSES;
+#ifdef WR_DEC_CANARY
+        if (a.dbg) ak.dbg = a.dbg + (size_t)lo * max_pk * 32;
+#endif
+#ifdef WR_GUARD_DEBUG
+        if (a.dbg) ak.dbg = a.dbg + (size_t)lo * max_pk * 16;
+#endif
         if (a.llr_out) ak.llr_out = a.llr_out + (size_t)lo * max_pk * WR_NCODE;
         WR_CHECK(hipEventRecord(e.ev[0], stream), -4);
         // A capture is a serial job, so the batch demodulator works in rounds of the captures a device holds (two workgroups per CU); what is
@@ -1386,7 +1421,11 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw_in, const 
         // memory on the copy stream while the next part decodes: the copy-back (280 B per slot, 7 ms for 3584 captures) leaves the
         // critical path except for the last part's -- which is therefore the smallest (an eighth of the captures instead of a quarter).
         static const int kPartCut[5] = {0, 300, 600, 875, 1000};
+#if (defined(WR_DEC_CANARY) && WR_DEC_CANARY >= 2) || defined(WR_DEC_ONE_PART)
+        const int nparts = 1;                                            // (the per-iteration records sit behind the launch's own slots)
+#else
         const int nparts = n >= 1024 ? 4 : 1;
+#endif
         if (nparts > 1) { WrDecodeArgs as = ak; as.phase = 1; WR_CHECK(wr_launch_decode(&as, stream), -4); }      // LLR statistics of the whole sub-batch in one launch
         for (int p = 0; p < nparts; p++) {
             const int plo = nparts > 1 ? (int)((long long)n * kPartCut[p] / 1000) : 0, phi = nparts > 1 ? (int)((long long)n * kPartCut[p + 1] / 1000) : n;
@@ -1398,7 +1437,18 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw_in, const 
             ap.esn0 = ak.esn0 + (size_t)plo * max_pk;
             ap.pbase = ak.pbase + (size_t)plo * max_pk;
             ap.work = (unsigned *)(a.esn0 + (size_t)nchan * max_pk) + (k * 4 + p);      // one counter per launch, behind the array
+            const int li = k * 4 + p;                                                  // agreement guard: this launch's records and lists
+            if (ak.agree && li < 1024 && rx->d_redo.reserve((size_t)rx->nchunks * 4 * 8192)) {
+                ap.agree = ak.agree + (size_t)plo * max_pk * (WR_DEC_THREADS / 64);
+                ap.redo = rx->d_redo.as<unsigned>() + (size_t)li * 2048;
+            } else ap.agree = nullptr;
             ap.census = ak.census + (size_t)plo * WR_CENSUS_CLASSES;
+#ifdef WR_DEC_CANARY
+            if (ak.dbg) ap.dbg = ak.dbg + (size_t)plo * max_pk * 32;
+#endif
+#ifdef WR_GUARD_DEBUG
+            if (ak.dbg) ap.dbg = ak.dbg + (size_t)plo * max_pk * 16;
+#endif
             if (ak.llr_out) ap.llr_out = ak.llr_out + (size_t)plo * max_pk * WR_NCODE;
             WR_CHECK(wr_launch_decode(&ap, stream), -4);
             hipEvent_t done = rx->part_event(k * 4 + p);
@@ -1408,6 +1458,8 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw_in, const 
             const size_t s0 = (size_t)(lo + plo) * max_pk, ns = (size_t)(phi - plo) * max_pk;
             WR_CHECK(hipMemcpyAsync(rx->h_out + s0, rx->d_out.as<WrPacketOut>() + s0, ns * sizeof(WrPacketOut), hipMemcpyDeviceToHost, rx->res_stream), -3);
             WR_CHECK(hipMemcpyAsync(rx->h_starts + s0, rx->d_starts.as<long long>() + s0, ns * 8, hipMemcpyDeviceToHost, rx->res_stream), -3);
+            if (ap.agree) WR_CHECK(hipMemcpyAsync(rx->h_redo + li, ap.redo, sizeof(unsigned), hipMemcpyDeviceToHost, rx->res_stream), -3);
+            rx->dec_parts.push_back(ap); rx->dec_part_slot0.push_back(s0);
         }
         WR_CHECK(hipEventRecord(e.ev[3], stream), -4);
     }
@@ -1504,7 +1556,7 @@ const char *device_view_of_host(const void *p) {
 }
 }  // namespace
 
-static void live_close(wenet_rx *rx) { rx->live_n = 0; rx->live_fmt = -1; rx->live_ticks = 0; }
+static void live_close(wenet_rx *rx) { rx->live_n = 0; rx->live_fmt = -1; rx->live_ticks = 0; rx->nchan = 0; }     // (nchan 0: the getters have nothing to describe once the streams have ended -- the batch layout does not hold for a tick's buffers)
 
 extern "C" int wenet_rx_flush(wenet_rx *rx) {
     if (!rx) return -1;
@@ -1687,9 +1739,7 @@ extern "C" long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *c
     a.input_kind = WR_DEC_IN_STREAM; a.mode = rx->mode; a.max_iter = rx->max_iter; a.nchan = nchan; a.max_pk = (int)max_pk;
     a.dchans = rx->d_dchans.as<WrDeframeChan>();
     a.out = rx->d_out.as<WrPacketOut>();
-    a.esn0 = rx->d_esn0.as<double>();
-    a.work = (unsigned *)(a.esn0 + (size_t)nchan * max_pk);
-    a.pbase = (unsigned long long *)(rx->d_esn0.as<char>() + (size_t)nchan * max_pk * 8 + 4096);
+    carve_decode_scratch(a, rx->d_esn0.as<char>(), (size_t)nchan * max_pk);
     a.census = rx->d_census.as<unsigned>();
     a.llr_out = rx->want_llr ? rx->d_llr.as<float>() : nullptr;
     fill_decode_tables(a, t);
@@ -1708,6 +1758,20 @@ extern "C" long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *c
         WR_LIVE_CHECK(hipMemcpyAsync(rx->h_out, rx->d_out.p, out_bytes, hipMemcpyDeviceToHost, stream), -3);
         WR_LIVE_CHECK(hipMemcpyAsync(rx->h_starts, rx->d_starts.p, st_bytes, hipMemcpyDeviceToHost, stream), -3);
         WR_LIVE_CHECK(hipStreamSynchronize(stream), -4);
+        if (a.agree) {                                                // agreement guard: a tick has few packets -- look for a listed one among the slots that came back
+            bool listed = false;
+            const WrDeframeState *ds = (const WrDeframeState *)(hp + o_dst);
+            for (int i = 0; i < nchan && !listed; i++)
+                for (long long k = 0; k < ds[i].npackets && !listed; k++) listed = rx->h_out[(size_t)i * max_pk + k].done == 2;
+            if (listed) {
+                const int again = wr_decode_settle(&a, stream);
+                if (again < 0) { fprintf(stderr, "libwenet_rx: the decoder's wavefronts did not agree on a packet after four rounds (%d)\n", again); live_close(rx); return again; }
+                rx->repeats += again; g_decoder_repeats += again;
+                WR_LIVE_CHECK(hipMemcpyAsync(hp + o_cen, rx->d_census.p, rx->h_census.size() * 4, hipMemcpyDeviceToHost, stream), -3);
+                WR_LIVE_CHECK(hipMemcpyAsync(rx->h_out, rx->d_out.p, out_bytes, hipMemcpyDeviceToHost, stream), -3);
+                WR_LIVE_CHECK(hipStreamSynchronize(stream), -4);
+            }
+        }
         for (int i = 0; i < nchan; i++) memcpy(&rx->h_states[(size_t)i * c.st_floats], hp + o_hdr + sizeof(WrChanHdr) * (size_t)i, sizeof(WrChanHdr));
         memcpy(rx->h_dstates.data(), hp + o_dst, sizeof(WrDeframeState) * nchan);
         memcpy(rx->h_census.data(), hp + o_cen, rx->h_census.size() * 4);
@@ -1785,10 +1849,20 @@ extern "C" int wenet_rx_collect(wenet_rx *rx) {
                     (double)d[0] / d[6], (double)d[1] / d[6], (double)d[2] / d[6], (double)d[7] / d[6], (double)d[2] / (d[7] > 0 ? d[7] : 1), (double)d[3] / d[6], (double)d[5] / d[6], d[6]);
     }
 #endif
-    rx->h_census.resize((size_t)nchan * WR_CENSUS_CLASSES);
-    WR_CHECK(hipMemcpy(rx->h_census.data(), rx->d_census.p, rx->h_census.size() * 4, hipMemcpyDeviceToHost), -3);
     // packet slots + start offsets were copied to the pinned host buffer behind each decode launch (rx_enqueue)
     WR_CHECK(hipEventSynchronize(rx->copied_all), -4);
+    // agreement guard: a launch that listed packets (its count came back with its slots) decodes them again, and its slots are fetched again
+    for (size_t i = 0; i < rx->dec_parts.size(); i++) {
+        const WrDecodeArgs &ap = rx->dec_parts[i];
+        if (!ap.agree || rx->h_redo[(ap.redo - rx->d_redo.as<unsigned>()) >> 11] == 0) continue;
+        const int again = wr_decode_settle(&ap, 0);
+        if (again < 0) { fprintf(stderr, "libwenet_rx: the decoder's wavefronts did not agree on %s (%d)\n", "a packet after four rounds", again); rx->pending = false; return again; }
+        rx->repeats += again; g_decoder_repeats += again;
+        const size_t s0 = rx->dec_part_slot0[i], ns = (size_t)ap.nchan * ap.max_pk;
+        WR_CHECK(hipMemcpy(rx->h_out + s0, rx->d_out.as<WrPacketOut>() + s0, ns * sizeof(WrPacketOut), hipMemcpyDeviceToHost), -3);
+    }
+    rx->h_census.resize((size_t)nchan * WR_CENSUS_CLASSES);
+    WR_CHECK(hipMemcpy(rx->h_census.data(), rx->d_census.p, rx->h_census.size() * 4, hipMemcpyDeviceToHost), -3);
     rx->pending = false;
     return 0;
 }
@@ -1971,5 +2045,52 @@ extern "C" int wenet_phi0_eval(const float *x, float *y, long n) {
     WR_CHECK(hipMemcpy(y, dy.p, (size_t)n * 4, hipMemcpyDeviceToHost), -3);
     return 0;
 }
+#ifdef WR_GUARD_DEBUG
+// development: the guard's debug words (8 wavefronts x 4 words per slot) and the packet slots as they came back
+extern "C" long long wenet_rx_debug_guard(wenet_rx *rx, void *out, long long cap) {
+    if (!rx || !rx->d_prof.p) return -1;
+    const long long n = (long long)rx->nchan * rx->max_pk * 128;
+    if (n > cap) return -n;
+    DeviceGuard g(rx->device);
+    if (hipMemcpy(out, rx->d_prof.p, (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) return -3;
+    return n;
+}
+extern "C" long long wenet_rx_debug_slots(wenet_rx *rx, void *out, long long cap) {
+    if (!rx || rx->pending || !rx->h_out) return -1;
+    const long long n = (long long)rx->nchan * rx->max_pk * (long long)sizeof(WrPacketOut);
+    if (n > cap) return -n;
+    memcpy(out, rx->h_out, (size_t)n);
+    return n;
+}
+#endif
+#ifdef WR_DEC_CANARY
+// development: the decode kernel's per-wavefront records of the last batch (nchan * max_pk slots x 8 wavefronts x 8 words); returns the bytes copied
+extern "C" long long wenet_rx_debug_canary(wenet_rx *rx, void *out, long long cap) {
+    if (!rx || !rx->d_prof.p) return -1;
+    const long long n = (long long)rx->nchan * rx->max_pk * 256;
+    if (n > cap) return -n;
+    DeviceGuard g(rx->device);
+    if (hipMemcpy(out, rx->d_prof.p, (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) return -3;
+    return n;
+}
+// development (-DWR_DEC_CANARY=2): one slot's per-iteration records (8 wavefronts x 10 iterations x 8 words)
+extern "C" long long wenet_rx_debug_canary_iters(wenet_rx *rx, long long slot, void *out) {
+    if (!rx || !rx->d_prof.p) return -1;
+    DeviceGuard g(rx->device);
+    const size_t nslots = (size_t)rx->nchan * rx->max_pk;
+    if (hipMemcpy(out, rx->d_prof.as<char>() + nslots * 256 + (size_t)slot * 2560, 2560, hipMemcpyDeviceToHost) != hipSuccess) return -3;
+    return 2560;
+}
+// development: the packet slots of the last collected batch as they came back (nchan * max_pk records of 280 bytes); returns the bytes copied
+extern "C" long long wenet_rx_debug_slots(wenet_rx *rx, void *out, long long cap) {
+    if (!rx || rx->pending || !rx->h_out) return -1;
+    const long long n = (long long)rx->nchan * rx->max_pk * (long long)sizeof(WrPacketOut);
+    if (n > cap) return -n;
+    memcpy(out, rx->h_out, (size_t)n);
+    return n;
+}
+#endif
 extern "C" const char *wenet_rx_version(void) { return "wenet_rx 0.4 (gfx950)"; }
+// packets the decoder's agreement guard decoded again: process-wide (handle NULL) or by this handle's batches and ticks.  0 in every run seen with the shipped decoder.
+extern "C" long long wenet_rx_decoder_repeats(wenet_rx *rx) { return rx ? rx->repeats : (long long)g_decoder_repeats; }
 extern "C" const char *wenet_rx_source_id(void) { return WR_SOURCE_ID; }

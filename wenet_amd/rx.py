@@ -196,5 +196,9 @@ class RxBatch:
         """diagnostics of the last collected batch: what = 0 frames with nin != N, 1 mix-stage passes that parked every integrator output"""
         return int(self._L.wenet_rx_channel_counter(self._h, ch, what))
 
+    def decoder_repeats(self):
+        """packets of this handle's batches and ticks that the decoder's agreement guard decoded again (include/wenet_rx.h)"""
+        return int(self._L.wenet_rx_decoder_repeats(self._h))
+
     def last_ms(self, what=3):
         return float(self._L.wenet_rx_last_ms(self._h, what))
