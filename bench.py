@@ -181,7 +181,7 @@ def main():
     import threading
 
     import torch
-    from wenet_amd import siggen
+    from wenet_amd import siggen, lib as _lib
     from wenet_amd.rx import RxBatch
 
     rank = int(os.environ.get("RANK", "0"))
@@ -427,6 +427,8 @@ def main():
             "kernel_ms": {"demod": round(k_ms[0], 3), "deframe": round(k_ms[1], 3), "decode": round(k_ms[2], 3),
                           "gpu_total": round(k_ms[3], 3)},
             "roofline": roof,
+            # the decoder's agreement guard (include/wenet_rx.h: wenet_rx_decoder_repeats): packets it had to decode again in this process, all legs -- 0 is the expected value
+            "decoder_repeats": int(_lib.load().wenet_rx_decoder_repeats(None)),
         }
         if dist_note:
             line["dist_note"] = dist_note
@@ -486,13 +488,15 @@ def main():
                     #  garbage-collection pass that unpins such a block stalls the device for tens of milliseconds; the collector then rests while the ticks are timed)
                     import gc
                     gc.collect(); torch.cuda.synchronize(); gc.disable()
-                    for k in range(0, nsamp, tick):
-                        nk = min(tick, nsamp - k)
-                        tl = time.perf_counter()
-                        npk_l += rl.push_ptrs(base_l + np.uint64(2 * k), np.full(nl, nk, np.int64), "cu8")
-                        lat.append(time.perf_counter() - tl)
-                        kms += [rl.last_ms(i) for i in range(3)]
-                    gc.enable()
+                    try:
+                        for k in range(0, nsamp, tick):
+                            nk = min(tick, nsamp - k)
+                            tl = time.perf_counter()
+                            npk_l += rl.push_ptrs(base_l + np.uint64(2 * k), np.full(nl, nk, np.int64), "cu8")
+                            lat.append(time.perf_counter() - tl)
+                            kms += [rl.last_ms(i) for i in range(3)]
+                    finally:
+                        gc.enable()                                              # (whatever a tick raises: the legs after this one run with the collector on)
                     lk = rl.last_kernel()
                     gathered = rl.live_gathered()
                     rl.flush()

@@ -249,6 +249,11 @@ const char *wenet_rx_version(void);
  * a measurement is attributed to the sources only when the two agree, i.e. the library is not a stale build) */
 const char *wenet_rx_source_id(void);
 
+/* One number for everything the last batch (or tick) delivered -- per capture the packet count, per packet the 258 decoded bytes, CRC flag, iteration count and
+ * stream position -- so that two runs over the same input can be compared without fetching a million packets (the reference pipe is deterministic by being one
+ * thread, src/drs232_ldpc.c:176-274; here it is a property to be tested).  npackets / nvalid (may be NULL): totals over the captures.  0 if nothing is collected. */
+unsigned long long wenet_rx_result_digest(wenet_rx *rx, long long *npackets, long long *nvalid);
+
 /* The decoder's agreement guard (no counterpart in the reference: src/mpdecode_core.c:385-489 is one thread).  The eight wavefronts that decode a packet
  * each leave the iteration loop on what they read from a shared counter; a packet on which they did not leave together is not trusted -- it is decoded
  * again before any result is handed over.  This returns how many packets that happened to: for the batches and ticks of one handle, or process-wide

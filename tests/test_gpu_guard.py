@@ -1,7 +1,8 @@
 """GPU: the decoder's agreement guard (include/wenet_rx.h: wenet_rx_decoder_repeats; ldpc_kernel.hip).  The eight wavefronts that decode a packet must leave the iteration loop
 together; a packet on which they did not is decoded again before results are handed over.  Round 5 found builds of the decoder in which one wavefront in ~10^7 packets stayed in
 the loop (tools/experiments/README.md); here the same is provoked on purpose (WENET_RX_DBG_DESYNC: wavefront 3 of every workgroup ignores the stop of its n-th packet) and the
-results must equal the undisturbed run's, packet for packet, with the repeats counted."""
+results must equal the undisturbed run's, packet for packet, with the repeats counted.  (The cause found in round 5 -- a store still in flight at the barrier that heads the
+decoder's packet loop -- is fixed in the kernel; the guard stays as the second line: it costs 1 % of the decode step and catches the whole class.)"""
 import os
 
 import numpy as np
@@ -47,12 +48,12 @@ def _run(cfg, caps, nsamp):
     return out, rep
 
 
-@pytest.mark.parametrize("nth,B", [(1, 96), (2, 96), (3, 1280), (5, 96), (8, 512)])
+@pytest.mark.parametrize("nth,B", [(1, 96), (2, 96), (3, 1280), (5, 1280), (8, 1280)])
 def test_a_wavefront_that_stays_in_the_loop_is_caught_and_the_packets_are_decoded_again(nth, B):
     cfg, caps, nsamp = _batch(B=B)
     os.environ.pop("WENET_RX_DBG_DESYNC", None)
     ref, rep0 = _run(cfg, caps, nsamp)
-    assert rep0 <= 2           # (the undisturbed decoder: a wavefront reads another count than its siblings about twice in a million packets -- harmless unless the count is 516)
+    assert rep0 == 0                                                       # the undisturbed decoder agrees with itself
     assert sum(len(r[1]) for r in ref) > 5 * len(caps) and sum(int(r[2].sum()) for r in ref) > 0
     os.environ["WENET_RX_DBG_DESYNC"] = str(nth)
     try:

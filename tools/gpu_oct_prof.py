@@ -26,7 +26,8 @@ nsym = int(secs * cfg.Rs); nsamp = nsym * cfg.Ts
 tx = Tx.from_config(cfg)
 spp = tx.symbols_per_packet
 nfr = nsym // spp + 1
-payloads = torch.randint(0, 256, (B * nfr, 256), dtype=torch.uint8, device=dev)
+_g = torch.Generator(device=dev); _g.manual_seed(2001)          # (seeded: numbers of different runs describe the same batch)
+payloads = torch.randint(0, 256, (B * nfr, 256), dtype=torch.uint8, device=dev, generator=_g)
 symbols = torch.empty(B * nfr * spp, dtype=torch.uint8, device=dev)
 tx.frame_packets_device(payloads.data_ptr(), B * nfr, symbols.data_ptr())
 caps_t = [torch.empty(2 * nsamp, dtype=torch.uint8, device=dev) for _ in range(B)]

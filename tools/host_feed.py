@@ -16,7 +16,8 @@ dev = torch.device("cuda", 0)
 nsym = int(secs * cfg.Rs); nsamp = nsym * cfg.Ts
 tx = Tx.from_config(cfg); spp = tx.symbols_per_packet; nfr = nsym // spp + 1
 G = min(B, 64)                                                   # a few distinct captures, reused: the host copies are what matters here
-payloads = torch.randint(0, 256, (G * nfr, 256), dtype=torch.uint8, device=dev)
+_g = torch.Generator(device=dev); _g.manual_seed(2001)          # (seeded: numbers of different runs describe the same batch)
+payloads = torch.randint(0, 256, (G * nfr, 256), dtype=torch.uint8, device=dev, generator=_g)
 symbols = torch.empty(G * nfr * spp, dtype=torch.uint8, device=dev)
 tx.frame_packets_device(payloads.data_ptr(), G * nfr, symbols.data_ptr())
 caps = [torch.empty(2 * nsamp, dtype=torch.uint8, device=dev) for _ in range(G)]

@@ -215,7 +215,7 @@ __device__ __attribute__((noinline)) void oct_slice_done(WrSliceCtl *ctl, WrChan
         WrChan &c = chans[bid * G + lane];
         WrSliceInfo &inf = ctl->info[bid * G + lane];
         const WrChanHdr *h = (const WrChanHdr *)c.state;
-        inf.slips_acc += h->slips_call; inf.allout_acc += h->allout_call;
+        if (slice + 1 < ctl->nslices) { inf.slips_acc += h->slips_call; inf.allout_acc += h->allout_call; }      // (the LAST slice's counts stay in the header: wenet_rx_collect adds the two)
         const long long done_smp = ((const char *)c.raw - inf.base) / ctl->bps + h->consumed_call;
         const long long next_end = (long long)(slice + 2) * ctl->slice_len, end = inf.total < next_end ? inf.total : next_end;
         c.raw = inf.base + done_smp * ctl->bps;

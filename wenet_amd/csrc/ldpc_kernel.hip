@@ -585,9 +585,6 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
     inj_seq++;
 #ifdef WR_DEC_CANARY
     cn_bar = 0;
-#if WR_DEC_CANARY == 3 || WR_DEC_CANARY == 4 || defined(WR_DEC_ASMCMP)
-    unsigned long long cn_hist = 0, cn_dmask = 0, cn_amask = 0; unsigned cn_any = 0;
-#endif
 #endif
 #ifdef WR_DEC_STAMPS
     if (st_t) DSTAMP(5);                                                           // [5] end of the previous packet -> everyone at the top
@@ -610,9 +607,6 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
         base = (unsigned long long)uni64((long long)A.pbase[slot]);
         estEsN0 = __longlong_as_double(uni64(__double_as_longlong(A.esn0[slot])));
     }
-#ifdef WR_DEC_WAIT_EMPTY_PATH                                                     // (diagnosis: the wait only where an empty slot's claim is written)
-    if (base == 0ull) { put_claim(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); continue; }
-#endif
     if (base == 0ull) { put_claim(); continue; }                                   // nothing in this slot
     const int n = (A.input_kind == WR_DEC_IN_SD64) ? A.n_sd : WR_NCODE;
 
@@ -713,35 +707,6 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
         // ---- update r: thread = check (mpdecode_core.c:414-436).  All 14 slots are processed for every check:
         //      the phantom 14th edge of check 0 adds +0.0 LAST to phi_sum (no change) and contributes no sign.
         int ok = 0;
-#if defined(WR_DEC_CANARY) && WR_DEC_CANARY == 10                 // (far from the decision: the cell of the previous iteration is still intact here -- read it AGAIN and compare with what was carried)
-        if (iter > 0 && pcc_written) {
-            const int again = red[((iter - 1) & 1) * 2 + 0];
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(pcc != again);
-            if (m != 0ull && A.dbg) {
-                unsigned *r = (unsigned *)A.dbg + (size_t)nslots * 64 + ((size_t)slot * 8 + (tid >> 6)) * 80;
-                if ((tid & 63) == 0) { r[64] = (unsigned)m; r[65] = (unsigned)(m >> 32); r[66] = (unsigned)iter; r[67] = 0xAAAAu; r[68] = (unsigned)pcc; r[69] = (unsigned)again; r[70] = (unsigned)red[((iter - 1) & 1) * 2 + 1]; r[71] = (unsigned)red[(iter & 1) * 2 + 0]; }
-            }
-        }
-#endif
-#if defined(WR_DEC_CANARY) && WR_DEC_CANARY == 9                  // (far from the decision: the carried count into an LDS history, copied out with the packet's record)
-        if (iter > 0 && (tid & 63) == 0) ((unsigned *)(smem + WR_DEC_LDS_BYTES))[(tid >> 6) * 10 + iter] = (unsigned)pcc | ((unsigned)pcc_written << 16) | 0x80000000u;
-#endif
-#if defined(WR_DEC_CANARY) && WR_DEC_CANARY == 8                  // (far from the decision: the count every wavefront carried out of the previous iteration)
-        if (iter > 0 && A.dbg && (tid & 63) == 0) {
-            unsigned *r = (unsigned *)A.dbg + (size_t)nslots * 64 + ((size_t)slot * 8 + (tid >> 6)) * 80;
-            r[iter] = (unsigned)pcc | ((unsigned)pcc_written << 16) | 0x80000000u;
-        }
-#endif
-#if defined(WR_DEC_CANARY) && WR_DEC_CANARY == 7                  // (far from the decision: a wavefront that went on although its count, as carried in pcc, says 516 on some or all lanes)
-        if (iter > 0 && pcc_written) {
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(pcc != WR_NPAR);
-            if (m != ~0ull && A.dbg) {
-                unsigned *r = (unsigned *)A.dbg + (size_t)nslots * 64 + ((size_t)slot * 8 + (tid >> 6)) * 80;
-                r[tid & 63] = (unsigned)pcc;
-                if ((tid & 63) == 0) { r[64] = (unsigned)m; r[65] = (unsigned)(m >> 32); r[66] = (unsigned)iter; r[67] = 0x7777u; }
-            }
-        }
-#endif
 #pragma unroll
         for (int cj = 0; cj < WR_DEC_CHECKS_PER_THREAD; cj++) {
             const int chk = tid + cj * WR_DEC_THREADS;          // the whole checks: one per thread (512 threads; two with -DWR_DEC_THREADS=256)
@@ -842,19 +807,14 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
         WR_LDS_BARRIER();
-#if defined(WR_DEC_FIX) && WR_DEC_FIX == 2                          // (diagnosis: the count is read behind the SECOND barrier, next to the flag -- not held in a register through the variable pass)
-        if (tid == 0) { red[(par ^ 1) * 2 + 0] = 0; red[(par ^ 1) * 2 + 1] = 0; }
-#elif defined(WR_DEC_FIX) && WR_DEC_FIX == 1                        // (diagnosis: the decision on lane 0's copy)
-        const int ssum = __builtin_amdgcn_readfirstlane(red[par * 2 + 0]);
-        if (tid == 0) { red[(par ^ 1) * 2 + 0] = 0; red[(par ^ 1) * 2 + 1] = 0; }
-#elif defined(WR_DEC_PIN_V1)                                          // (diagnosis: the count held in v1, as in the builds that deviate)
-        int ssum = red[par * 2 + 0];
-        asm volatile("; ssum in %0" : "+{v1}"(ssum));
-        if (tid == 0) { red[(par ^ 1) * 2 + 0] = 0; red[(par ^ 1) * 2 + 1] = 0; }
-#else
+#ifdef WR_DEC_VECTOR_DECISION
         const int ssum = red[par * 2 + 0];
-        if (tid == 0) { red[(par ^ 1) * 2 + 0] = 0; red[(par ^ 1) * 2 + 1] = 0; }
+#else
+        // (one copy per wavefront, in a scalar register: the stop rules are then scalar branches, the count rides through the variable pass without a vector register, and
+        //  the agreement guard's fingerprint below is two scalar instructions)
+        const int ssum = __builtin_amdgcn_readfirstlane(red[par * 2 + 0]);
 #endif
+        if (tid == 0) { red[(par ^ 1) * 2 + 0] = 0; red[(par ^ 1) * 2 + 1] = 0; }
         // ---- update q: thread = variable (mpdecode_core.c:439-464) ---------------------------
         int any_data = 0;
         bits = 0;
@@ -900,79 +860,21 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
         }
         if (__ballot(any_data) && (tid & 63) == 0) red[par * 2 + 1] = 1;
         WR_LDS_BARRIER();
+#ifdef WR_DEC_VECTOR_DECISION
         const int any = red[par * 2 + 1];
-#ifdef WR_DEC_PIN_V1
-        asm volatile("; ssum still in %0" : "+{v1}"(ssum));
+#else
+        const int any = __builtin_amdgcn_readfirstlane(red[par * 2 + 1]);
 #endif
-#if defined(WR_DEC_FIX) && WR_DEC_FIX == 2
-        const int ssum = red[par * 2 + 0];
-#endif
-#if defined(WR_DEC_CANARY) && WR_DEC_CANARY == 6                  // (cold path only: when SOME lanes of the wavefront hold another count than the others, every lane writes down what it holds)
-        {
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(ssum != WR_NPAR);
-            if (m != 0ull && m != ~0ull && A.dbg) {
-                unsigned *r = (unsigned *)A.dbg + (size_t)nslots * 64 + ((size_t)slot * 8 + (tid >> 6)) * 80;
-                r[tid & 63] = (unsigned)ssum;
-                if ((tid & 63) == 0) { r[64] = (unsigned)m; r[65] = (unsigned)(m >> 32); r[66] = (unsigned)iter + 1u; r[67] = (unsigned)any; }
-            }
-        }
-#endif
-#if defined(WR_DEC_CANARY) && WR_DEC_CANARY == 4                  // (lightest: only scalar work on the comparison the loop makes anyway)
-        {
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(ssum != WR_NPAR), ma = __builtin_amdgcn_ballot_w64(any != 0);
-            if (m != 0ull && m != ~0ull) { cn_dmask = m; cn_any = (unsigned)iter + 1u; }
-            if (ma != 0ull && ma != ~0ull) { cn_amask = ma; cn_hist = (unsigned long long)iter + 1ull; }
-        }
-#endif
-#if defined(WR_DEC_CANARY) && WR_DEC_CANARY == 3                  // (lighter: the history stays in scalar registers until the packet's record is written)
-        {
-            const int s0 = __builtin_amdgcn_readfirstlane(ssum);
-            cn_hist = (cn_hist << 10) | (unsigned long long)(s0 & 0x3ff);
-            cn_dmask |= __builtin_amdgcn_ballot_w64(ssum != s0);
-            cn_any = (cn_any << 1) | (unsigned)(__builtin_amdgcn_readfirstlane(any) != 0);
-            cn_amask |= __builtin_amdgcn_ballot_w64(any != __builtin_amdgcn_readfirstlane(any));
-        }
-#endif
-#if defined(WR_DEC_CANARY) && WR_DEC_CANARY == 2
-        if (A.dbg && iter < 10) {                                // what this wavefront saw when it decided: the two cells as lane 0 read them, the lanes that read something else
-            const int s0 = __builtin_amdgcn_readfirstlane(ssum), a0 = __builtin_amdgcn_readfirstlane(any);
-            const unsigned long long ds = __builtin_amdgcn_ballot_w64(ssum != s0), da = __builtin_amdgcn_ballot_w64(any != a0), ex = __builtin_amdgcn_ballot_w64(true);
-            if ((tid & 63) == 0) {
-                unsigned *r = (unsigned *)A.dbg + (size_t)nslots * 64 + (((size_t)slot * 8 + (tid >> 6)) * 10 + iter) * 8;
-                r[0] = (unsigned)s0 | 0x80000000u; r[1] = (unsigned)ds; r[2] = (unsigned)(ds >> 32); r[3] = (unsigned)a0; r[4] = (unsigned)da; r[5] = (unsigned)(da >> 32);
-                r[6] = (unsigned)ex; r[7] = (unsigned)(ex >> 32);
-            }
-        }
-#endif
+#ifndef WR_GUARD_NO_HASH
         seen = seen * 33u + (unsigned)ssum * 2u + (unsigned)(any != 0);          // agreement guard: what this wavefront read, iteration by iteration
+#endif
 #ifdef WR_GUARD_DEBUG                                                     // (development: one more word per wavefront -- the sum of the counts it read, in front of how many flags were set)
         seen2 += (unsigned)ssum + ((unsigned)(any != 0) << 20);
-#endif
-#if defined(WR_DEC_CANARY) && WR_DEC_CANARY == 12                         // (development: the pairs themselves, per wavefront, copied out with the packet's record)
-        if ((tid & 63) == 0 && iter < 10) ((unsigned *)(smem + WR_DEC_LDS_BYTES))[(tid >> 6) * 10 + iter] = (unsigned)ssum | ((unsigned)(any != 0) << 16) | 0x80000000u | ((__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) & 0x3fu) << 20);
 #endif
         // ---- stop rules (mpdecode_core.c:466-483) --------------------------------------------
         if (!any) { result = iter + 1; break; }                 // "zero bit errors" against the all-zero data[]
         pcc = ssum; pcc_written = 1;
-#ifdef WR_DEC_ASMCMP                                                     // (diagnosis: the comparison as written-out instructions, with or without wait states behind it)
-        {
-            unsigned long long ne;
-#if WR_DEC_ASMCMP == 3                                                   // (and the count as lane 0 holds it into a scalar history: six iterations x 10 bits)
-            unsigned t32, h0 = (unsigned)cn_hist, h1 = (unsigned)(cn_hist >> 32);
-            asm volatile("v_cmp_ne_u32_e64 %0, %4, %5\n\ts_lshl_b32 %2, %2, 10\n\ts_lshr_b32 %3, %1, 20\n\ts_or_b32 %2, %2, %3\n\ts_lshl_b32 %1, %1, 10\n\ts_and_b32 %1, %1, 0x3fffffff\n\t"
-                         "v_readfirstlane_b32 %3, %5\n\ts_and_b32 %3, %3, 0x3ff\n\ts_or_b32 %1, %1, %3"
-                         : "=s"(ne), "+s"(h0), "+s"(h1), "=&s"(t32) : "s"(WR_NPAR), "v"(ssum));
-            cn_hist = ((unsigned long long)h1 << 32) | h0;
-#elif WR_DEC_ASMCMP == 1
-            asm volatile("v_cmp_ne_u32_e64 %0, %1, %2" : "=s"(ne) : "s"(WR_NPAR), "v"(ssum));
-#else
-            asm volatile("v_cmp_ne_u32_e64 %0, %1, %2\n\ts_nop 7\n\ts_nop 7" : "=s"(ne) : "s"(WR_NPAR), "v"(ssum));
-#endif
-            if (ne == 0ull) { result = iter + 1; break; }
-        }
-#else
-        if (ssum == WR_NPAR && !(A.dbg_inject && (tid >> 6) == 3 && inj_seq == A.dbg_inject)) { result = iter + 1; break; }     // (dbg_inject: tests of the agreement guard)
-#endif
+        if (ssum == WR_NPAR && !(A.dbg_inject && (blockIdx.x & 7) == 0 && (tid >> 6) == 3 && inj_seq == A.dbg_inject)) { result = iter + 1; break; }     // (dbg_inject: tests of the agreement guard)
     }
 
     DSTAMP(2);                                                      // [2] the iterations
@@ -1014,37 +916,20 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
         g2[0] = seen2 | 0x80000000u; g2[1] = (unsigned)result | ((unsigned)pcc << 8); g2[2] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)); g2[3] = (unsigned)__builtin_readcyclecounter();
     }
 #endif
+#ifndef WR_GUARD_OFF
     if ((tid & 63) == 0 && A.agree) A.agree[slot * (WR_DEC_THREADS / 64) + (tid >> 6)] = (((seen * 0x9E3779B1u) ^ ((unsigned)slot_i << 8)) & 0xffffff00u) | 0x80u | ((unsigned)result & 0x7fu);      // agreement guard (wenet_crc_kernel)
+#endif
 #ifdef WR_DEC_CANARY
     if ((tid & 63) == 0 && A.dbg) {
         unsigned *rec = (unsigned *)A.dbg + ((size_t)slot * 8 + (tid >> 6)) * 8;
         rec[0] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));       // HW_REG_HW_ID
         rec[1] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));      // HW_REG_XCC_ID
         rec[2] = (unsigned)slot_i; rec[3] = (unsigned)result; rec[4] = cn_bar; rec[5] = (blockIdx.x << 12) | (cn_seq & 0xfffu);
-#if defined(WR_DEC_ASMCMP) && WR_DEC_ASMCMP == 3
-        rec[6] = (unsigned)cn_hist; rec[7] = (unsigned)(cn_hist >> 32);
-#else
         rec[6] = (unsigned)pcc; rec[7] = (unsigned)__builtin_readcyclecounter();
-#endif
-#if WR_DEC_CANARY == 12
-        { unsigned *r9 = (unsigned *)A.dbg + (size_t)nslots * 64 + ((size_t)slot * 8 + (tid >> 6)) * 80; unsigned *h9 = (unsigned *)(smem + WR_DEC_LDS_BYTES) + (tid >> 6) * 10;
-          for (int q = 0; q < 10; q++) { r9[q] = h9[q]; h9[q] = 0u; } r9[10] = (unsigned)__builtin_readcyclecounter(); }
-#endif
-#if WR_DEC_CANARY == 9
-        { unsigned *r9 = (unsigned *)A.dbg + (size_t)nslots * 64 + ((size_t)slot * 8 + (tid >> 6)) * 80; unsigned *h9 = (unsigned *)(smem + WR_DEC_LDS_BYTES) + (tid >> 6) * 10;
-          for (int q = 1; q < 10; q++) { r9[q] = h9[q]; h9[q] = 0u; } }
-#endif
-#if WR_DEC_CANARY == 3 || WR_DEC_CANARY == 4
-        unsigned *r = (unsigned *)A.dbg + (size_t)nslots * 64 + ((size_t)slot * 8 + (tid >> 6)) * 80;
-        r[0] = (unsigned)cn_hist; r[1] = (unsigned)(cn_hist >> 32); r[2] = (unsigned)cn_dmask; r[3] = (unsigned)(cn_dmask >> 32); r[4] = cn_any; r[5] = (unsigned)cn_amask; r[6] = (unsigned)(cn_amask >> 32);
-#endif
     }
     cn_seq++;
 #endif
     DSTAMP(3);                                              // [3] bits -> bytes -> packet slot
-#ifdef WR_DEC_WAIT_EPILOGUE                                                         // (diagnosis: the wait only behind the byte staging's stores)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
   }
 #ifdef WR_DEC_STAMPS
   if (tid == 0 && A.dbg) for (int k = 0; k < 8; k++) atomicAdd((unsigned long long *)&A.dbg[k], (unsigned long long)st_acc[k]);
@@ -1102,13 +987,21 @@ extern "C" hipError_t wr_launch_decode(const WrDecodeArgs *args, hipStream_t str
 #ifdef WR_DEC_STATIC_LDS
     const int lds = 0;
 #else
-#if defined(WR_DEC_CANARY) && (WR_DEC_CANARY == 9 || WR_DEC_CANARY == 12)
-    const int lds = WR_DEC_LDS_BYTES + 320;
-#else
     const int lds = WR_DEC_LDS_BYTES;
-#endif
     wr_attr_ok(hipFuncSetAttribute((const void *)wenet_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
 #endif
+    {   // The add-TID stores of the check pass address the message array by ABSOLUTE LDS offsets (M0 + immediate): right only while the kernel's dynamic block starts at LDS
+        // address 0, i.e. while the kernel has no static LDS object of its own.  Checked once per process: a `__shared__` added to the kernel then fails every launch loudly.
+        static int lds_layout_ok = -1;
+        if (lds_layout_ok < 0) {
+            hipFuncAttributes fa;
+            lds_layout_ok = (hipFuncGetAttributes(&fa, (const void *)wenet_decode_kernel) == hipSuccess && fa.sharedSizeBytes == 0) ? 1 : 0;
+            if (!lds_layout_ok) fprintf(stderr, "libwenet_rx: wenet_decode_kernel has %zu bytes of static LDS: its add-TID stores assume the dynamic block at LDS address 0 (ldpc_kernel.hip)\n", (size_t)fa.sharedSizeBytes);
+        }
+#if !defined(WR_DEC_NO_ADDTID) && !defined(WR_DEC_STATIC_LDS)
+        if (!lds_layout_ok) return hipErrorInvalidConfiguration;
+#endif
+    }
     static int ncu = 0;
     if (ncu == 0) { hipDeviceProp_t p; int dev = 0; (void)hipGetDevice(&dev); ncu = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }
     const long long want = (long long)4 * ncu;                       // four workgroups (32 wavefronts) per CU fill it; they loop over the packet slots

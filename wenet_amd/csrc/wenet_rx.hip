@@ -803,7 +803,7 @@ extern "C" int wenet_run_ldpc_decoder(struct wenet_ldpc *ldpc, uint8_t out_char[
 }
 
 extern "C" void wenet_sd_to_llr(float llr[], double sd[], int n) {
-    if (n <= 0 || n > 2880) { fprintf(stderr, "libwenet_rx: wenet_sd_to_llr: n=%d unsupported\n", n); return; }
+    if (n <= 0 || n > 3072) { fprintf(stderr, "libwenet_rx: wenet_sd_to_llr: n=%d unsupported (1..3072: WR_VARS_PER_THREAD x 512 threads, wenet_llr_stats_small_kernel's xs[3072])\n", n); return; }
     (void)run_dense(WR_DEC_IN_SD64, sd, 1, n, 0, 0, 1, nullptr, llr);
 }
 
@@ -1547,11 +1547,20 @@ __global__ __launch_bounds__(256) void wenet_live_gather_kernel(const WrGather *
     if (blockIdx.x == 0 && (long long)threadIdx.x < n - done) g.dst[done + threadIdx.x] = g.src[done + threadIdx.x];
 }
 // the address the DEVICE reads a host buffer at, or nullptr if it cannot (pageable memory)
-const char *device_view_of_host(const void *p) {
-    hipPointerAttribute_t at;
+// (the WHOLE chunk [p, p + bytes) must lie in pinned / registered memory: a chunk that starts in a pinned region and runs past its end -- a ring pinned in parts -- would
+//  make the gather kernel read unmapped host memory; its last byte is therefore probed too and must belong to the same mapping)
+const char *device_view_of_host(const void *p, size_t bytes) {
+    hipPointerAttribute_t at, at2;
     memset(&at, 0, sizeof(at));
     if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     if (at.type != hipMemoryTypeHost || at.devicePointer == nullptr) return nullptr;
+    if (bytes > 1) {
+        memset(&at2, 0, sizeof(at2));
+        const char *last = (const char *)p + bytes - 1;
+        if (hipPointerGetAttributes(&at2, last) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (at2.type != hipMemoryTypeHost || at2.devicePointer == nullptr) return nullptr;
+        if ((const char *)at2.devicePointer - (const char *)at.devicePointer != (ptrdiff_t)(bytes - 1)) return nullptr;     // (two mappings that are not one contiguous view)
+    }
     return (const char *)at.devicePointer;
 }
 }  // namespace
@@ -1644,8 +1653,10 @@ extern "C" long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *c
             { live_close(rx); return -2; }
         }
         for (int i = 0; i < nchan && rx->live_ticks > 0; i++) {
-            if (rx->live_carry_smp[i] > 0) WR_LIVE_CHECK(hipMemcpy((char *)n_in + (size_t)i * nis, rx->d_live_in.as<char>() + (size_t)i * rx->live_in_stride, (size_t)rx->live_carry_smp[i] * bps, hipMemcpyDeviceToDevice), -3);
-            if (rx->live_carry_sym[i] > 0) WR_LIVE_CHECK(hipMemcpy((float *)n_sd + (size_t)i * nss, rx->d_sd.as<float>() + (size_t)i * rx->live_sd_stride, (size_t)rx->live_carry_sym[i] * 4, hipMemcpyDeviceToDevice), -3);
+            hipError_t ce = hipSuccess;                               // (a failure here must not leak the two new blocks)
+            if (rx->live_carry_smp[i] > 0) ce = hipMemcpy((char *)n_in + (size_t)i * nis, rx->d_live_in.as<char>() + (size_t)i * rx->live_in_stride, (size_t)rx->live_carry_smp[i] * bps, hipMemcpyDeviceToDevice);
+            if (ce == hipSuccess && rx->live_carry_sym[i] > 0) ce = hipMemcpy((float *)n_sd + (size_t)i * nss, rx->d_sd.as<float>() + (size_t)i * rx->live_sd_stride, (size_t)rx->live_carry_sym[i] * 4, hipMemcpyDeviceToDevice);
+            if (ce != hipSuccess) { (void)hipFree(n_in); (void)hipFree(n_sd); WR_LIVE_CHECK(ce, -3); }
         }
         if (rx->d_live_in.p) (void)hipFree(rx->d_live_in.p);
         if (rx->d_sd.p) (void)hipFree(rx->d_sd.p);
@@ -1681,7 +1692,7 @@ extern "C" long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *c
     for (int i = 0; i < nchan; i++) {
         char *blk = rx->d_live_in.as<char>() + (size_t)i * rx->live_in_stride;
         if (nsamples[i] > 0) {
-            const char *dv = try_gather ? device_view_of_host(chunk[i]) : nullptr;
+            const char *dv = try_gather ? device_view_of_host(chunk[i], (size_t)nsamples[i] * bps) : nullptr;
             if (dv) gl[ngl++] = WrGather{dv, blk + (size_t)rx->live_carry_smp[i] * bps, (long long)((size_t)nsamples[i] * bps)};
             else WR_LIVE_CHECK(hipMemcpyAsync(blk + (size_t)rx->live_carry_smp[i] * bps, chunk[i], (size_t)nsamples[i] * bps, hipMemcpyHostToDevice, stream), -3);
         }
@@ -1899,6 +1910,31 @@ extern "C" long long wenet_rx_frames(wenet_rx *rx, int ch) {
 extern "C" long long wenet_rx_packets(wenet_rx *rx, int ch) {
     if (!rx || rx->pending || ch < 0 || ch >= rx->nchan || (size_t)ch >= rx->h_dstates.size()) return -1;
     return rx->h_dstates[ch].npackets;
+}
+// one number for everything the last batch (or tick) delivered: per capture its packet count, and of every packet the 258 decoded bytes, the CRC flag, the iteration
+// count and the position in the symbol stream (FNV-1a over 8-byte words).  Two runs over the same input must give the same digest (tests/test_gpu_repro.py).
+extern "C" unsigned long long wenet_rx_result_digest(wenet_rx *rx, long long *npackets, long long *nvalid) {
+    if (!rx || rx->pending) return 0ull;
+    unsigned long long h = 1469598103934665603ull;
+    auto mix = [&](unsigned long long w) { h = (h ^ w) * 1099511628211ull; };
+    long long np = 0, nv = 0;
+    for (int ch = 0; ch < rx->nchan && (size_t)ch < rx->h_dstates.size(); ch++) {
+        const long long n = rx->h_dstates[ch].npackets;
+        mix((unsigned long long)n);
+        for (long long i = 0; i < n; i++) {
+            const WrPacketOut &o = rx->h_out[(size_t)ch * rx->max_pk + i];
+            unsigned long long w[33];
+            w[32] = 0; memcpy(w, o.bytes, 258);
+            for (int k = 0; k < 33; k++) mix(w[k]);
+            mix(((unsigned long long)(unsigned)o.iter << 8) | (unsigned long long)o.crc_ok);
+            mix((unsigned long long)rx->h_starts[(size_t)ch * rx->max_pk + i]);
+            nv += o.crc_ok ? 1 : 0;
+        }
+        np += n;
+    }
+    if (npackets) *npackets = np;
+    if (nvalid) *nvalid = nv;
+    return h;
 }
 extern "C" long long wenet_rx_get_packets(wenet_rx *rx, int ch, uint8_t *pkt_bytes, wenet_packet_info *info, long long cap) {
     long long n = wenet_rx_packets(rx, ch);

@@ -28,7 +28,7 @@ EXPORTS = [
     "wenet_rx_enable_trace", "wenet_rx_get_trace", "wenet_rx_enable_llr_dump", "wenet_rx_get_llrs",
     "wenet_rx_last_ms", "wenet_rx_device_info", "wenet_rx_version", "wenet_rx_last_kernel", "wenet_rx_get_device", "wenet_rx_channel_counter", "wenet_rx_set_cf32_quantise",
     "wenet_packet_type_class", "wenet_ssdv_packet_info", "wenet_rx_get_packets_of_class", "wenet_rx_ssdv_images",
-    "wenet_phi0_eval", "wenet_rx_source_id", "wenet_rx_decoder_repeats", "wenet_rx_push", "wenet_rx_flush", "wenet_rx_live_gathered", "wenet_rx_pin_host", "wenet_rx_unpin_host", "wenet_fsk_last_ebnodb",
+    "wenet_phi0_eval", "wenet_rx_source_id", "wenet_rx_decoder_repeats", "wenet_rx_result_digest", "wenet_rx_push", "wenet_rx_flush", "wenet_rx_live_gathered", "wenet_rx_pin_host", "wenet_rx_unpin_host", "wenet_fsk_last_ebnodb",
 ]
 # every symbol include/wenet_tx.h declares
 EXPORTS_TX = [
@@ -129,6 +129,7 @@ def load():
     L.wenet_rx_source_id.restype = C.c_char_p
     L.wenet_phi0_eval.argtypes = [vp, vp, l]
     L.wenet_rx_decoder_repeats.restype = ll; L.wenet_rx_decoder_repeats.argtypes = [vp]
+    L.wenet_rx_result_digest.restype = C.c_ulonglong; L.wenet_rx_result_digest.argtypes = [vp, C.POINTER(ll), C.POINTER(ll)]
     d = C.c_double
     L.wenet_tx_create.restype = vp; L.wenet_tx_create.argtypes = [i, i, i, i, d, d]
     L.wenet_tx_destroy.argtypes = [vp]

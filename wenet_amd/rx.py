@@ -196,6 +196,12 @@ class RxBatch:
         """diagnostics of the last collected batch: what = 0 frames with nin != N, 1 mix-stage passes that parked every integrator output"""
         return int(self._L.wenet_rx_channel_counter(self._h, ch, what))
 
+    def result_digest(self):
+        """(digest, packets, CRC-valid packets) of everything the last batch or tick delivered (include/wenet_rx.h: wenet_rx_result_digest)"""
+        n, v = C.c_longlong(0), C.c_longlong(0)
+        d = int(self._L.wenet_rx_result_digest(self._h, C.byref(n), C.byref(v)))
+        return d, int(n.value), int(v.value)
+
     def decoder_repeats(self):
         """packets of this handle's batches and ticks that the decoder's agreement guard decoded again (include/wenet_rx.h)"""
         return int(self._L.wenet_rx_decoder_repeats(self._h))
