@@ -152,6 +152,112 @@ def load_pmc_profile(kernel_name, inst, captures):
     return best
 
 
+def live_mode(args, cfg, nsym, nsamp, rank, local_rank, world, dist, dist_note, ndev):
+    """BASELINE config 5 as written (the reference's shape: start_rx_headless.sh:77-80, one receiver chain per channel, src/fsk_demod.c:270-413 reading what has arrived):
+    --live CHANNELS concurrent channels, channel c on rank c mod N (no exchange between ranks), every rank pushes ITS channels' 100 ms of new samples per tick through
+    wenet_rx_push from pinned host rings -- modem and deframer state, unconsumed samples and undecided symbols stay on the GPU -- and gets the packets completed in the tick.
+    Timed: all ticks of --seconds of signal between two barriers, max over ranks; value = all channels' samples / that time (PCIe-inclusive by nature: live samples arrive
+    in host memory).  The captures' packets are checked against what was sent."""
+    import gc
+    import numpy as np
+    import torch
+    from wenet_amd.rx import RxBatch
+    from wenet_amd.shard import shard_indices
+    from wenet_amd.tx import Tx
+    from wenet_amd import lib as _lib
+    dev = torch.device("cuda", local_rank % ndev)
+    torch.cuda.set_device(dev)
+    mine = shard_indices(args.live, rank, world)
+    nl = len(mine)
+    if nl == 0:
+        raise SystemExit(f"rank {rank}: no channel (--live {args.live} over {world} ranks)")
+    tx = Tx.from_config(cfg)
+    spp = tx.symbols_per_packet
+    nfr = nsym // spp + 1
+    g = torch.Generator(device=dev); g.manual_seed(5000 + rank)
+    payloads = torch.randint(0, 256, (nl * nfr, 256), dtype=torch.uint8, device=dev, generator=g)
+    symbols = torch.empty(nl * nfr * spp, dtype=torch.uint8, device=dev)
+    tx.frame_packets_device(payloads.data_ptr(), nl * nfr, symbols.data_ptr())
+    caps = [torch.empty(2 * nsamp, dtype=torch.uint8, device=dev) for _ in range(nl)]
+    tx.modulate_device([symbols.data_ptr() + i * nfr * spp for i in range(nl)], [nsym] * nl, [c.data_ptr() for c in caps], [args.ebno] * nl, seeds=[5000 + c for c in mine])
+    torch.cuda.synchronize()
+    host = [c.cpu().pin_memory().numpy() for c in caps]               # the channels' rings in pinned host memory: the GPU reads the chunks itself
+    sent = payloads.cpu().numpy().reshape(nl, nfr, 256)
+    base = np.array([h.ctypes.data for h in host], np.uint64)
+    tick = cfg.Fs // 10
+    rl = RxBatch(cfg.Fs, cfg.Rs, cfg.M, framing=cfg.mode, max_iter=args.max_iter)
+    # warm-up: the first ticks of another handle (code objects, allocations of this size)
+    rw = RxBatch(cfg.Fs, cfg.Rs, cfg.M, framing=cfg.mode, max_iter=args.max_iter)
+    for k in range(0, min(nsamp, max(args.warmup, 1) * tick), tick):
+        rw.push_ptrs(base + np.uint64(2 * k), np.full(nl, min(tick, nsamp - k), np.int64), "cu8")
+    rw.flush(); rw.close()
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+    lat, npk, got = [], 0, [[] for _ in range(nl)]
+    gc.collect(); sync(); gc.disable()
+    t0 = time.perf_counter()
+    try:
+        for k in range(0, nsamp, tick):
+            nk = min(tick, nsamp - k)
+            tl = time.perf_counter()
+            npk += rl.push_ptrs(base + np.uint64(2 * k), np.full(nl, nk, np.int64), "cu8")
+            lat.append(time.perf_counter() - tl)
+            for c in range(nl):                                       # (the consumer's side of a tick: take the packets that completed in it)
+                if rl.npackets(c):
+                    got[c].append(rl.valid_payloads(c))
+    finally:
+        gc.enable()
+    sync()
+    dt = time.perf_counter() - t0
+    rl.flush()
+    # every CRC-valid packet must be one that was sent on its channel, in order
+    nvalid, wrong = 0, 0
+    for c in range(nl):
+        blob = b"".join(got[c]); pk = [blob[i:i + 256] for i in range(0, len(blob), 256)]
+        nvalid += len(pk)
+        sent_c = {bytes(sent[c, f]): f for f in range(nfr)}
+        idx = [sent_c.get(p, -1) for p in pk]
+        wrong += sum(1 for i in idx if i < 0) + sum(1 for a, b in zip(idx, idx[1:]) if b <= a)
+    mine_line = {"rank": rank, "channels": nl, "ms_per_tick_mean": round(1e3 * sum(lat) / len(lat), 3), "ms_per_tick_median": round(1e3 * float(np.median(lat)), 3),
+                 "ms_per_tick_worst": round(1e3 * max(lat), 3), "packets_completed": int(npk), "packets_valid": int(nvalid), "packets_not_as_sent": int(wrong),
+                 "chunks_read_by_the_gpu_itself_last_tick": rl.live_gathered(), "kernel": rl.last_kernel()}
+    rl.close()
+    dt_max = dt
+    per_rank = [mine_line]
+    if dist is not None:
+        onc = dist.get_backend() == "nccl"
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if onc else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt_max = float(t.item())
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine_line)
+    if rank == 0:
+        total_samples = args.live * nsamp
+        line = {"metric": "IQ Msamples/s demod+LDPC-decoded", "value": round(total_samples / dt_max / 1e6, 3), "unit": "Msamples/s", "n_gpus": world, "steps": len(lat), "warmup": args.warmup,
+                "ms_per_step": round(dt_max / len(lat) * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "mode": "exact (bit-identical to the reference pipe); live channels: a step is one 100 ms tick of every channel, host memory to packets in host memory (PCIe-inclusive)",
+                "config": {"workload": f"{cfg.name} {cfg.M}-FSK Rs={cfg.Rs} Fs={cfg.Fs} cu8 Eb/N0={args.ebno}dB, {args.live} CONCURRENT channels x {args.seconds:g}s in 100 ms ticks, "
+                                       f"channel c on rank c mod {world} (BASELINE config 5 as written)", "channels": args.live, "channels_per_gpu": nl, "samples_per_channel": nsamp,
+                           "framing": cfg.mode, "ldpc_max_iter": args.max_iter},
+                "x_realtime_sustained": round(args.seconds / dt_max, 1),
+                "packets_per_s": round(sum(p["packets_valid"] for p in per_rank) / dt_max, 1),
+                "packets_valid_total": sum(p["packets_valid"] for p in per_rank), "packets_not_as_sent_total": sum(p["packets_not_as_sent"] for p in per_rank),
+                "per_rank": per_rank,
+                "launch": f"{world} ranks, torch.distributed backend {dist.get_backend()}" if dist is not None else "one rank",
+                "roofline": None, "cpu_baseline": None,
+                "decoder_repeats": int(_lib.load().wenet_rx_decoder_repeats(None)),
+                "note": "roofline / cpu_baseline belong to the batch line (python bench.py): a tick of 16 channels is latency-bound (DESIGN.md 4.6)"}
+        if dist_note:
+            line["dist_note"] = dist_note
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -173,6 +279,9 @@ def main():
     ap.add_argument("--single-process", action="store_true",
                     help="drive --gpus N devices from ONE process: N handles (one per device) on N host threads, no torch.distributed (SURVEY.md 7-8's "
                          "'one host thread + stream set per GPU'); devices are shared modulo the device count when the box has fewer")
+    ap.add_argument("--live", type=int, default=0, metavar="CHANNELS",
+                    help="BASELINE config 5 as written: this many CONCURRENT channels (128) dealt to the ranks round-robin (16 per rank on 8 GPUs) and pushed in 100 ms ticks "
+                         "through wenet_rx_push from pinned host buffers; --seconds of signal per channel; the line carries every rank's tick latency and packets")
     ap.add_argument("--no-single-stream", action="store_true", help="(kept for the profiling scripts: implies nothing else is launched after the timed steps)")
     args = ap.parse_args()
     if args.no_single_stream:
@@ -220,6 +329,8 @@ def main():
     cfg = siggen.CONFIGS[args.config]()
     nsym = int(args.seconds * cfg.Rs)
     nsamp = nsym * cfg.Ts
+    if args.live > 0:
+        return live_mode(args, cfg, nsym, nsamp, rank, local_rank, world, dist, dist_note, ndev)
     # one process, N GPUs ("one host thread + stream set per device"): N workers, each on its own device with its own handle
     # (wenet_rx handles are per device, include/wenet_rx.h), driven by N host threads -- ctypes releases the GIL inside the library calls.
     # On a box with fewer GPUs than workers the devices are shared (index mod device count), as the multi-rank tests do.

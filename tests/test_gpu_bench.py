@@ -117,3 +117,27 @@ def test_single_process_two_handles_on_two_host_threads():
     nsamp = d["config"]["samples_per_capture"]
     assert abs(d["value"] - 2 * 16 * nsamp * 2 / (d["ms_per_step"] * 2e-3) / 1e6) < 1e-3 * d["value"]
     assert d["packets_valid_total"] > d["packets_valid_per_step_rank0"] > 0
+
+
+def test_live_channels_two_ranks_on_one_gpu_over_gloo():
+    """BASELINE config 5 AS WRITTEN (concurrent channels): bench.py --live deals the channels to the ranks round-robin and every rank pushes its
+    channels' 100 ms ticks through wenet_rx_push -- here 12 channels over two ranks sharing the one GPU (gloo); the line carries every rank's tick latency and packets,
+    every CRC-valid packet is one that was sent on its channel, in order."""
+    env = dict(os.environ, WENET_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = _torchrun(2, 29531, ["--gpus", "2", "--live", "12", "--seconds", "2", "--warmup", "1"], env, 900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _line(r.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["channels"] == 12 and d["config"]["channels_per_gpu"] == 6 and d["steps"] == 20
+    assert len(d["per_rank"]) == 2 and [p["rank"] for p in d["per_rank"]] == [0, 1]
+    for p in d["per_rank"]:
+        assert p["channels"] == 6 and p["packets_valid"] > 6 * 4 and p["packets_not_as_sent"] == 0 and p["ms_per_tick_mean"] > 0
+    nsamp = d["config"]["samples_per_channel"]
+    assert abs(d["value"] - 12 * nsamp / (d["ms_per_step"] * 20e-3) / 1e6) < 2e-3 * d["value"]
+    assert d["decoder_repeats"] == 0
+
+
+def test_live_channels_one_rank():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--live", "16", "--seconds", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _line(r.stdout)
+    assert d["n_gpus"] == 1 and d["config"]["channels_per_gpu"] == 16 and d["per_rank"][0]["packets_not_as_sent"] == 0 and d["per_rank"][0]["packets_valid"] > 16 * 2
