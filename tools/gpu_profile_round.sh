@@ -3,7 +3,7 @@
 # usage: gpu_profile_round.sh [captures] [tag] [extra bench args...]
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-B=${1:-3584}; TAG=${2:-r04}; shift; shift
+B=${1:-3584}; TAG=${2:-r05}; shift; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o k -- python $GRAFT_REPO_ROOT/bench.py --captures $B --steps 5 --warmup 1 --no-cpu-baseline --no-extras "$@" > $OUT/${TAG}_prof.log 2>&1

@@ -1,46 +1,52 @@
-# development aid: one GPU-box round = bench + rocprofv3 kernel stats + PMC pass (outputs under gpurun_out/)
-set -x
+# One round's measurement set on the GPU box, parametrised by the round's tag (usage: gpu_round.sh r05 [light]; rounds 1-4 had a script each)
+# Measurement set (outputs under gpurun_out/, copied into profiles/ afterwards): headline profile round, BASELINE config 4 (batch + single
+# stream), v1, batch sizes (multiples of a round and not), live channels (in the headline line), host feed (pinned and pageable), CLI timings, config 3 at scale, soaks.
+T=${1:-r05}; LIGHT=${2:-}
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
+bash tools/gpu_profile_round.sh 3584 ${T} > gpurun_out/${T}_round.log 2>&1
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
-B=${1:-512}
-python bench.py --captures $B --steps 10 --warmup 1 2>&1 | tail -1 > gpurun_out/bench_b$B.json; cat gpurun_out/bench_b$B.json
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o r01 -- python $GRAFT_REPO_ROOT/bench.py --captures $B --steps 10 --warmup 1 --no-cpu-baseline --no-single-stream > $GRAFT_REPO_ROOT/gpurun_out/prof_bench.log 2>&1
-head -8 $GRAFT_REPO_ROOT/gpurun_out/prof/r01_kernel_stats.csv | cut -c1-200
-# HBM traffic: separate PMC passes (FETCH_SIZE and WRITE_SIZE cannot share a pass), small batch to keep it short
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_fetch -o f -- python $GRAFT_REPO_ROOT/bench.py --captures 64 --steps 1 --warmup 0 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_write -o w -- python $GRAFT_REPO_ROOT/bench.py --captures 64 --steps 1 --warmup 0 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/pmc_write.log 2>&1
-ls $GRAFT_REPO_ROOT/gpurun_out/pmc_fetch $GRAFT_REPO_ROOT/gpurun_out/pmc_write
-python $GRAFT_REPO_ROOT/bench.py --captures 16 --steps 5 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 > $GRAFT_REPO_ROOT/gpurun_out/bench_b16.json
-python - <<'PY'
-import csv, glob, json, os
-root = os.environ["GRAFT_REPO_ROOT"] + "/gpurun_out"
-# per-launch durations of our kernels from the kernel trace (the stats file averages over warm-up launches too)
-with open(f"{root}/kernel_launches.csv", "w") as fo:
-    fo.write("kernel,grid_x,duration_ms\n")
-    for r in csv.DictReader(open(f"{root}/prof/r01_kernel_trace.csv")):
-        if "wenet" in r["Kernel_Name"]:
-            fo.write('"%s",%s,%.6f\n' % (r["Kernel_Name"].split("(")[0], r["Grid_Size_X"],
-                                        (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6))
-NS = 64 * 9600000
-out = {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (tools/gpu_round.sh), bench.py --captures 64 "
-               "--steps 1 --warmup 0; values are the 64-capture launch (614.4 M IQ samples). FETCH_SIZE is doubled (gfx950 counts "
-               "128-B requests at 64 B, MI355X_MICROARCH.md HBM section); WRITE_SIZE uncorrected.",
-       "samples_in_launch": NS, "kernels": {}}
-for tag, key in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
-    for f in glob.glob(f"{root}/{tag}/*counter_collection.csv"):
-        acc = {}
-        for r in csv.DictReader(open(f)):
-            k = r.get("Kernel_Name", "")
-            if "wenet" in k and r["Counter_Name"] == key:
-                acc[k[:60]] = max(acc.get(k[:60], 0.0), float(r["Counter_Value"]))
-        for k, v in acc.items():
-            out["kernels"].setdefault(k, {})[key + "_KB_raw"] = v
-for k, d in out["kernels"].items():
-    d["read_bytes_corrected"] = 2 * 1024 * d.get("FETCH_SIZE_KB_raw", 0.0)
-    d["write_bytes"] = 1024 * d.get("WRITE_SIZE_KB_raw", 0.0)
-    d["hbm_bytes"] = d["read_bytes_corrected"] + d["write_bytes"]
-    d["hbm_bytes_per_iq_sample"] = d["hbm_bytes"] / NS
-json.dump(out, open(f"{root}/pmc_traffic.json", "w"), indent=1)
-print(json.dumps({k[:30]: round(v["hbm_bytes_per_iq_sample"], 4) for k, v in out["kernels"].items()}))
+bash tools/gpu_profile_round.sh 1024 ${T}c4 --config 4fsk --max-iter 50 > gpurun_out/${T}c4_round.log 2>&1
+cd $GRAFT_REPO_ROOT
+python bench.py --config v1 --captures 3584 --no-extras 2>/dev/null | tail -1 > gpurun_out/${T}_bench_v1_b3584.json
+python bench.py --config 4fsk --captures 1 --max-iter 50 --no-extras 2>/dev/null | tail -1 > gpurun_out/${T}_bench_config4_b1.json
+for B in 16 256 768 1536 2048 3600 4000 5000 7168; do
+  python bench.py --captures $B --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > gpurun_out/${T}_bench_b$B.json
+done
+[ "$LIGHT" = light ] && exit 0
+python bench.py --captures 3584 --ppm 100 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > gpurun_out/${T}_bench_b3584_100ppm.json
+{
+  echo "# one 10 s v2 capture through the command lines (VERDICT r03 item 5): tools/cli_pipe.py and tools/cli_fused_time.py on the GPU box, reference binaries beside them"
+  python tools/cli_pipe.py 10 2>&1 | grep -v amdgpu.ids
+  python tools/cli_fused_time.py 10 2>&1 | grep -v amdgpu.ids
+} > gpurun_out/${T}_cli_times.txt 2>&1
+{
+  for k in pinned pageable; do python tools/host_feed.py 768 10 $k 2>&1 | grep -v amdgpu.ids; python tools/host_feed.py 256 10 $k 2>&1 | grep -v amdgpu.ids; done
+  python tools/host_feed.py 3584 10 pinned 2>&1 | grep -v amdgpu.ids
+} > gpurun_out/${T}_host_feed.txt 2>&1
+{
+  echo "# Parity soak, round ${T} (tools/soak.py, tools/soak_short.py): random captures (Eb/N0 3-15 dB, clock error 0 or +-1500 ppm, 1-13 packets) through the GPU chain,"
+  echo "# soft decisions and packets compared bit for bit with the CPU oracle."
+  echo "## batch demodulator, 7 captures per workgroup, v2 + v1, host-fed time slices of 20 000 samples"
+  WENET_RX_OCT=7 WENET_RX_SLICE_SAMPLES=20000 python tools/soak.py 500 41 2>&1 | tail -2
+  echo "## batch demodulator, 4 per workgroup, one launch per capture set"
+  WENET_RX_OCT=4 WENET_RX_NO_SLICES=1 python tools/soak.py 400 42 2>&1 | tail -2
+  echo "## default kernel choice (pipelined kernels), slices of 50 000 samples"
+  WENET_RX_SLICE_SAMPLES=50000 python tools/soak.py 200 43 2>&1 | tail -2
+  echo "## 4-FSK Ts 32: four captures + chain wave + sum wave per workgroup; the single-stream form"
+  WENET_RX_OCT=4 WENET_RX_OCT_ND=2 python tools/soak.py 120 44 4fsk 2>&1 | tail -2
+  WENET_RX_OCT=1 WENET_RX_OCT_ND=2 WENET_RX_OCT_HLP=1 WENET_RX_SLICE_SAMPLES=300000 python tools/soak.py 80 46 4fsk 2>&1 | tail -2
+  echo "## captures of 0..6 frames"
+  WENET_RX_OCT=7 python tools/soak_short.py 2>&1 | tail -1
+} > gpurun_out/${T}_soak.txt 2>&1
+python tools/sweep.py --config v2 --n 3584 --bins 17 --check-cpu 6 > gpurun_out/${T}_config3_sweep3584_v2.md 2>&1
+python tools/gpu_allout.py v2 3584 2 8 > gpurun_out/${T}_allout.txt 2>&1; python tools/gpu_allout.py 4fsk 1024 2 8 >> gpurun_out/${T}_allout.txt 2>&1
+python - $T <<'PY'
+import json, glob, sys
+for f in sorted(glob.glob("gpurun_out/%s*_bench_*.json" % sys.argv[1])):
+    try:
+        d = json.load(open(f))
+        print(f, d["value"], d["kernel_ms"], d["roofline"]["kernel"], d["roofline"].get("frac"), d["roofline"].get("traffic"), (d.get("cpu_baseline") or {}).get("value"))
+    except Exception as e:
+        print(f, "ERR", e)
 PY
+cat gpurun_out/${T}_soak.txt; cat gpurun_out/${T}_host_feed.txt; cat gpurun_out/${T}_allout.txt; cat gpurun_out/${T}_cli_times.txt
