@@ -1,0 +1,18 @@
+"""CPU: the built code objects obey the rule round 5 paid for -- every s_barrier is preceded, on every path, by a completed wait for the wavefront's LDS stores
+(tools/isa_barrier_audit.py).  hipcc 7.2 dropped that wait at the barrier heading the decoder's packet loop (the stores arrive over the loop's back edges), and on gfx950 a
+read behind the barrier then overtook the store about once in 10^6 packets; the kernels now write the wait out (WR_LDS_BARRIER / lds_barrier), and this test keeps it so."""
+import glob
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_no_barrier_is_reached_by_an_lds_store_in_flight():
+    objs = sorted(glob.glob(os.path.join(ROOT, "wenet_amd", "csrc", "*.o")))
+    assert objs, "build first (python -c 'import __graft_entry__ as g; g.build()')"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_barrier_audit.py")] + objs, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+    last = r.stdout.strip().splitlines()[-1]
+    assert last.endswith(" 0 findings") and int(last.split()[0]) > 200, last        # (297 barriers in the round-5 build)
