@@ -16,3 +16,17 @@ def test_no_barrier_is_reached_by_an_lds_store_in_flight():
     assert r.returncode == 0, r.stdout[-3000:]
     last = r.stdout.strip().splitlines()[-1]
     assert last.endswith(" 0 findings") and int(last.split()[0]) > 200, last        # (297 barriers in the round-5 build)
+
+
+def test_the_audit_sees_the_dropped_wait_in_the_minimal_kernel(tmp_path):
+    """tools/ubench/syncthreads_loop_header.hip is the decoder's packet loop reduced to 45 lines: hipcc 7.2 emits its loop-header barrier without the wait for the claim store.
+    The audit must find exactly that (if a later compiler keeps the wait, the finding is gone and this test says so by skipping)."""
+    import pytest
+    obj = str(tmp_path / "slh.o")
+    c = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-c", os.path.join(ROOT, "tools", "ubench", "syncthreads_loop_header.hip"), "-o", obj],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert c.returncode == 0, c.stdout[-2000:]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_barrier_audit.py"), obj], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    if r.returncode == 0:
+        pytest.skip("this compiler keeps the wait at the loop header: " + r.stdout.strip().splitlines()[-1])
+    assert "ds_write_b32" in r.stdout and "offset:39184" in r.stdout, r.stdout[-2000:]
