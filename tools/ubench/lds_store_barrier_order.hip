@@ -1,10 +1,8 @@
-// Minimal reproducer (round 5): an LDS store issued right before s_barrier WITHOUT a completion wait can be overtaken by another wavefront's read behind the barrier on gfx950.
-//
-// What the decoder did (wenet_decode_kernel before round 5, the empty-packet-slot path): thread 0 writes the workgroup's next claim into an LDS cell -- ds_write_b32, s_branch,
-// s_barrier with nothing in between -- and every wavefront reads the cell right behind the barrier.  hipcc 7.2's __syncthreads() is fence(release, "workgroup", "local") +
-// s_barrier + fence(acquire, ...): for an LDS-only release fence the AMDGPU backend emits no s_waitcnt ("LDS operations for all waves are executed in a total global ordering as
-// observed by all waves", SIMemoryLegalizer) -- so nothing made the store complete before the barrier.  About once in 10^6 packets the second or fourth wavefront of the
-// workgroup read the cell's OLD value, took another path through the barriers than its siblings, and the workgroup decoded out of step for one packet or for the rest of the launch.
+// The BARE sequence (round 5): an LDS store issued right before s_barrier without a completion wait, read by the other wavefronts right behind the barrier.  This is what
+// wenet_decode_kernel's empty-slot path came down to (thread 0's claim store: ds_write_b32, s_branch, s_barrier -- hipcc 7.2 emitted no s_waitcnt lgkmcnt(0) at that loop header,
+// tools/ubench/syncthreads_loop_header.hip) and what made one wavefront in ~10^6 packets read the cell stale.  In THIS form -- steps of equal shape, light or heavy LDS load
+// beside them -- 3*10^9 reads returned no stale value: the window needs more of the decoder's shape.  tools/ubench/claim_cell_race.hip (the packet loop's skeleton: a global
+// atomic in front of the store, a tenth of the steps empty, barrier-separated passes over a message array otherwise) DOES reproduce it: profiles/r05_claim_cell_race.txt.
 //
 // Here: workgroups of eight wavefronts, four per CU.  Per step thread 0 stores the step number into cell[step & 1]; then s_barrier (mode 0: no wait, exactly the sequence
 // above; mode 1: s_waitcnt lgkmcnt(0) first); every wavefront reads the cell and compares; a little LDS traffic of varying length between the steps so that the wavefronts
