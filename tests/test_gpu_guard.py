@@ -98,3 +98,37 @@ def test_dense_entry_point_and_live_ticks_are_guarded_too():
     for a, b in zip(ref, got):
         assert (np.asarray(a) == np.asarray(b)).all()
     assert int(L.wenet_rx_decoder_repeats(None)) >= before
+
+
+def test_live_ticks_are_guarded_too():
+    """the same provocation on live channels (wenet_rx_push): a tick's packets are decoded again inside the call, the caller sees what the undisturbed stream gives"""
+    from wenet_amd.rx import RxBatch
+    cfg, caps, nsamp = _batch(B=24, secs=1.0)
+    host = [c.cpu().numpy() for c in caps]
+    tick = cfg.Fs // 10
+
+    def run():
+        rx = RxBatch(cfg.Fs, cfg.Rs, cfg.M, framing=cfg.mode)
+        out = [[] for _ in host]
+        for k in range(0, nsamp, tick):
+            rx.push([h[2 * k: 2 * min(k + tick, nsamp)] for h in host], "cu8")
+            for c in range(len(host)):
+                p = rx.packets(c)
+                out[c].append((p["bytes"].copy(), p["iter"].copy(), p["crc_ok"].copy(), p["start"].copy()))
+        rep = rx.decoder_repeats()
+        rx.flush(); rx.close()
+        return out, rep
+
+    os.environ.pop("WENET_RX_DBG_DESYNC", None)
+    ref, rep0 = run()
+    assert rep0 == 0 and sum(len(t[1]) for c in ref for t in c) > 24 * 10
+    os.environ["WENET_RX_DBG_DESYNC"] = "1"
+    try:
+        got, rep = run()
+    finally:
+        os.environ.pop("WENET_RX_DBG_DESYNC", None)
+    assert rep > 0
+    for c, (a, b) in enumerate(zip(ref, got)):
+        for t, (x, y) in enumerate(zip(a, b)):
+            for u, v in zip(x, y):
+                assert u.shape == v.shape and (u == v).all(), f"channel {c}, tick {t}"
