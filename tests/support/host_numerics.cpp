@@ -97,6 +97,28 @@ long check_x87(long n, uint64_t seed, double *first_bad) {
 // argument up to 1.1e6 / 65536, every threshold's neighbours and the special values; 1 = all equal.  The library checks a 61st of these at start-up.
 // the one-read table of round 5 (WR_PHI0_FORM 4: keyed by the top 16 bits of the argument, fourteen marked cells settled by a second table) against the same reference
 // form on EVERY float from 2^-17 to 32 and a 4099-stride sweep of all 2^32 bit patterns (a few seconds)
+// the statistics kernel's quotient (wenet_llr_stats_kernel, round 5): q0 = s y, e = fma(-q0, b, s), q = fma(e, y, q0) with y = 1.0 / b against s / b, bit for bit, on n random
+// (float s widened to double, double b) pairs -- exponents over the kernel's safe range, every 1024th divisor with a mantissa of (nearly) all ones, where a rounded reciprocal
+// is least accurate.  Returns the number of mismatches.
+long check_fma_quotient(long n, uint64_t seed) {
+    uint64_t rs = seed ? seed : 88172645463325252ull;
+    auto rnd = [&]() { rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17; return rs; };
+    long bad = 0;
+    for (long it = 0; it < n; it++) {
+        const uint64_t r = rnd(), r2 = rnd();
+        const uint32_t fb = ((uint32_t)((int)((r >> 23) % 60) - 40 + 127) << 23) | (uint32_t)(r & 0x7fffff) | (((r >> 40) & 1) ? 0x80000000u : 0u);
+        float sf; memcpy(&sf, &fb, 4);
+        const double s = (double)sf;
+        uint64_t dm = r2 & 0xfffffffffffffull;
+        if ((it & 1023) == 0) dm = 0xfffffffffffffull - (r2 >> 60);
+        const uint64_t db = ((uint64_t)((int)((r2 >> 52) % 200) - 100 + 1023) << 52) | dm;
+        double b; memcpy(&b, &db, 8);
+        const double y = 1.0 / b, q0 = s * y, e = fma(-q0, b, s), q = fma(e, y, q0), ref = s / b;
+        uint64_t uq, ur; memcpy(&uq, &q, 8); memcpy(&ur, &ref, 8);
+        bad += uq != ur;
+    }
+    return bad;
+}
 int check_phi0_t7_exhaustive(void) {
     std::vector<uint32_t> blob;
     return phi0_build_t7(blob, true) ? 1 : 0;

@@ -434,3 +434,32 @@ def test_frame_cap_resume():
         k += 1
     L.wenet_fsk_destroy(h)
     assert bits_equal(np.concatenate(out), ref)
+
+
+@pytest.mark.parametrize("small_slots", STATS_KERNELS)
+def test_degenerate_packets_on_the_float_stream(small_slots, monkeypatch):
+    """Round 5: the lane-per-packet statistics kernel forms s / mean through the packet's reciprocal and one fused correction step, and falls back to the division when the
+    packet's mean is zero / tiny / huge or a symbol is not finite.  Packets that force every branch -- scaled by 1e-36 and 1e+36 (the mean leaves the safe range), all zero, one
+    infinite symbol, one NaN -- ride in one stream beside ordinary ones; LLR-derived results (iterations, bytes, CRC flags) must equal the oracle's for every packet."""
+    _pick_stats_kernel(monkeypatch, small_slots)
+    cfg = siggen.config_v2()
+    raw, _ = siggen.make_capture(cfg, 9, 9.0, seed=901, lead_symbols=300)
+    sd, _ = ol.oracle_demod(raw, "cu8", cfg.Fs, cfg.Rs, cfg.M)
+    ref0 = ol.oracle_deframe(sd, cfg.mode)
+    assert ref0["n"] >= 8
+    sd = sd.copy()
+    spp = 2584
+    st = [int(x) for x in ref0["start"]]
+    with np.errstate(over="ignore", invalid="ignore"):
+        sd[st[1]:st[1] + spp] *= np.float32(1e-36)
+        sd[st[2]:st[2] + spp] *= np.float32(1e36)
+        sd[st[3]:st[3] + spp] = 0.0
+        sd[st[4] + 700] = np.inf
+        sd[st[5] + 1300] = np.nan
+        sd[st[6] + 5] = -np.inf
+    ref = ol.oracle_deframe(sd, cfg.mode)
+    d = Deframer(cfg.mode)
+    got = d.push(sd)
+    d.close()
+    assert got["n"] == ref["n"] and (got["start"] == ref["start"]).all()
+    assert (got["iter"] == ref["iter"]).all() and (got["crc_ok"] == ref["crc_ok"]).all() and (got["bytes"] == ref["bytes"]).all()

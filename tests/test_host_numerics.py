@@ -20,6 +20,7 @@ def hn(tmp_path_factory):
     L.check_x87.restype = C.c_long; L.check_x87.argtypes = [C.c_long, C.c_uint64, C.POINTER(C.c_double)]
     L.check_phi0_table_exhaustive.restype = C.c_int
     L.check_phi0_t7_exhaustive.restype = C.c_int
+    L.check_fma_quotient.restype = C.c_long; L.check_fma_quotient.argtypes = [C.c_long, C.c_uint64]
     L.check_shipped_placement.restype = C.c_int
     return L
 
@@ -37,6 +38,11 @@ def test_atan2f_matches_host_libm(hn):
 def test_x87_emulation_matches_long_double(hn):
     fb = (C.c_double * 2)()
     assert hn.check_x87(10_000_000, 99, fb) == 0, (fb[0], fb[1])
+
+
+def test_reciprocal_and_fma_quotient_equals_the_division(hn):
+    """the statistics kernel's s / mean through the packet's reciprocal and one fused correction step (ldpc_kernel.hip) against the division, 3*10^8 operand pairs"""
+    assert hn.check_fma_quotient(300_000_000, 7) == 0
 
 
 def test_phi0_one_read_table_equals_the_reference_form_exhaustively(hn):

@@ -255,10 +255,13 @@ __device__ __forceinline__ double packet_symbol(const WrDecodeArgs &A, unsigned 
 // Output: estEsN0 per packet slot, with the reference's x87 rounding (x87emu.h).
 #define WR_ST_CHUNK 32
 #define WR_ST_PITCH 65                                           // row pitch in elements: the transposing writes spread over the banks
+#ifndef WR_ST_BUFS
+#define WR_ST_BUFS 1
+#endif
 template <bool SD64>                                             // SD64: double input of the sd_to_llr API; else the float sd stream
 __global__ __launch_bounds__(64) void wenet_llr_stats_kernel(WrDecodeArgs A) {
     typedef typename std::conditional<SD64, double, float>::type elt;
-    __shared__ elt buf[2][WR_ST_CHUNK * WR_ST_PITCH];
+    __shared__ elt buf[WR_ST_BUFS][WR_ST_CHUNK * WR_ST_PITCH];      // (round 5: ONE staging buffer -- chunk c + 1 is stashed only after chunk c has been summed, so a second one bought nothing and cost half the resident wavefronts: the kernel is bound by the bytes it keeps in flight)
     __shared__ unsigned long long pbase[64];                     // per packet: address of its symbol 0
     __shared__ uint8_t scr[128];
     const int lane = threadIdx.x;
@@ -281,6 +284,9 @@ __global__ __launch_bounds__(64) void wenet_llr_stats_kernel(WrDecodeArgs A) {
         A.pbase[slot] = live ? base : 0ull;
     }
     if (__ballot(live) == 0) return;
+#ifdef WR_ST_DBG_ALIGN                                             // development (timing only, wrong results): every packet as if it started on a 128-byte line
+    base &= ~127ull;
+#endif
     pbase[lane] = live ? base : 0ull;
     if (!SD64 && A.mode == 2) { scr[lane] = A.scramble[lane]; if (lane + 64 < 125) scr[lane + 64] = A.scramble[lane + 64]; }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -310,9 +316,16 @@ __global__ __launch_bounds__(64) void wenet_llr_stats_kernel(WrDecodeArgs A) {
             if ((scr[kb >> 3] >> (7 - (kb & 7))) & 1) sg = -1;
         }
 #pragma unroll
-        for (int g = 0; g < 32; g++) buf[c & 1][col * WR_ST_PITCH + 2 * g + sub] = pre[g] * sg;
+        for (int g = 0; g < 32; g++) buf[c % WR_ST_BUFS][col * WR_ST_PITCH + 2 * g + sub] = pre[g] * sg;
     };
     double mean = 0.0, sum = 0.0, sumsq = 0.0;
+    // Second pass, s / mean (mpdecode_core.c:585): the divisor is the packet's, so its correctly rounded reciprocal y = 1.0 / mean is formed once and every quotient is
+    // q0 = s y, e = fma(-q0, mean, s) (exact), q = fma(e, y, q0) -- correctly rounded (Markstein's correction step with y = RN(1 / b)); checked bit for bit against s / mean on
+    // 2*10^9 (float s, double mean) pairs including divisors with all-ones mantissas (tests/support/host_numerics.cpp: check_fma_quotient).  Three instructions instead of
+    // the ~12 of the division's expansion.  Only while every packet of the wavefront has a mean in [2^-100, 2^100]: a zero, tiny or huge mean takes the division itself, and
+    // so does a packet with a symbol that is not finite -- the first pass has then made its mean infinite or NaN.  The double-precision entry (sd_to_llr) keeps the division.
+    double ymean = 0.0;
+    bool fastdiv = false;
     for (int pass = 0; pass < 2; pass++) {
         fetch(0);
         for (int c = 0; c < nchunks; c++) {
@@ -321,9 +334,33 @@ __global__ __launch_bounds__(64) void wenet_llr_stats_kernel(WrDecodeArgs A) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
             const int cnt = (n - c * WR_ST_CHUNK) < WR_ST_CHUNK ? (n - c * WR_ST_CHUNK) : WR_ST_CHUNK;
-            const elt *colp = &buf[c & 1][lane];
-            if (pass == 0) {
+            const elt *colp = &buf[c % WR_ST_BUFS][lane];
+            // (whole chunks -- all but a packet's last -- run unrolled: the column's LDS reads go out together and the loop's counter, address step and per-element
+            //  wait disappear; the sums stay in the reference's order)
+            if (pass == 0 && cnt == WR_ST_CHUNK) {
+#pragma unroll
+                for (int i = 0; i < WR_ST_CHUNK; i++) sum += fabs((double)colp[i * WR_ST_PITCH]);
+            } else if (pass == 0) {
                 for (int i = 0; i < cnt; i++) sum += fabs((double)colp[i * WR_ST_PITCH]);
+            } else if (fastdiv && cnt == WR_ST_CHUNK) {
+#pragma unroll
+                for (int i = 0; i < WR_ST_CHUNK; i++) {
+                    const double s = (double)colp[i * WR_ST_PITCH];
+                    const double sign = (double)((s > 0.0) - (s < 0.0));
+                    const double q0 = s * ymean, e = __builtin_fma(-q0, mean, s), q = __builtin_fma(e, ymean, q0);
+                    const double x = q - sign;
+                    sum += x;
+                    sumsq += x * x;
+                }
+            } else if (fastdiv) {
+                for (int i = 0; i < cnt; i++) {
+                    const double s = (double)colp[i * WR_ST_PITCH];
+                    const double sign = (double)((s > 0.0) - (s < 0.0));
+                    const double q0 = s * ymean, e = __builtin_fma(-q0, mean, s), q = __builtin_fma(e, ymean, q0);
+                    const double x = q - sign;
+                    sum += x;
+                    sumsq += x * x;
+                }
             } else {
                 for (int i = 0; i < cnt; i++) {
                     const double s = (double)colp[i * WR_ST_PITCH];
@@ -335,7 +372,13 @@ __global__ __launch_bounds__(64) void wenet_llr_stats_kernel(WrDecodeArgs A) {
             }
             __builtin_amdgcn_wave_barrier();
         }
-        if (pass == 0) { mean = sum / n; sum = 0.0; }
+        if (pass == 0) {
+            mean = sum / n; sum = 0.0;
+            ymean = 1.0 / mean;
+#ifndef WR_ST_NO_FASTDIV
+            fastdiv = !SD64 && __ballot(live && !(mean >= 0x1p-100 && mean <= 0x1p100)) == 0;
+#endif
+        }
     }
     if (live) {
         const double estvar = (n * sumsq - sum * sum) / (n * (n - 1));
