@@ -178,8 +178,12 @@ int wenet_rx_collect(wenet_rx *rx);
  * checked before anything is touched (a refused call leaves the streams as they were); a device or allocation failure later in a tick ends the streams. */
 long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *chunk, const long long *nsamples, int fmt);
 int wenet_rx_flush(wenet_rx *rx);
-/* How many of the last tick's chunks the GPU read from the caller's buffers itself (one gather kernel over PCIe instead of one copy per channel):
- * every chunk in PINNED host memory (hipHostMalloc / hipHostRegister; torch pin_memory) goes that way, pageable ones are copied as before. */
+/* How many of the last tick's chunks the GPU read from the caller's buffers where they lie (one gather kernel over PCIe instead of one copy per channel):
+ * every chunk in PINNED host memory (hipHostMalloc / hipHostRegister; torch pin_memory) goes that way; a chunk in pageable memory is first copied by the
+ * calling thread, piece by piece, into the handle's pinned staging block and fetched from there.  Either way the chunks cross the link in pieces in TIME order
+ * and -- up to one channel per compute unit -- the demodulator runs beside the gather and waits for a piece only when its read-ahead reaches it (the two
+ * kernels need the device to run them concurrently: under a tool that serialises kernels set WENET_RX_NO_LIVE_OVERLAP=1, which orders them; a demodulator
+ * that has waited two seconds for a piece gives up and the call fails with -6, ending the streams). */
 int wenet_rx_live_gathered(wenet_rx *rx);
 /* Pin a host buffer the caller already owns (a per-channel ring, a numpy array) so that chunks inside it go the gather way: hipHostRegister / hipHostUnregister
  * for callers that do not link HIP themselves.  Once per buffer, not per tick (registration costs about a millisecond per 20 MB).  0, or < 0 on error. */

@@ -149,6 +149,32 @@ def test_live_pinned_buffers_are_read_by_the_gpu_itself(name, fmt, mean, pinned)
     assert _check(cfg, caps, fmt, out, frames) > 0
 
 
+@pytest.mark.parametrize("switch", ["WENET_RX_NO_LIVE_OVERLAP", "WENET_RX_LIVE_GATHER_SHARED_CU", "WENET_RX_LIVE_COPIES"])
+@pytest.mark.parametrize("pinned", [True, False])
+def test_live_tick_paths_behind_their_switches(monkeypatch, switch, pinned):
+    """Round 5: by default the pipelined demodulator runs BESIDE the gather kernel and takes the chunks piece by piece as they cross PCIe (arrival words, agent-scope
+    loads), the gather on compute units of its own (LDS reservation), the results leave through one export kernel.  The older paths stay behind switches: the gather
+    finished before the demodulator starts; gather and demodulator sharing compute units; results through five copies.  Same bits on every path."""
+    monkeypatch.setenv(switch, "1")
+    cfg = siggen.config_v2()
+    rng = np.random.default_rng(len(switch) + int(bool(pinned)))
+    caps = [siggen.make_capture(cfg, 3, 9.0, seed=2900 + ch, ppm=(150.0 if ch == 1 else 0.0))[0] for ch in range(9)]
+    cuts = [_ragged_cuts(rng, c.size // 2, 60000) for c in caps]
+    out, frames, _ = _run_live(cfg, caps, "cu8", cuts, pinned=pinned)
+    assert _check(cfg, caps, "cu8", out, frames) > 0
+
+
+def test_live_long_ticks_arrive_in_pieces_while_the_demodulator_runs():
+    """ticks long enough that every piece of a chunk is many frames (the demodulator really waits for pieces in the middle of its launch), pageable and pinned
+    channels side by side, a slipping channel among them; more channels than the gather has workgroups"""
+    cfg = siggen.config_v2()
+    rng = np.random.default_rng(41)
+    caps = [siggen.make_capture(cfg, 12, 8.5, seed=4100 + ch, ppm=(-180.0 if ch == 3 else 0.0))[0] for ch in range(40)]
+    cuts = [_ragged_cuts(rng, c.size // 2, 220000) for c in caps]           # ~0.19 s per tick on average
+    out, frames, _ = _run_live(cfg, caps, "cu8", cuts, pinned="mixed")
+    assert _check(cfg, caps, "cu8", out, frames) > 0
+
+
 def test_live_many_channels_through_the_batch_demodulator(monkeypatch):
     """enough channels that the per-tick launch takes the batch demodulator (one wavefront per capture) with carried state"""
     monkeypatch.setenv("WENET_RX_OCT", "7")

@@ -114,6 +114,15 @@ __device__ __forceinline__ uint2 load_raw(const void *raw, int fmt, long long id
     else { const unsigned long long v = ((const WR_GLOBAL unsigned long long *)(uintptr_t)raw)[idx]; r.x = (unsigned)v; r.y = (unsigned)(v >> 32); }
     return r;
 }
+// the same load performed at AGENT scope (sc1: past this XCD's L2): samples that another kernel, on other compute units, is writing beside this one
+// (live ticks, WrChan::arrive) -- no stale line of the caller's own L2 / vector cache can answer it, so the reader needs no cache invalidate behind the arrival word
+__device__ __forceinline__ uint2 load_raw_agent(const void *raw, int fmt, long long idx) {
+    uint2 r = make_uint2(0u, 0u);
+    if (fmt == WR_FMT_CU8 || fmt == WR_FMT_S16_REAL) r.x = __hip_atomic_load(&((const unsigned short *)raw)[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else if (fmt == WR_FMT_CS16) r.x = __hip_atomic_load(&((const unsigned int *)raw)[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else { const unsigned long long v = __hip_atomic_load(&((const unsigned long long *)raw)[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); r.x = (unsigned)v; r.y = (unsigned)(v >> 32); }
+    return r;
+}
 // KPRE raw samples per lane (sample index base + lane + 64k, clamped to `last`): the format switch is
 // hoisted so that each arm is KPRE back-to-back loads with nothing waiting on them
 template <int KPRE>

@@ -153,6 +153,7 @@ __global__ __launch_bounds__(WP_THREADS, 4) void wenet_demod_tri_kernel(WrDemodC
         // first 4*Nmax samples into the ring
         const long long last = C.nsamples - 1;
         for (long long i = ctid; i < 4LL * Nmax; i += WT_CTHREADS)
+#define WP_LOAD_SAMPLE(i_) load_raw(C.raw, fmt_k, (i_))
 #include "demod_pipe_shared_1.inc"
     auto chain = [&](int j, int nin_j, int capmask) {                   // C(j) of the captures in capmask (lanes 4c..4c+3 carry capture c)
         // (the packed form of the one-capture kernel -- one lane per capture and tone, shorter dependent path -- measured 9 % slower
@@ -420,5 +421,6 @@ __global__ __launch_bounds__(WP_THREADS, 4) void wenet_demod_tri_kernel(WrDemodC
         }
     }
 #undef RIDX
+#undef WP_LOAD_SAMPLE
 }
 

@@ -393,10 +393,29 @@ __global__ __launch_bounds__(64) void wenet_llr_stats_kernel(WrDecodeArgs A) {
 // each (the second pass's two on different wavefronts, side by side).  Same expressions in the same order: same bits.  ~25 us per packet and workgroup; wr_launch_decode takes this
 // kernel up to WR_ST_SMALL_SLOTS packet slots (beyond that the throughput of one LANE per packet wins).
 #define WR_ST_SMALL_SLOTS 32768
+// sum of f(x[i]) in index order on ONE lane, x in LDS: the next eight terms are read while the current eight are added (written as one loop the compiler waits for every
+// pair of reads in front of the four adds that use them: 27 cycles per term instead of the add's own ~9 -- 29 us per pass over a packet)
+template <typename F>
+__device__ __forceinline__ double ordered_sum(const double *x, int n, F f) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const d2 *p = (const d2 *)x;
+    double sum = 0.0;
+    int i = 0;
+    if (n >= 8) {
+        d2 a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3];
+        for (; i + 8 <= n; i += 8) {
+            const d2 b0 = p[(i >> 1) + 4], b1 = p[(i >> 1) + 5], b2 = p[(i >> 1) + 6], b3 = p[(i >> 1) + 7];      // (up to 15 terms past n: inside the array's padding, not used)
+            sum += f(a0.x); sum += f(a0.y); sum += f(a1.x); sum += f(a1.y); sum += f(a2.x); sum += f(a2.y); sum += f(a3.x); sum += f(a3.y);
+            a0 = b0; a1 = b1; a2 = b2; a3 = b3;
+        }
+    }
+    for (; i < n; i++) sum += f(x[i]);
+    return sum;
+}
 template <bool SD64>
 __global__ __launch_bounds__(256) void wenet_llr_stats_small_kernel(WrDecodeArgs A) {
     typedef typename std::conditional<SD64, double, float>::type elt;
-    __shared__ double xs[3072];
+    __shared__ __attribute__((aligned(16))) double xs[3072 + 16];              // (+ 16: ordered_sum reads a block ahead)
     __shared__ double red[4];
     const int tid = threadIdx.x;
     const long long slot = blockIdx.x;
@@ -428,12 +447,7 @@ __global__ __launch_bounds__(256) void wenet_llr_stats_small_kernel(WrDecodeArgs
         xs[i] = (double)v;
     }
     __syncthreads();
-    if (tid == 0) {                                                             // mpdecode_core.c:575-579
-        double sum = 0.0;
-#pragma unroll 8
-        for (int i = 0; i < n; i++) sum += fabs(xs[i]);
-        red[0] = sum / n;
-    }
+    if (tid == 0) red[0] = ordered_sum(xs, n, [](double x) { return fabs(x); }) / n;      // mpdecode_core.c:575-579
     __syncthreads();
     const double mean = red[0];
     for (int i = tid; i < n; i += 256) {                                        // mpdecode_core.c:583-587: x = sd/mean - sign(sd)
@@ -442,18 +456,8 @@ __global__ __launch_bounds__(256) void wenet_llr_stats_small_kernel(WrDecodeArgs
         xs[i] = s / mean - sign;
     }
     __syncthreads();
-    if (tid == 0) {
-        double sum = 0.0;
-#pragma unroll 8
-        for (int i = 0; i < n; i++) sum += xs[i];
-        red[1] = sum;
-    }
-    if (tid == 64) {
-        double sumsq = 0.0;
-#pragma unroll 8
-        for (int i = 0; i < n; i++) { const double x = xs[i]; sumsq += x * x; }
-        red[2] = sumsq;
-    }
+    if (tid == 0) red[1] = ordered_sum(xs, n, [](double x) { return x; });
+    if (tid == 64) red[2] = ordered_sum(xs, n, [](double x) { return x * x; });
     __syncthreads();
     if (tid == 0) {
         const double sum = red[1], sumsq = red[2];
@@ -1049,12 +1053,20 @@ extern "C" hipError_t wr_launch_decode(const WrDecodeArgs *args, hipStream_t str
     if (ncu == 0) { hipDeviceProp_t p; int dev = 0; (void)hipGetDevice(&dev); ncu = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }
     const long long want = (long long)4 * ncu;                       // four workgroups (32 wavefronts) per CU fill it; they loop over the packet slots
     const unsigned grid = (unsigned)(slots < want ? slots : want);
-    hipError_t e = hipMemsetAsync(args->work, 0, sizeof(unsigned), stream);
-    if (e != hipSuccess) return e;
-    if (args->agree && !args->redo_in) {                             // agreement guard: no records, no packets listed (a repeat launch: the CRC kernel cleared the listed packets' records)
-        e = hipMemsetAsync(args->agree, 0, (size_t)slots * (WR_DEC_THREADS / 64) * sizeof(unsigned), stream);
-        if (e == hipSuccess) e = hipMemsetAsync(args->redo, 0, sizeof(unsigned), stream);
+    hipError_t e;
+    const size_t agree_bytes = (size_t)slots * (WR_DEC_THREADS / 64) * sizeof(unsigned);
+    if (args->agree && !args->redo_in && (char *)args->work + 4096 == (char *)args->agree && (char *)args->agree + agree_bytes == (char *)args->redo) {
+        // the scratch block as carve_decode_scratch lays it out: work counters | records | the list's count -- one fill (three cost a live tick 10 us)
+        e = hipMemsetAsync(args->work, 0, 4096 + agree_bytes + 256, stream);      // (the list's count and its first entries: a whole number of 256-byte units is ONE fill kernel)
         if (e != hipSuccess) return e;
+    } else {
+        e = hipMemsetAsync(args->work, 0, sizeof(unsigned), stream);
+        if (e != hipSuccess) return e;
+        if (args->agree && !args->redo_in) {                         // agreement guard: no records, no packets listed (a repeat launch: the CRC kernel cleared the listed packets' records)
+            e = hipMemsetAsync(args->agree, 0, agree_bytes, stream);
+            if (e == hipSuccess) e = hipMemsetAsync(args->redo, 0, sizeof(unsigned), stream);
+            if (e != hipSuccess) return e;
+        }
     }
     const long long items = args->redo_in ? (long long)args->redo_n : slots;
     hipLaunchKernelGGL(wenet_decode_kernel, dim3((unsigned)(items < (long long)grid ? items : (long long)grid)), dim3(WR_DEC_THREADS), lds, stream, *args);

@@ -159,6 +159,13 @@ struct WrChan {
     long long  *prof;           // development: per-phase cycle totals (profiling instantiation only)
     long long  *prof2;          // development: sub-phase totals of the pipelined kernel's D/T wave
     unsigned char *big;         // frame scratch of WrDemodCfg::big_bytes (only when WrDemodCfg::big)
+    // Live ticks (wenet_rx_push) through the pipelined kernel: the samples behind `arrive_have` may still be on their way over PCIe when the launch starts --
+    // wenet_live_gather_kernel (its own stream) publishes every channel's chunk piece by piece, the demodulator waits for a piece only when its read-ahead reaches it.
+    const unsigned long long *arrive;   // [arrive_n], piece p: (tick number << 32 | samples of this block in place once pieces 0..p have landed); null: everything is in place
+    unsigned    arrive_seq;     // this tick's number (a word of an earlier tick reads as "not yet")
+    int         arrive_n;
+    long long   arrive_have;    // samples in place at launch (what the previous tick left over)
+    unsigned   *arrive_err;     // set to 1 if a piece did not arrive within ~2 s (the host then ends the streams)
 };
 
 // ---- time slices of a device-resident batch inside ONE launch of the batch demodulator (demod_oct_impl.h) ----

@@ -15,6 +15,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <algorithm>
@@ -510,9 +511,9 @@ void fill_decode_tables(WrDecodeArgs &a, const LdpcTables *t) {
 }
 // the decoder's scratch block (wr_dec_scratch_bytes): estimates | work counters | packet addresses | exit records | two repeat lists
 void carve_decode_scratch(WrDecodeArgs &a, char *base, size_t nslots) {
-    a.esn0 = (double *)base;
-    a.work = (unsigned *)(base + nslots * 8);
-    a.pbase = (unsigned long long *)(base + nslots * 8 + 4096);
+    a.esn0 = (double *)base;                                            // | Es/N0 | packet bases | work counters (4 KB) | agreement records | two repeat lists (8 KB) |
+    a.pbase = (unsigned long long *)(base + nslots * 8);               //   (counters, records and the first list's count lie together: wr_launch_decode clears them with one fill)
+    a.work = (unsigned *)(base + nslots * 16);
     a.agree = getenv("WENET_RX_NO_GUARD") ? nullptr : (unsigned *)(base + nslots * 16 + 4096);
     a.redo = (unsigned *)(base + nslots * 48 + 4096);
     if (const char *e = getenv("WENET_RX_DBG_DESYNC")) a.dbg_inject = atoi(e);                // tests: a wavefront that stays in the iteration loop
@@ -960,16 +961,32 @@ struct wenet_rx {
     std::vector<WrDeframeState> h_dstates;
     // results land in ONE pinned host block with two async copies (states | deframer states, then packet slots | starts)
     void *h_pin = nullptr; size_t h_pin_cap = 0;
-    DevBuf d_live_gather;                   // live ticks: the gather list (chunks in pinned host memory)
-    int live_gathered = 0;                  // chunks of the last tick the device read itself
+    DevBuf d_live_tab, d_live_arrive;       // live ticks: channel table | deframer table | new-sample counts | gather list (one upload); the channels' arrival words (WrChan::arrive)
+    int live_gathered = 0;                  // chunks of the last tick the device read where the caller keeps them (pinned host memory)
+    void *h_stage = nullptr; size_t h_stage_cap = 0;      // live ticks: pinned staging block for chunks in pageable memory
+    const char *d_stage_view = nullptr;     // the address the device reads it at
+    hipEvent_t live_ev[2] = {nullptr, nullptr};           // [0] the compaction has run (main stream), [1] the tick's chunks have landed (copy stream)
+    bool stage_reserve(size_t bytes) {
+        if (bytes <= h_stage_cap) return true;
+        if (h_stage) (void)hipHostFree(h_stage);
+        h_stage = nullptr; h_stage_cap = 0; d_stage_view = nullptr;
+        void *dv = nullptr;
+        if (hipHostMalloc(&h_stage, bytes + bytes / 4, hipHostMallocDefault) != hipSuccess) { h_stage = nullptr; return false; }
+        if (hipHostGetDevicePointer(&dv, h_stage, 0) != hipSuccess || !dv) { (void)hipHostFree(h_stage); h_stage = nullptr; return false; }
+        h_stage_cap = bytes + bytes / 4; d_stage_view = (const char *)dv;
+        return true;
+    }
     WrPacketOut *h_out = nullptr;
     long long *h_starts = nullptr;
+    char *d_pin_view = nullptr;             // the address the device writes that block at (live ticks: the export kernel), or null
     bool pin_reserve(size_t bytes) {
         if (bytes <= h_pin_cap) return true;
         if (h_pin) (void)hipHostFree(h_pin);
-        h_pin = nullptr; h_pin_cap = 0;
+        h_pin = nullptr; h_pin_cap = 0; d_pin_view = nullptr;
         if (hipHostMalloc(&h_pin, bytes + bytes / 4, hipHostMallocDefault) != hipSuccess) { h_pin = nullptr; return false; }
         h_pin_cap = bytes + bytes / 4;
+        void *dv = nullptr;
+        if (hipHostGetDevicePointer(&dv, h_pin, 0) == hipSuccess) d_pin_view = (char *)dv; else (void)hipGetLastError();
         return true;
     }
     // per sub-batch: [0] before demod, [1] after demod, [2] after deframe, [3] after decode; copied = its input is in HBM
@@ -997,7 +1014,11 @@ struct wenet_rx {
     // ---- live channels (wenet_rx_push): state, unconsumed samples and undecided symbols carried from tick to tick ----
     int live_n = 0, live_fmt = -1;
     long long live_ticks = 0;
+    double live_phase_us[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // WENET_RX_LIVE_TIMING=1: host time per phase of a tick, summed (printed when the streams end)
+    long long live_phase_n = 0;
+    double live_wait[3] = {0, 0, 0};        // the same switch: 10 ns ticks the workgroups' first D waves waited for chunks (sum over channels), longest single wait, the share of the first piece
     long long live_in_stride = 0, live_sd_stride = 0;   // bytes / floats between the channels' blocks in d_live_in / d_sd
+    int live_alloc_nchan = 0;                           // the channel count those strides were laid out for
     std::vector<long long> live_carry_smp, live_carry_sym, live_sym_base, live_new_sym;   // host mirror, per channel
     DevBuf d_live_in, d_live_meta;
     bool pending = false;
@@ -1016,6 +1037,8 @@ struct wenet_rx {
     ~wenet_rx() {
         for (auto &c : cev) { for (auto &e : c.ev) if (e) (void)hipEventDestroy(e); if (c.copied) (void)hipEventDestroy(c.copied); }
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
+        if (h_stage) (void)hipHostFree(h_stage);
+        for (hipEvent_t &ev : live_ev) if (ev) (void)hipEventDestroy(ev);
         if (res_stream) (void)hipStreamDestroy(res_stream);
         if (copied_all) (void)hipEventDestroy(copied_all);
         if (h_redo) (void)hipHostFree(h_redo);
@@ -1436,7 +1459,7 @@ static int rx_enqueue(wenet_rx *rx, int nchan, const void *const *raw_in, const 
             ap.out = ak.out + (size_t)plo * max_pk;
             ap.esn0 = ak.esn0 + (size_t)plo * max_pk;
             ap.pbase = ak.pbase + (size_t)plo * max_pk;
-            ap.work = (unsigned *)(a.esn0 + (size_t)nchan * max_pk) + (k * 4 + p);      // one counter per launch, behind the array
+            ap.work = a.work + (k * 4 + p);                                              // one counter per launch
             const int li = k * 4 + p;                                                  // agreement guard: this launch's records and lists
             if (ak.agree && li < 1024 && rx->d_redo.reserve((size_t)rx->nchunks * 4 * 8192)) {
                 ap.agree = ak.agree + (size_t)plo * max_pk * (WR_DEC_THREADS / 64);
@@ -1516,35 +1539,110 @@ __global__ __launch_bounds__(256) void wenet_live_compact_kernel(char *in_base, 
     }
     if (tid == 0) { meta[ch].carry_smp = have - used; meta[ch].carry_sym = nsym - res; }
 }
-// A tick's uploads when the caller's buffers are PINNED host memory (hipHostMalloc / hipHostRegister: the device can read them): one kernel copies every
-// channel's chunk over PCIe into its input block -- N hipMemcpyAsync calls cost the host ~10 us each, 1.3 ms of a 3.8 ms tick at 128 channels.  Any alignment
-// of source and destination: whole 16-byte units of the DESTINATION, the source read in aligned dwords and shifted into place; heads and tails bytewise.
-// (A 4-aligned dword that holds at least one byte of the chunk lies in a page of the chunk: the reads around the ends touch nothing else.)
-struct WrGather { const char *src; char *dst; long long bytes; };
-__global__ __launch_bounds__(256) void wenet_live_gather_kernel(const WrGather *list) {
-    const WrGather g = list[blockIdx.y];
-    const long long n = g.bytes;
-    if (n <= 0) return;
-    const long long head = min(n, (long long)((16u - (unsigned)((uintptr_t)g.dst & 15u)) & 15u));
-    if (blockIdx.x == 0 && (long long)threadIdx.x < head) g.dst[threadIdx.x] = g.src[threadIdx.x];
-    const long long body = (n - head) >> 4;
-    const char *s0 = g.src + head;
-    uint4 *d0 = (uint4 *)(g.dst + head);
-    const unsigned a = (unsigned)((uintptr_t)s0 & 3u);
-    const unsigned *sw = (const unsigned *)(s0 - a);
-    for (long long u = (long long)blockIdx.x * 256 + threadIdx.x; u < body; u += (long long)gridDim.x * 256) {
-        const unsigned *q = sw + 4 * u;
-        uint4 o;
-        if (a == 0) {
-            o = (((uintptr_t)q & 15u) == 0) ? *(const uint4 *)q : make_uint4(q[0], q[1], q[2], q[3]);
-        } else {
+// A tick's uploads.  One kernel copies the channels' chunks over PCIe into their input blocks: N hipMemcpyAsync calls cost the host ~10 us each (1.3 ms of a 3.8 ms tick at
+// 128 channels in round 3).  A chunk in PINNED host memory (hipHostMalloc / hipHostRegister) is read where it lies; a chunk in pageable memory is first copied by the host
+// into the handle's pinned staging block, piece by piece, and read from there.  Any alignment of source and destination: whole 16-byte units of the DESTINATION, the
+// source read in aligned dwords and shifted into place; heads and tails bytewise.  (A 4-aligned dword that holds at least one byte of the chunk lies in a page of the
+// chunk: the reads around the ends touch nothing else; the bytes of such a dword that lie outside the unit are shifted out, so a piece never depends on its neighbours.)
+// Round 5: every chunk goes in WR_LIVE_PIECES pieces in TIME order (grid x = chunk, y = piece: the dispatcher hands out piece 0 of every channel first), and a workgroup
+// that has landed its piece says so in the channel's arrival words (WrChan::arrive) -- the pipelined demodulator runs beside this kernel and waits for a piece only when
+// its read-ahead reaches it: the 0.45 ms a tick's 29 MB need over PCIe lie under the demodulator's 1.0 ms instead of in front of them.
+#define WR_LIVE_PIECES 16
+struct WrGather { const char *src; char *dst; long long bytes; unsigned long long *flag; long long dst_off; int shift, pad; };     // dst_off: bytes of the channel's block in front of dst; shift: log2(bytes per sample)
+// piece p of a chunk of n bytes whose destination is `mis` bytes past a 16-byte boundary: bytes [lo, hi) -- the head joins piece 0, the tail the last piece.  Piece 0 is
+// SHORT (`first` 16-byte units: what the demodulator's prologue and first frame read), so that every channel's first samples are over the link before anything else;
+// the rest is cut evenly.
+__host__ __device__ inline void live_piece(long long n, unsigned mis, int P, int p, long long first, long long &lo, long long &hi) {
+    const long long h0 = (long long)((16u - (mis & 15u)) & 15u), head = n < h0 ? n : h0, body = (n - head) >> 4;
+    if (P <= 1) { lo = 0; hi = n; return; }
+    const long long f = body < first ? body : first, rest = body - f;
+    lo = p == 0 ? 0 : head + (f + (rest * (p - 1)) / (P - 1)) * 16;
+    hi = p == P - 1 ? n : (p == 0 ? head + f * 16 : head + (f + (rest * p) / (P - 1)) * 16);
+}
+// Stores that are performed at AGENT scope (sc1: written through this XCD's L2) -- what the demodulator on another XCD reads behind its acquire needs no L2 write-back
+// fence then, only the stores' completion (vmcnt).  (A release fence per workgroup = a write-back of the whole L2 two thousand times a tick: the gather took 0.73 ms instead of 0.45.)
+typedef unsigned wr_v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store16_agent(void *p, wr_v4u v) {     // (two 8-byte stores: the widest the compiler performs at a scope; written out in asm, a 16-byte store would
+    unsigned long long *q = (unsigned long long *)p;                   //  hide its data registers from the compiler's hazard checks)
+    __hip_atomic_store(q, (unsigned long long)v.x | ((unsigned long long)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(q + 1, (unsigned long long)v.z | ((unsigned long long)v.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void store1_agent(void *p, unsigned v) { __hip_atomic_store((unsigned char *)p, (unsigned char)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// WHERE it runs matters: a compute unit's vector memory path returns data in order, so a demodulator workgroup that shares its compute unit with gather wavefronts gets
+// its table reads and sample prefetches back behind reads that cross PCIe (measured: with the gather on every compute unit the demodulator's launch was 0.37 ms longer,
+// as long as the gather ran; 16 workgroups: 0.12 ms).  The gather therefore runs as FEW workgroups that each reserve so much LDS that no demodulator workgroup fits
+// beside them, in either order of arrival -- a handful of compute units fetch, the others compute.
+// The work is the list of (piece, chunk) pairs in TIME order -- piece 0 of every chunk, then piece 1 ... -- and a fixed number of workgroups walks it with a stride: were
+// every pair given its own workgroup, all of them would be resident at once, share the link equally, and every piece would land at the end (measured: the demodulator
+// beside it then waited 0.5 ms for its first samples).
+__global__ __launch_bounds__(1024) void wenet_live_gather_kernel(const WrGather *list, int nent, int P, int p_lo, int p_hi, long long first, unsigned seq) {
+    const int nt = (int)blockDim.x;
+    const long long nitems = (long long)(p_hi - p_lo) * nent;
+    for (long long w = blockIdx.x; w < nitems; w += gridDim.x) {
+        const int p = p_lo + (int)(w / nent);
+        const WrGather g = list[w % nent];
+        const long long n = g.bytes;
+        long long lo, hi;
+        live_piece(n, (unsigned)((uintptr_t)g.dst & 15u), P, p, first, lo, hi);
+        const long long head = min(n, (long long)((16u - (unsigned)((uintptr_t)g.dst & 15u)) & 15u)), body = (n - head) >> 4;
+        if (p == 0 && (long long)threadIdx.x < head) store1_agent(g.dst + threadIdx.x, (unsigned)(unsigned char)g.src[threadIdx.x]);
+        const char *s0 = g.src + head;
+        uint4 *d0 = (uint4 *)(g.dst + head);
+        const unsigned a = (unsigned)((uintptr_t)s0 & 3u);
+        const unsigned *sw = (const unsigned *)(s0 - a);
+        const long long u_lo = ((lo > head ? lo : head) - head) >> 4, u_hi = p == P - 1 ? body : (hi - head) >> 4;
+        auto fetch = [&](long long u) -> wr_v4u {
+            const unsigned *q = sw + 4 * u;
+            if (a == 0) {
+                const uint4 o = (((uintptr_t)q & 15u) == 0) ? *(const uint4 *)q : make_uint4(q[0], q[1], q[2], q[3]);
+                return wr_v4u{o.x, o.y, o.z, o.w};
+            }
             const unsigned w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3], w4 = q[4];
-            o = make_uint4(__builtin_amdgcn_alignbyte(w1, w0, a), __builtin_amdgcn_alignbyte(w2, w1, a), __builtin_amdgcn_alignbyte(w3, w2, a), __builtin_amdgcn_alignbyte(w4, w3, a));
+            return wr_v4u{__builtin_amdgcn_alignbyte(w1, w0, a), __builtin_amdgcn_alignbyte(w2, w1, a), __builtin_amdgcn_alignbyte(w3, w2, a), __builtin_amdgcn_alignbyte(w4, w3, a)};
+        };
+        long long u = u_lo + threadIdx.x;
+        for (; u + 3 * nt < u_hi; u += 4 * nt) {                        // four reads over the link in flight per thread
+            const wr_v4u o0 = fetch(u), o1 = fetch(u + nt), o2 = fetch(u + 2 * nt), o3 = fetch(u + 3 * nt);
+            store16_agent(d0 + u, o0); store16_agent(d0 + u + nt, o1); store16_agent(d0 + u + 2 * nt, o2); store16_agent(d0 + u + 3 * nt, o3);
         }
-        d0[u] = o;
+        for (; u < u_hi; u += nt) store16_agent(d0 + u, fetch(u));
+        const long long done = head + (body << 4);
+        if (p == P - 1 && (long long)threadIdx.x < n - done) store1_agent(g.dst + done + threadIdx.x, (unsigned)(unsigned char)g.src[done + threadIdx.x]);
+        if (g.flag) {                                                    // publish: this workgroup's stores have been performed (they are read on other compute units, behind other L2s)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0)
+                __hip_atomic_store(&g.flag[p], ((unsigned long long)seq << 32) | (unsigned long long)(unsigned)((g.dst_off + hi) >> g.shift), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (relaxed: everything in front of it was stored at agent scope and has completed -- a release would write the L2 back)
+        }
     }
-    const long long done = head + (body << 4);
-    if (blockIdx.x == 0 && (long long)threadIdx.x < n - done) g.dst[done + threadIdx.x] = g.src[done + threadIdx.x];
+}
+// A tick's results in ONE kernel, written straight into the handle's pinned host block (five copies -- a strided one for the state headers among them -- cost 60 us of a
+// 1.4 ms tick): per channel the state header, the deframer state, the census row and the packet slots and start offsets of the packets the tick completed.
+struct WrLiveExport {
+    const float *states; int st_floats; const WrDeframeState *dst; const unsigned *census; const WrPacketOut *out; const long long *starts; int max_pk, nchan;
+    char *host; size_t o_starts, o_hdr, o_dst, o_cen; int cen_tail;     // the block as the device addresses it; cen_tail: words behind the census rows (arrival error + statistics)
+};
+__global__ __launch_bounds__(256) void wenet_live_export_kernel(WrLiveExport E) {
+    const int ch = blockIdx.x, tid = threadIdx.x;
+    const unsigned *hs = (const unsigned *)(E.states + (size_t)ch * E.st_floats);
+    unsigned *hd = (unsigned *)(E.host + E.o_hdr + sizeof(WrChanHdr) * (size_t)ch);
+    if (tid < (int)(sizeof(WrChanHdr) / 4)) hd[tid] = hs[tid];
+    const unsigned *ds = (const unsigned *)(E.dst + ch);
+    unsigned *dd = (unsigned *)(E.host + E.o_dst + sizeof(WrDeframeState) * (size_t)ch);
+    if (tid >= 64 && tid < 64 + (int)(sizeof(WrDeframeState) / 4)) dd[tid - 64] = ds[tid - 64];
+    unsigned *cd = (unsigned *)(E.host + E.o_cen);
+    if (tid >= 128 && tid < 128 + WR_CENSUS_CLASSES) cd[(size_t)ch * WR_CENSUS_CLASSES + (tid - 128)] = E.census[(size_t)ch * WR_CENSUS_CLASSES + (tid - 128)];
+    if (ch == 0 && tid >= 192 && tid < 192 + E.cen_tail) cd[(size_t)E.nchan * WR_CENSUS_CLASSES + (tid - 192)] = E.census[(size_t)E.nchan * WR_CENSUS_CLASSES + (tid - 192)];
+    long long npk = E.dst[ch].npackets;
+    if (npk > E.max_pk) npk = E.max_pk;
+    constexpr int PW = (int)(sizeof(WrPacketOut) / 4);
+    static_assert(sizeof(WrPacketOut) % 4 == 0, "packet slots are copied in dwords");
+    const unsigned *os = (const unsigned *)(E.out + (size_t)ch * E.max_pk);
+    unsigned *od = (unsigned *)(E.host + sizeof(WrPacketOut) * (size_t)ch * E.max_pk);
+    for (long long i = tid; i < npk * PW; i += 256) od[i] = os[i];
+    const unsigned *ss = (const unsigned *)(E.starts + (size_t)ch * E.max_pk);
+    unsigned *sd = (unsigned *)(E.host + E.o_starts + 8 * (size_t)ch * E.max_pk);
+    for (long long i = tid; i < npk * 2; i += 256) sd[i] = ss[i];
 }
 // the address the DEVICE reads a host buffer at, or nullptr if it cannot (pageable memory)
 // (the WHOLE chunk [p, p + bytes) must lie in pinned / registered memory: a chunk that starts in a pinned region and runs past its end -- a ring pinned in parts -- would
@@ -1565,7 +1663,19 @@ const char *device_view_of_host(const void *p, size_t bytes) {
 }
 }  // namespace
 
-static void live_close(wenet_rx *rx) { rx->live_n = 0; rx->live_fmt = -1; rx->live_ticks = 0; rx->nchan = 0; }     // (nchan 0: the getters have nothing to describe once the streams have ended -- the batch layout does not hold for a tick's buffers)
+static void live_close(wenet_rx *rx) {
+    if (rx->live_n > 0 && rx->copy_stream) (void)hipStreamSynchronize(rx->copy_stream);      // (a tick that failed half-way may have left a gather in flight)
+    if (rx->live_phase_n > 0) {
+        static const char *names[12] = {"entry", "first tick / table block", "sizes", "compact launch", "reserves", "channel tables + pointer views", "table upload + gather of pinned chunks", "launches (+ staging of pageable chunks)", "export launch", "wait", "host mirror", ""};
+        fprintf(stderr, "libwenet_rx: %lld ticks, host time per phase (us):", rx->live_phase_n);
+        for (int k = 0; k < 11; k++) fprintf(stderr, " %s %.1f;", names[k], rx->live_phase_us[k] / (double)rx->live_phase_n);
+        fprintf(stderr, "\n            waiting for chunk pieces inside the demodulator: %.1f us per channel and tick (%.1f of them for the first piece), longest single wait %.1f us\n",
+                rx->live_wait[0] * 0.01 / (double)rx->live_phase_n / std::max(1, rx->live_n), rx->live_wait[2] * 0.01 / (double)rx->live_phase_n / std::max(1, rx->live_n), rx->live_wait[1] * 0.01);
+        rx->live_wait[0] = rx->live_wait[1] = rx->live_wait[2] = 0;
+        rx->live_phase_n = 0;
+        for (double &v : rx->live_phase_us) v = 0;
+    }
+    rx->live_n = 0; rx->live_fmt = -1; rx->live_ticks = 0; rx->nchan = 0; }     // (nchan 0: the getters have nothing to describe once the streams have ended -- the batch layout does not hold for a tick's buffers)
 
 extern "C" int wenet_rx_flush(wenet_rx *rx) {
     if (!rx) return -1;
@@ -1574,6 +1684,9 @@ extern "C" int wenet_rx_flush(wenet_rx *rx) {
 }
 
 extern "C" int wenet_rx_live_gathered(wenet_rx *rx) { return rx ? rx->live_gathered : -1; }
+// tests: the cut of a chunk into the pieces the gather publishes (host arithmetic only)
+extern "C" void wenet_rx_debug_live_piece(long long n, unsigned mis, int npieces, int p, long long first_units, long long *lo, long long *hi) { live_piece(n, mis, npieces, p, first_units, *lo, *hi); }
+extern "C" int wenet_rx_debug_live_pieces(void) { return WR_LIVE_PIECES; }
 extern "C" int wenet_rx_pin_host(void *p, size_t bytes) {
     if (!p || bytes == 0 || !device_ready()) return -1;
     const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterPortable | hipHostRegisterMapped);
@@ -1590,6 +1703,7 @@ extern "C" int wenet_rx_unpin_host(void *p) {
 extern "C" long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *chunk, const long long *nsamples, int fmt) {
     if (!rx || nchan <= 0 || fmt < 0 || fmt > 3 || !nsamples) return -1;
     for (int i = 0; i < nchan; i++) if (nsamples[i] < 0 || (nsamples[i] > 0 && (!chunk || !chunk[i]))) return -1;      // (nothing has been touched yet)
+    const auto t_entry = std::chrono::steady_clock::now();
     if (rx->pending && wenet_rx_collect(rx) < 0) return -1;
     DeviceGuard dg(rx->device);
     LdpcTables *t = ldpc_tables();
@@ -1601,10 +1715,18 @@ extern "C" long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *c
     const size_t bps = (size_t)kBytesPerSample[fmt];
     const size_t stb = (size_t)c.st_floats * 4;
     hipStream_t stream = nullptr;
+    static const bool phase_timing = getenv("WENET_RX_LIVE_TIMING") != nullptr;
+    auto t_last = t_entry;
+    int t_phase = 0;
+    auto lap = [&]() { if (phase_timing) { const auto n = std::chrono::steady_clock::now(); rx->live_phase_us[t_phase++] += std::chrono::duration<double, std::micro>(n - t_last).count(); t_last = n; } };
+    lap();
     if (rx->live_n == 0) {                                              // first tick: fresh modem + deframer state per channel (fsk.c:182-245; bit_buffer = 0)
         rx->live_n = nchan; rx->live_fmt = fmt; rx->live_ticks = 0;
         rx->live_carry_smp.assign(nchan, 0); rx->live_carry_sym.assign(nchan, 0); rx->live_sym_base.assign(nchan, 0); rx->live_new_sym.assign(nchan, 0);
-        rx->live_in_stride = 0; rx->live_sd_stride = 0;
+        // (the input and symbol blocks of an earlier set of streams serve again if they still fit this channel count: two allocations cost the first tick 0.4 - 3 ms)
+        if (rx->live_alloc_nchan != nchan || rx->d_live_in.cap < (size_t)rx->live_in_stride * nchan + 256 || rx->d_sd.cap < (size_t)rx->live_sd_stride * nchan * 4 + 256)
+            { rx->live_in_stride = 0; rx->live_sd_stride = 0; }
+        rx->live_alloc_nchan = nchan;
         rx->slip_rate = 0.0;
         std::vector<float> st0;
         rx->tab.init_state(st0);
@@ -1624,13 +1746,15 @@ extern "C" long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *c
     }
     rx->nchan = nchan; rx->stream = stream; rx->sliced = false;
     WrLiveMeta *d_meta = rx->d_live_meta.as<WrLiveMeta>();
-    long long *d_newsmp = (long long *)(d_meta + nchan);
-    // (1) what the previous tick left undone moves to the front of the blocks
-    if (rx->live_ticks > 0) {
-        hipLaunchKernelGGL(wenet_live_compact_kernel, dim3(nchan), dim3(256), 0, stream, rx->d_live_in.as<char>(), rx->live_in_stride, rx->d_sd.as<float>(),
-                           rx->live_sd_stride, rx->d_states.as<float>(), c.st_floats, rx->d_dstates.as<WrDeframeState>(), d_meta, d_newsmp, (int)bps, c.Nbits);
-        WR_LIVE_CHECK(hipGetLastError(), -4);
-    }
+    // the tick's tables go up in ONE copy: channel table | deframer table | new-sample counts | gather list, laid out alike in the pinned block and on the device
+    auto al64 = [](size_t x) { return (x + 63) & ~(size_t)63; };
+    const size_t t_dch = al64(sizeof(WrChan) * nchan), t_new = al64(t_dch + sizeof(WrDeframeChan) * nchan), t_gl = al64(t_new + 8 * (size_t)nchan), t_total = t_gl + sizeof(WrGather) * nchan;
+    if (!rx->d_live_tab.reserve(t_total)) { live_close(rx); return -2; }      // (the size depends on the channel count only: the block stays where it is for the life of the streams)
+    WrChan *d_tchans = rx->d_live_tab.as<WrChan>();
+    WrDeframeChan *d_tdch = (WrDeframeChan *)(rx->d_live_tab.as<char>() + t_dch);
+    long long *d_newsmp = (long long *)(rx->d_live_tab.as<char>() + t_new);      // (read by the NEXT tick's compaction, which runs before that tick's upload)
+    WrGather *d_tgl = (WrGather *)(rx->d_live_tab.as<char>() + t_gl);
+    lap();
     // (2) room for this tick: carried + new samples per channel, carried + new symbols; growing keeps what is carried
     const long long min_nin = c.N - c.Ts / 2;
     long long need_smp = 0, need_sym = 0, max_pk = 1;
@@ -1643,6 +1767,14 @@ extern "C" long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *c
         max_pk = std::max(max_pk, sym / rx->spp + 1);
     }
     const long long in_stride = (((need_smp + need_smp / 4) * (long long)bps + 255) & ~255LL) + 256, sd_stride = ((need_sym + need_sym / 4 + 63) & ~63LL) + 64;
+    lap();
+    // (1) what the previous tick left undone moves to the front of the blocks (the device works on it while the host prepares the tick's tables)
+    if (rx->live_ticks > 0) {
+        hipLaunchKernelGGL(wenet_live_compact_kernel, dim3(nchan), dim3(256), 0, stream, rx->d_live_in.as<char>(), rx->live_in_stride, rx->d_sd.as<float>(),
+                           rx->live_sd_stride, rx->d_states.as<float>(), c.st_floats, rx->d_dstates.as<WrDeframeState>(), d_meta, d_newsmp, (int)bps, c.Nbits);
+        WR_LIVE_CHECK(hipGetLastError(), -4);
+    }
+    lap();
     if (in_stride > rx->live_in_stride || sd_stride > rx->live_sd_stride) {
         WR_LIVE_CHECK(hipStreamSynchronize(stream), -4);
         const long long nis = std::max(in_stride, rx->live_in_stride), nss = std::max(sd_stride, rx->live_sd_stride);
@@ -1665,37 +1797,76 @@ extern "C" long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *c
         rx->live_in_stride = nis; rx->live_sd_stride = nss;
     }
     rx->max_pk = (int)max_pk;
-    if (!rx->d_starts.reserve((size_t)nchan * max_pk * 8) || !rx->d_out.reserve((size_t)nchan * max_pk * sizeof(WrPacketOut)) ||
-        !rx->d_esn0.reserve(wr_dec_scratch_bytes((size_t)nchan * max_pk)))
-        { live_close(rx); return -2; }
+    {   // (the slot count per channel creeps up by one or two over the first ticks: room for that at once -- a reallocation costs a tick half a millisecond)
+        const size_t need_slots = (size_t)nchan * max_pk;
+        if (need_slots * 8 > rx->d_starts.cap || need_slots * sizeof(WrPacketOut) > rx->d_out.cap || wr_dec_scratch_bytes(need_slots) > rx->d_esn0.cap) {
+            const size_t room = (size_t)nchan * (2 * max_pk + 2);
+            if (!rx->d_starts.reserve(room * 8) || !rx->d_out.reserve(room * sizeof(WrPacketOut)) || !rx->d_esn0.reserve(wr_dec_scratch_bytes(room))) { live_close(rx); return -2; }
+        }
+    }
     if (rx->want_trace && !rx->d_trace.reserve((size_t)nchan * (size_t)(rx->live_sd_stride / c.Nbits + 1) * WR_TRACE_FLOATS * 4)) { live_close(rx); return -2; }
     if (rx->want_llr && !rx->d_llr.reserve((size_t)nchan * max_pk * WR_NCODE * 4)) { live_close(rx); return -2; }
     const size_t oct_scr = (size_t)c.M * c.Ts * 64 * 8 + 64;
     if (!rx->d_big.reserve((size_t)nchan * (c.big ? (size_t)c.big_bytes : oct_scr))) { live_close(rx); return -2; }
     rx->profile = false;
+    lap();
     // (3) this tick's samples behind the carried ones; tables.  Everything the host hands over or takes back in a tick except the samples themselves lives in ONE pinned
-    //     block (the copies are real DMA, none is staged by the runtime): packet slots | start offsets | state headers | deframer states | census || tables in
-    const size_t n_slots = (size_t)nchan * max_pk, out_bytes = n_slots * sizeof(WrPacketOut), st_bytes = n_slots * 8;
-    auto al64 = [](size_t x) { return (x + 63) & ~(size_t)63; };
+    //     block (the copies are real DMA, none is staged by the runtime): packet slots | start offsets | state headers | deframer states | census + arrival error || tables in
+    const size_t n_slots = (size_t)nchan * max_pk, out_bytes = n_slots * sizeof(WrPacketOut), st_bytes = n_slots * 8, cen_bytes = (size_t)nchan * WR_CENSUS_CLASSES * 4 + 16;      // (+ the arrival error word and three statistics words)
     const size_t o_starts = al64(out_bytes), o_hdr = al64(o_starts + st_bytes), o_dst = al64(o_hdr + sizeof(WrChanHdr) * nchan), o_cen = al64(o_dst + sizeof(WrDeframeState) * nchan),
-                 o_chans = al64(o_cen + (size_t)nchan * WR_CENSUS_CLASSES * 4), o_dch = al64(o_chans + sizeof(WrChan) * nchan), o_new = al64(o_dch + sizeof(WrDeframeChan) * nchan),
-                 o_gl = al64(o_new + 8 * (size_t)nchan), pin_total = o_gl + sizeof(WrGather) * nchan + 64;
-    if (!rx->pin_reserve(pin_total)) { live_close(rx); return -2; }
+                 o_chans = al64(o_cen + cen_bytes), o_dch = o_chans + t_dch, o_new = o_chans + t_new, o_gl = o_chans + t_gl, pin_total = o_chans + t_total + 64;
+    if (pin_total > rx->h_pin_cap && !rx->pin_reserve(pin_total + (size_t)nchan * (size_t)(max_pk + 2) * (sizeof(WrPacketOut) + 8))) { live_close(rx); return -2; }      // (room for the slot count's creep: pinning is slow)
+    if (!rx->d_census.reserve(cen_bytes)) { live_close(rx); return -2; }
     char *hp = (char *)rx->h_pin;
     WrChan *chans = (WrChan *)(hp + o_chans);
     WrDeframeChan *dch = (WrDeframeChan *)(hp + o_dch);
-    WrGather *gl = (WrGather *)(hp + o_gl);                              // chunks the device reads itself (pinned host memory): one kernel instead of a copy per channel
-    size_t ngl = 0;
+    WrGather *gl = (WrGather *)(hp + o_gl);                              // the chunks: first those the device reads where they lie (pinned), then those staged by the host
     rx->sd_off.assign(nchan + 1, 0);
     rx->cap_frames = capf;
+    const DemodChoice dcs = choose_demod(rx, nchan, fmt);
+    rx->last_kernel = dcs.use_oct ? "wenet_demod_oct_kernel" : (dcs.launch_cfg.p_tri ? "wenet_demod_tri_kernel" : (dcs.launch_cfg.pipe_ok && !dcs.launch_cfg.big ? "wenet_demod_pipe_kernel" : "wenet_demod_kernel"));
+    // the pipelined kernel takes the chunks as they arrive (WrChan::arrive); the other demodulators start when the gather has finished
+    const bool no_overlap = getenv("WENET_RX_NO_LIVE_OVERLAP") != nullptr;
+    const bool overlap = !no_overlap && !dcs.use_oct && !dcs.launch_cfg.p_tri && dcs.launch_cfg.pipe_ok && !dcs.launch_cfg.big && (unsigned long long)(rx->live_in_stride / (long long)bps) < 0xffffffffull;
+    const int P = WR_LIVE_PIECES;
+    const long long first_units = ((long long)(6 * (c.N + c.Ts / 2) + 640 + 64) * (long long)bps + 15) / 16;      // the prologue reads 4 frames of the longest kind, the first frame's prefetch two more and 640 samples
+    const unsigned seq = (unsigned)(rx->live_ticks + 1);
+    if (!rx->d_live_arrive.reserve((size_t)nchan * P * 8)) { live_close(rx); return -2; }
+    if (rx->live_ticks == 0) WR_LIVE_CHECK(hipMemset(rx->d_live_arrive.p, 0, (size_t)nchan * P * 8), -3);
+    if (!rx->copy_stream) WR_LIVE_CHECK(hipStreamCreateWithFlags(&rx->copy_stream, hipStreamNonBlocking), -4);
+    for (hipEvent_t &ev : rx->live_ev) if (!ev) WR_LIVE_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming), -4);
+    hipStream_t cstream = rx->copy_stream;
+    const int shift = bps == 2 ? 1 : (bps == 4 ? 2 : 3);
     const bool try_gather = getenv("WENET_RX_NO_GATHER") == nullptr;
+    size_t npin = 0, npage = 0, stage_bytes = 0;
+    std::vector<int> page_ch;                                            // channels whose chunk lies in pageable memory
+    std::vector<const char *> views(nchan, nullptr);
+    for (int i = 0; i < nchan; i++) {
+        if (nsamples[i] <= 0) continue;
+        views[i] = try_gather ? device_view_of_host(chunk[i], (size_t)nsamples[i] * bps) : nullptr;
+        if (views[i]) npin++; else { page_ch.push_back(i); stage_bytes += (size_t)nsamples[i] * bps + 32; }
+    }
+    npage = page_ch.size();
+    if (npage > 0 && !rx->stage_reserve(stage_bytes + 64)) { live_close(rx); return -2; }
+    unsigned long long *d_arrive = rx->d_live_arrive.as<unsigned long long>();
+    unsigned *d_arrive_err = (unsigned *)(rx->d_census.as<char>() + cen_bytes - 16);
+    std::vector<size_t> stage_off(npage);
+    {
+        size_t kp = 0, kg = npin, cur = 0;
+        for (int i = 0; i < nchan; i++) {
+            if (nsamples[i] <= 0) continue;
+            char *dst = rx->d_live_in.as<char>() + (size_t)i * rx->live_in_stride + (size_t)rx->live_carry_smp[i] * bps;
+            WrGather g{nullptr, dst, (long long)((size_t)nsamples[i] * bps), overlap ? d_arrive + (size_t)i * P : nullptr, (long long)((size_t)rx->live_carry_smp[i] * bps), shift, 0};
+            if (views[i]) { g.src = views[i]; gl[kp++] = g; }
+            else {                                                       // staged at the destination's alignment: the gather then moves aligned 16-byte units
+                const size_t so = ((cur + 15) & ~(size_t)15) + ((uintptr_t)dst & 15u);
+                stage_off[kg - npin] = so; cur = so + (size_t)g.bytes;
+                g.src = rx->d_stage_view + so; gl[kg++] = g;
+            }
+        }
+    }
     for (int i = 0; i < nchan; i++) {
         char *blk = rx->d_live_in.as<char>() + (size_t)i * rx->live_in_stride;
-        if (nsamples[i] > 0) {
-            const char *dv = try_gather ? device_view_of_host(chunk[i], (size_t)nsamples[i] * bps) : nullptr;
-            if (dv) gl[ngl++] = WrGather{dv, blk + (size_t)rx->live_carry_smp[i] * bps, (long long)((size_t)nsamples[i] * bps)};
-            else WR_LIVE_CHECK(hipMemcpyAsync(blk + (size_t)rx->live_carry_smp[i] * bps, chunk[i], (size_t)nsamples[i] * bps, hipMemcpyHostToDevice, stream), -3);
-        }
         float *sdb = rx->d_sd.as<float>() + (size_t)i * rx->live_sd_stride;
         WrChan &ch = chans[i];
         memset(&ch, 0, sizeof(ch));
@@ -1705,6 +1876,7 @@ extern "C" long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *c
         ch.cap_frames = capf[i];
         ch.trace = rx->want_trace ? rx->d_trace.as<float>() + (size_t)i * (size_t)(rx->live_sd_stride / c.Nbits + 1) * WR_TRACE_FLOATS : nullptr;
         ch.big = rx->d_big.as<unsigned char>() + (size_t)i * (c.big ? (size_t)c.big_bytes : oct_scr);
+        if (overlap && nsamples[i] > 0) { ch.arrive = d_arrive + (size_t)i * P; ch.arrive_seq = seq; ch.arrive_n = P; ch.arrive_have = rx->live_carry_smp[i]; ch.arrive_err = d_arrive_err; }
         rx->sd_off[i] = (long long)((size_t)i * rx->live_sd_stride) + rx->live_carry_sym[i];       // (wenet_rx_get_soft: this tick's soft decisions)
         WrDeframeChan &d = dch[i];
         memset(&d, 0, sizeof(d));
@@ -1716,39 +1888,82 @@ extern "C" long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *c
         d.starts = rx->d_starts.as<long long>() + (size_t)i * max_pk;
         d.cap_packets = max_pk;
     }
-    rx->live_gathered = (int)ngl;
-    if (ngl > 0) {
-        if (!rx->d_live_gather.reserve(sizeof(WrGather) * (size_t)nchan)) { live_close(rx); return -2; }
-        WR_LIVE_CHECK(hipMemcpyAsync(rx->d_live_gather.p, gl, sizeof(WrGather) * ngl, hipMemcpyHostToDevice, stream), -3);
-        long long mx = 0;
-        for (size_t k = 0; k < ngl; k++) mx = std::max(mx, gl[k].bytes);
-        const unsigned pieces = (unsigned)std::min<long long>(16, std::max<long long>(1, mx / 16384));        // >= 16 KB of a chunk per workgroup
-        for (size_t g0 = 0; g0 < ngl; g0 += 65535) {                     // (grid y <= 65535)
-            hipLaunchKernelGGL(wenet_live_gather_kernel, dim3(pieces, (unsigned)std::min<size_t>(65535, ngl - g0)), dim3(256), 0, stream, rx->d_live_gather.as<WrGather>() + g0);
+    rx->live_gathered = (int)npin;
+    lap();
+    // the tables first (a small upload queued behind the chunks' reads would wait for its turn on the link: 0.4 ms), then the copy stream: behind the compaction
+    // (the new samples land where it reads the leftover from) and the list, the chunks that lie in pinned memory
+    memcpy(hp + o_new, nsamples, 8 * (size_t)nchan);
+    WR_LIVE_CHECK(hipMemcpyAsync(rx->d_live_tab.p, hp + o_chans, t_total, hipMemcpyHostToDevice, stream), -3);
+    WR_LIVE_CHECK(hipMemsetAsync(rx->d_census.as<char>() + cen_bytes - 16, 0, 16, stream), -3);      // (the arrival error word: the demodulator may write it; the census itself is cleared behind the launch)
+    WR_LIVE_CHECK(hipEventRecord(rx->live_ev[0], stream), -4);
+    WR_LIVE_CHECK(hipStreamWaitEvent(cstream, rx->live_ev[0], 0), -4);
+    // the gather's shape: few fat workgroups that keep their compute units to themselves (see the kernel) -- as many as the demodulator's workgroups surely leave free
+    static const size_t gather_wgs_env = getenv("WENET_RX_LIVE_GATHER_WGS") ? (size_t)std::max(1, atoi(getenv("WENET_RX_LIVE_GATHER_WGS"))) : 0;      // (development switches)
+    static const unsigned gather_nt = getenv("WENET_RX_LIVE_GATHER_THREADS") ? (unsigned)std::min(1024, std::max(64, atoi(getenv("WENET_RX_LIVE_GATHER_THREADS")) & ~63)) : 1024u;
+    size_t gather_wgs = gather_wgs_env ? gather_wgs_env : 32, gather_lds = 0;
+    if (overlap && getenv("WENET_RX_LIVE_GATHER_SHARED_CU") == nullptr) {
+        static size_t lds_cu = 0, lds_wg = 0, ncu = 0;
+        if (lds_cu == 0) {
+            hipDeviceProp_t pr;
+            if (hipGetDeviceProperties(&pr, rx->device) == hipSuccess) { lds_cu = pr.maxSharedMemoryPerMultiProcessor; lds_wg = pr.sharedMemPerBlock; ncu = (size_t)pr.multiProcessorCount; } else { (void)hipGetLastError(); lds_cu = 1; }
+            int optin = 0;
+            if (hipDeviceGetAttribute(&optin, hipDeviceAttributeSharedMemPerBlockOptin, rx->device) == hipSuccess && (size_t)optin > lds_wg) lds_wg = (size_t)optin; else (void)hipGetLastError();
+        }
+        // LDS the gather's workgroups reserve: what a compute unit has, less what a demodulator workgroup needs, and a little -- neither fits beside the other.  Only while
+        // the demodulator's workgroups (one per channel) leave compute units free: a gather that found none would never start, and the demodulator would wait for it.
+        const size_t need = (size_t)dcs.launch_cfg.p_lds_bytes, free_cu = ncu > (size_t)nchan ? ncu - (size_t)nchan : 0;
+        if (lds_cu > need && free_cu >= 8) {
+            gather_lds = std::min(lds_wg, ((lds_cu - need + 1024 + 255) & ~(size_t)255));
+            if (gather_lds + need <= lds_cu) gather_lds = 0;          // (the device does not let one workgroup reserve that much: shared compute units then)
+            else gather_wgs = std::min(gather_wgs, free_cu);
+        }
+        if (gather_lds > 0 && hipFuncSetAttribute((const void *)wenet_live_gather_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gather_lds) != hipSuccess) { (void)hipGetLastError(); gather_lds = 0; }
+    }
+    if (gather_lds == 0 && !gather_wgs_env) gather_wgs = 16;           // shared compute units: the fewer the gather touches, the fewer demodulator workgroups it slows
+    if (npin > 0) {
+        hipLaunchKernelGGL(wenet_live_gather_kernel, dim3((unsigned)std::min<size_t>(gather_wgs, npin * P)), dim3(gather_nt), gather_lds, cstream, d_tgl, (int)npin, P, 0, P, first_units, seq);
+        WR_LIVE_CHECK(hipGetLastError(), -4);
+    }
+    // chunks in pageable memory: the host copies piece p of every such chunk into the pinned staging block, the device fetches it from there -- while the host copies piece p + 1
+    auto stage_and_gather = [&]() -> long long {
+        for (int pc = 0; pc < P && npage > 0; pc++) {
+            for (size_t k = 0; k < npage; k++) {
+                const WrGather &g = gl[npin + k];
+                long long lo, hi;
+                live_piece(g.bytes, (unsigned)((uintptr_t)g.dst & 15u), P, pc, first_units, lo, hi);
+                if (hi > lo) memcpy((char *)rx->h_stage + stage_off[k] + lo, (const char *)chunk[page_ch[k]] + lo, (size_t)(hi - lo));
+            }
+            hipLaunchKernelGGL(wenet_live_gather_kernel, dim3((unsigned)std::min<size_t>(gather_wgs, npage)), dim3(gather_nt), gather_lds, cstream, d_tgl + npin, (int)npage, P, pc, pc + 1, first_units, seq);
             WR_LIVE_CHECK(hipGetLastError(), -4);
         }
-    }
-    memcpy(hp + o_new, nsamples, 8 * (size_t)nchan);
-    WR_LIVE_CHECK(hipMemcpyAsync(rx->d_chans.p, chans, sizeof(WrChan) * nchan, hipMemcpyHostToDevice, stream), -3);
-    WR_LIVE_CHECK(hipMemcpyAsync(rx->d_dchans.p, dch, sizeof(WrDeframeChan) * nchan, hipMemcpyHostToDevice, stream), -3);
-    WR_LIVE_CHECK(hipMemcpyAsync(d_newsmp, hp + o_new, sizeof(long long) * nchan, hipMemcpyHostToDevice, stream), -3);
-    WR_LIVE_CHECK(hipMemsetAsync(rx->d_census.p, 0, (size_t)nchan * WR_CENSUS_CLASSES * 4, stream), -3);
+        WR_LIVE_CHECK(hipEventRecord(rx->live_ev[1], cstream), -4);
+        return 0;
+    };
+    lap();
     // (4) demodulate every whole frame, look for unique words in carried + new symbols, decode every packet completed
     rx->nchunks = 1;
     if (!rx->chunk_events(1)) { live_close(rx); return -4; }
     wenet_rx::ChunkEv &e = rx->cev[0];
-    const DemodChoice dcs = choose_demod(rx, nchan, fmt);
-    rx->last_kernel = dcs.use_oct ? "wenet_demod_oct_kernel" : (dcs.launch_cfg.p_tri ? "wenet_demod_tri_kernel" : (dcs.launch_cfg.pipe_ok && !dcs.launch_cfg.big ? "wenet_demod_pipe_kernel" : "wenet_demod_kernel"));
+    static const bool dbg_ordered = getenv("WENET_RX_LIVE_ORDERED_DEBUG") != nullptr;      // development: arrival words in use, but the demodulator starts behind the gather
+    if (!overlap || dbg_ordered) {                                       // every chunk in place first
+        if (const long long rc = stage_and_gather()) return rc;
+        WR_LIVE_CHECK(hipStreamWaitEvent(stream, rx->live_ev[1], 0), -4);
+    }
     WR_LIVE_CHECK(hipEventRecord(e.ev[0], stream), -4);
-    if (dcs.use_oct) WR_LIVE_CHECK(wr_launch_demod_oct(&dcs.oct_cfg, rx->d_chans.as<WrChan>(), nchan, stream), -4);
-    else WR_LIVE_CHECK(wr_launch_demod_ex(&dcs.launch_cfg, rx->d_chans.as<WrChan>(), nchan, stream, 0), -4);
+    if (dcs.use_oct) WR_LIVE_CHECK(wr_launch_demod_oct(&dcs.oct_cfg, d_tchans, nchan, stream), -4);
+    else WR_LIVE_CHECK(wr_launch_demod_ex(&dcs.launch_cfg, d_tchans, nchan, stream, 0), -4);
+    WR_LIVE_CHECK(hipMemsetAsync(rx->d_census.p, 0, cen_bytes - 16, stream), -3);
+    if (overlap && !dbg_ordered) {                                       // the demodulator is running: feed it
+        if (const long long rc = stage_and_gather()) return rc;
+        WR_LIVE_CHECK(hipStreamWaitEvent(stream, rx->live_ev[1], 0), -4);     // (a channel that stopped at its frame cap has not waited for its last pieces: the tick ends behind them)
+    }
     WR_LIVE_CHECK(hipEventRecord(e.ev[1], stream), -4);
-    WR_LIVE_CHECK(wr_launch_deframe(rx->d_dchans.as<WrDeframeChan>(), nchan, rx->mode, stream), -4);
+    WR_LIVE_CHECK(wr_launch_deframe(d_tdch, nchan, rx->mode, stream), -4);
     WR_LIVE_CHECK(hipEventRecord(e.ev[2], stream), -4);
     WrDecodeArgs a;
     memset(&a, 0, sizeof(a));
     a.input_kind = WR_DEC_IN_STREAM; a.mode = rx->mode; a.max_iter = rx->max_iter; a.nchan = nchan; a.max_pk = (int)max_pk;
-    a.dchans = rx->d_dchans.as<WrDeframeChan>();
+    a.dchans = d_tdch;
     a.out = rx->d_out.as<WrPacketOut>();
     carve_decode_scratch(a, rx->d_esn0.as<char>(), (size_t)nchan * max_pk);
     a.census = rx->d_census.as<unsigned>();
@@ -1756,19 +1971,35 @@ extern "C" long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *c
     fill_decode_tables(a, t);
     WR_LIVE_CHECK(wr_launch_decode(&a, stream), -4);
     WR_LIVE_CHECK(hipEventRecord(e.ev[3], stream), -4);
+    lap();
     // (5) results: state headers, deframer states, packet slots
     {
         rx->h_out = (WrPacketOut *)hp;
         rx->h_starts = (long long *)(hp + o_starts);
         rx->h_dstates.resize(nchan);
         rx->h_census.resize((size_t)nchan * WR_CENSUS_CLASSES);
-        // (the host reads the HEADERS of the state blocks only: one strided copy; every slot of the tick comes back with them -- a few per channel -- and ONE wait ends the tick)
-        WR_LIVE_CHECK(hipMemcpy2DAsync(hp + o_hdr, sizeof(WrChanHdr), rx->d_states.p, stb, sizeof(WrChanHdr), (size_t)nchan, hipMemcpyDeviceToHost, stream), -3);
-        WR_LIVE_CHECK(hipMemcpyAsync(hp + o_dst, rx->d_dstates.p, sizeof(WrDeframeState) * nchan, hipMemcpyDeviceToHost, stream), -3);
-        WR_LIVE_CHECK(hipMemcpyAsync(hp + o_cen, rx->d_census.p, rx->h_census.size() * 4, hipMemcpyDeviceToHost, stream), -3);
-        WR_LIVE_CHECK(hipMemcpyAsync(rx->h_out, rx->d_out.p, out_bytes, hipMemcpyDeviceToHost, stream), -3);
-        WR_LIVE_CHECK(hipMemcpyAsync(rx->h_starts, rx->d_starts.p, st_bytes, hipMemcpyDeviceToHost, stream), -3);
+        // (the host reads the HEADERS of the state blocks only; every slot of the tick comes back with them -- a few per channel -- and ONE wait ends the tick)
+        if (rx->d_pin_view && getenv("WENET_RX_LIVE_COPIES") == nullptr) {
+            WrLiveExport E{rx->d_states.as<float>(), c.st_floats, rx->d_dstates.as<WrDeframeState>(), rx->d_census.as<unsigned>(), rx->d_out.as<WrPacketOut>(), rx->d_starts.as<long long>(),
+                           (int)max_pk, nchan, rx->d_pin_view, o_starts, o_hdr, o_dst, o_cen, 4};
+            hipLaunchKernelGGL(wenet_live_export_kernel, dim3(nchan), dim3(256), 0, stream, E);
+            WR_LIVE_CHECK(hipGetLastError(), -4);
+        } else {
+            WR_LIVE_CHECK(hipMemcpy2DAsync(hp + o_hdr, sizeof(WrChanHdr), rx->d_states.p, stb, sizeof(WrChanHdr), (size_t)nchan, hipMemcpyDeviceToHost, stream), -3);
+            WR_LIVE_CHECK(hipMemcpyAsync(hp + o_dst, rx->d_dstates.p, sizeof(WrDeframeState) * nchan, hipMemcpyDeviceToHost, stream), -3);
+            WR_LIVE_CHECK(hipMemcpyAsync(hp + o_cen, rx->d_census.p, cen_bytes, hipMemcpyDeviceToHost, stream), -3);
+            WR_LIVE_CHECK(hipMemcpyAsync(rx->h_out, rx->d_out.p, out_bytes, hipMemcpyDeviceToHost, stream), -3);
+            WR_LIVE_CHECK(hipMemcpyAsync(rx->h_starts, rx->d_starts.p, st_bytes, hipMemcpyDeviceToHost, stream), -3);
+        }
+        lap();
         WR_LIVE_CHECK(hipStreamSynchronize(stream), -4);
+        lap();
+        if (phase_timing) { const unsigned *st = (const unsigned *)(hp + o_cen + cen_bytes - 16); rx->live_wait[0] += st[1]; rx->live_wait[1] = std::max<double>(rx->live_wait[1], st[2]); rx->live_wait[2] += st[3]; }
+        if (*(const unsigned *)(hp + o_cen + cen_bytes - 16) != 0u) {
+            fprintf(stderr, "libwenet_rx: wenet_rx_push: a chunk did not arrive on the device within 2 s (the gather kernel did not run beside the demodulator; WENET_RX_NO_LIVE_OVERLAP=1 orders them); the live streams are ended\n");
+            live_close(rx);
+            return -6;
+        }
         if (a.agree) {                                                // agreement guard: a tick has few packets -- look for a listed one among the slots that came back
             bool listed = false;
             const WrDeframeState *ds = (const WrDeframeState *)(hp + o_dst);
@@ -1803,6 +2034,8 @@ extern "C" long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *c
         }
         if (fr > 0) rx->slip_rate = (double)sl / (double)fr;
         rx->live_ticks++;
+        lap();
+        if (phase_timing) rx->live_phase_n++;
         return total;
     }
 }
