@@ -38,6 +38,15 @@ python bench.py --captures 3584 --ppm 100 --no-cpu-baseline --no-extras 2>/dev/n
   echo "## captures of 0..6 frames"
   WENET_RX_OCT=7 python tools/soak_short.py 2>&1 | tail -1
 } > gpurun_out/${T}_soak.txt 2>&1
+{
+  echo "# live ticks (tools/gpu_live_phases.py: 128 / 16 / 250 channels x 100 ms, pinned and pageable host buffers; host time per phase of wenet_rx_push, the demodulator's waits for chunk pieces)"
+  for n in 128 16 250; do python tools/gpu_live_phases.py $n 10 both 2>&1 | grep -v "amdgpu.ids\|: 1 ticks"; done
+  echo "# the same 128 channels with the gather finished before the demodulator starts (WENET_RX_NO_LIVE_OVERLAP=1), and with gather and demodulator sharing compute units"
+  WENET_RX_NO_LIVE_OVERLAP=1 python tools/gpu_live_phases.py 128 10 both 2>&1 | grep "channels,"
+  WENET_RX_LIVE_GATHER_SHARED_CU=1 python tools/gpu_live_phases.py 128 10 pinned 2>&1 | grep "channels,"
+  echo "# tools/soak_live.py"
+  python tools/soak_live.py 2>&1 | tail -2
+} > gpurun_out/${T}_live_phases.txt 2>&1
 python tools/sweep.py --config v2 --n 3584 --bins 17 --check-cpu 6 > gpurun_out/${T}_config3_sweep3584_v2.md 2>&1
 python tools/gpu_allout.py v2 3584 2 8 > gpurun_out/${T}_allout.txt 2>&1; python tools/gpu_allout.py 4fsk 1024 2 8 >> gpurun_out/${T}_allout.txt 2>&1
 python - $T <<'PY'
@@ -49,4 +58,4 @@ for f in sorted(glob.glob("gpurun_out/%s*_bench_*.json" % sys.argv[1])):
     except Exception as e:
         print(f, "ERR", e)
 PY
-cat gpurun_out/${T}_soak.txt; cat gpurun_out/${T}_host_feed.txt; cat gpurun_out/${T}_allout.txt; cat gpurun_out/${T}_cli_times.txt
+cat gpurun_out/${T}_soak.txt; cat gpurun_out/${T}_live_phases.txt; cat gpurun_out/${T}_host_feed.txt; cat gpurun_out/${T}_allout.txt; cat gpurun_out/${T}_cli_times.txt
