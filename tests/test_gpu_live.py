@@ -175,6 +175,45 @@ def test_live_long_ticks_arrive_in_pieces_while_the_demodulator_runs():
     assert _check(cfg, caps, "cu8", out, frames) > 0
 
 
+def test_three_handles_tick_at_once_and_fill_the_device_together():
+    """Three handles of 128 channels each, ticking at the same time from three threads: 384 demodulator workgroups that wait for their chunks on a device of 256 compute
+    units, and three gathers that want compute units to themselves.  Every demodulator is launched behind the gate (a workgroup of its tick's gather is resident), so all
+    sets of streams finish every tick; results equal those of a handle that ticks alone."""
+    import threading
+    import torch
+    cfg = siggen.config_v2()
+    base = [np.ascontiguousarray(siggen.make_capture(cfg, 12, 9.0, seed=5200 + k)[0]).view(np.uint8).reshape(-1) for k in range(8)]
+    n = min(b.size for b in base)
+    tick = 2 * 28800                                                        # bytes per tick: 30 ms
+    nt = n // tick
+
+    def run(out, idx, go):
+        keep = [torch.from_numpy(base[(ch + idx) % 8][:n].copy()).pin_memory() for ch in range(128)]
+        host = [t.numpy() for t in keep]
+        ptr = np.array([h.ctypes.data for h in host], np.uint64)
+        rx = RxBatch(cfg.Fs, cfg.Rs, cfg.M, framing=cfg.mode)
+        go.wait()
+        dig = []
+        for t in range(nt):
+            npk = rx.push_ptrs(ptr + np.uint64(t * tick), np.full(128, tick // 2, np.int64), "cu8")
+            dig.append((npk, rx.result_digest()))
+        rx.flush(); rx.close()
+        out[idx] = dig
+
+    alone, go = {}, threading.Event()
+    go.set()
+    for i in range(3):
+        run(alone, i, go)
+    assert sum(d[0] for d in alone[0]) > 128 * 8
+    for rep in range(3):
+        both, go = {}, threading.Event()
+        th = [threading.Thread(target=run, args=(both, i, go)) for i in range(3)]
+        for t in th: t.start()
+        go.set()
+        for t in th: t.join()
+        assert all(both[i] == alone[i] for i in range(3)), rep
+
+
 def test_live_many_channels_through_the_batch_demodulator(monkeypatch):
     """enough channels that the per-tick launch takes the batch demodulator (one wavefront per capture) with carried state"""
     monkeypatch.setenv("WENET_RX_OCT", "7")

@@ -1575,8 +1575,9 @@ __device__ __forceinline__ void store1_agent(void *p, unsigned v) { __hip_atomic
 // The work is the list of (piece, chunk) pairs in TIME order -- piece 0 of every chunk, then piece 1 ... -- and a fixed number of workgroups walks it with a stride: were
 // every pair given its own workgroup, all of them would be resident at once, share the link equally, and every piece would land at the end (measured: the demodulator
 // beside it then waited 0.5 ms for its first samples).
-__global__ __launch_bounds__(1024) void wenet_live_gather_kernel(const WrGather *list, int nent, int P, int p_lo, int p_hi, long long first, unsigned seq) {
+__global__ __launch_bounds__(1024) void wenet_live_gather_kernel(const WrGather *list, int nent, int P, int p_lo, int p_hi, long long first, unsigned seq, unsigned *gate) {
     const int nt = (int)blockDim.x;
+    if (gate && threadIdx.x == 0) __hip_atomic_store(gate, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // "a workgroup of this tick's gather is resident" (wenet_live_gate_kernel)
     const long long nitems = (long long)(p_hi - p_lo) * nent;
     for (long long w = blockIdx.x; w < nitems; w += gridDim.x) {
         const int p = p_lo + (int)(w / nent);
@@ -1614,6 +1615,19 @@ __global__ __launch_bounds__(1024) void wenet_live_gather_kernel(const WrGather 
             if (threadIdx.x == 0)
                 __hip_atomic_store(&g.flag[p], ((unsigned long long)seq << 32) | (unsigned long long)(unsigned)((g.dst_off + hi) >> g.shift), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (relaxed: everything in front of it was stored at agent scope and has completed -- a release would write the L2 back)
         }
+    }
+}
+// The gather's workgroups keep their compute units to themselves, the demodulator's workgroups wait for what the gather brings: were the device full of such waiting
+// demodulators (two handles, two processes) before a gather workgroup found a compute unit, nothing would move until the two-second limit.  So the demodulator is launched
+// behind this gate: one thread that waits until a workgroup of the tick's gather is RESIDENT.  The gather walks its list with a stride -- one resident workgroup finishes the
+// whole list -- so every demodulator that starts has a gather that runs, whatever else holds the device.  (Chunks staged from pageable memory are gathered by launches that
+// come after the demodulator's: those run without the LDS reservation, in whatever room the waiting workgroups leave.)
+__global__ __launch_bounds__(64) void wenet_live_gate_kernel(const unsigned *gate, unsigned seq, unsigned *err) {
+    if (threadIdx.x != 0) return;
+    const long long t0 = (long long)wall_clock64();
+    while (__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq) {
+        __builtin_amdgcn_s_sleep(4);
+        if ((long long)wall_clock64() - t0 > 200000000LL) { if (err) *err = 1u; return; }      // 2 s at 100 MHz
     }
 }
 // A tick's results in ONE kernel, written straight into the handle's pinned host block (five copies -- a strided one for the state headers among them -- cost 60 us of a
@@ -1831,8 +1845,9 @@ extern "C" long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *c
     const int P = WR_LIVE_PIECES;
     const long long first_units = ((long long)(6 * (c.N + c.Ts / 2) + 640 + 64) * (long long)bps + 15) / 16;      // the prologue reads 4 frames of the longest kind, the first frame's prefetch two more and 640 samples
     const unsigned seq = (unsigned)(rx->live_ticks + 1);
-    if (!rx->d_live_arrive.reserve((size_t)nchan * P * 8)) { live_close(rx); return -2; }
-    if (rx->live_ticks == 0) WR_LIVE_CHECK(hipMemset(rx->d_live_arrive.p, 0, (size_t)nchan * P * 8), -3);
+    if (!rx->d_live_arrive.reserve((size_t)nchan * P * 8 + 64)) { live_close(rx); return -2; }      // (+ the gate word)
+    if (rx->live_ticks == 0) WR_LIVE_CHECK(hipMemset(rx->d_live_arrive.p, 0, (size_t)nchan * P * 8 + 64), -3);
+    unsigned *d_gate = (unsigned *)(rx->d_live_arrive.as<char>() + (size_t)nchan * P * 8);
     if (!rx->copy_stream) WR_LIVE_CHECK(hipStreamCreateWithFlags(&rx->copy_stream, hipStreamNonBlocking), -4);
     for (hipEvent_t &ev : rx->live_ev) if (!ev) WR_LIVE_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming), -4);
     hipStream_t cstream = rx->copy_stream;
@@ -1921,7 +1936,7 @@ extern "C" long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *c
     }
     if (gather_lds == 0 && !gather_wgs_env) gather_wgs = 16;           // shared compute units: the fewer the gather touches, the fewer demodulator workgroups it slows
     if (npin > 0) {
-        hipLaunchKernelGGL(wenet_live_gather_kernel, dim3((unsigned)std::min<size_t>(gather_wgs, npin * P)), dim3(gather_nt), gather_lds, cstream, d_tgl, (int)npin, P, 0, P, first_units, seq);
+        hipLaunchKernelGGL(wenet_live_gather_kernel, dim3((unsigned)std::min<size_t>(gather_wgs, npin * P)), dim3(gather_nt), gather_lds, cstream, d_tgl, (int)npin, P, 0, P, first_units, seq, gather_lds > 0 ? d_gate : nullptr);
         WR_LIVE_CHECK(hipGetLastError(), -4);
     }
     // chunks in pageable memory: the host copies piece p of every such chunk into the pinned staging block, the device fetches it from there -- while the host copies piece p + 1
@@ -1933,7 +1948,7 @@ extern "C" long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *c
                 live_piece(g.bytes, (unsigned)((uintptr_t)g.dst & 15u), P, pc, first_units, lo, hi);
                 if (hi > lo) memcpy((char *)rx->h_stage + stage_off[k] + lo, (const char *)chunk[page_ch[k]] + lo, (size_t)(hi - lo));
             }
-            hipLaunchKernelGGL(wenet_live_gather_kernel, dim3((unsigned)std::min<size_t>(gather_wgs, npage)), dim3(gather_nt), gather_lds, cstream, d_tgl + npin, (int)npage, P, pc, pc + 1, first_units, seq);
+            hipLaunchKernelGGL(wenet_live_gather_kernel, dim3((unsigned)std::min<size_t>(16, npage)), dim3(gather_nt), 0, cstream, d_tgl + npin, (int)npage, P, pc, pc + 1, first_units, seq, nullptr);
             WR_LIVE_CHECK(hipGetLastError(), -4);
         }
         WR_LIVE_CHECK(hipEventRecord(rx->live_ev[1], cstream), -4);
@@ -1948,6 +1963,10 @@ extern "C" long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *c
     if (!overlap || dbg_ordered) {                                       // every chunk in place first
         if (const long long rc = stage_and_gather()) return rc;
         WR_LIVE_CHECK(hipStreamWaitEvent(stream, rx->live_ev[1], 0), -4);
+    }
+    if (overlap && !dbg_ordered && npin > 0 && gather_lds > 0 && getenv("WENET_RX_LIVE_NO_GATE") == nullptr) {          // the demodulator behind the gate (see the kernel)
+        hipLaunchKernelGGL(wenet_live_gate_kernel, dim3(1), dim3(64), 0, stream, d_gate, seq, d_arrive_err);
+        WR_LIVE_CHECK(hipGetLastError(), -4);
     }
     WR_LIVE_CHECK(hipEventRecord(e.ev[0], stream), -4);
     if (dcs.use_oct) WR_LIVE_CHECK(wr_launch_demod_oct(&dcs.oct_cfg, d_tchans, nchan, stream), -4);
