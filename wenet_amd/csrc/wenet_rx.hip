@@ -16,6 +16,8 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <thread>
 #include <map>
 #include <mutex>
 #include <algorithm>
@@ -939,6 +941,55 @@ __global__ __launch_bounds__(256) void wenet_advance_kernel(WrChan *chans, WrSli
 }
 }  // namespace
 
+// Live ticks from PAGEABLE host memory: the chunks are copied into the handle's pinned staging block by the CPU, and one core moves 24 GB/s -- 1.25 ms for a tick's
+// 29.5 MB, longer than the demodulator runs.  A second thread takes half of every piece's copies.  It spins for work while a tick is in progress (a piece every ~40 us)
+// and sleeps on a condition variable between ticks; it touches host memory only, never the HIP runtime.
+namespace {
+struct StageHelper {
+    struct Item { char *dst; const char *src; size_t len; };
+    std::vector<Item> items;                    // the job: written by the owner before submit(), read by the helper until it reports done
+    std::atomic<unsigned long long> job{0}, done{0};
+    std::atomic<bool> quit{false};
+    std::mutex m;
+    std::condition_variable cv;
+    std::thread th;
+    static inline void relax() {
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    void run() {
+        unsigned long long seen = 0;
+        for (;;) {
+            unsigned long long j;
+            int spins = 0;
+            while ((j = job.load(std::memory_order_acquire)) == seen && !quit.load(std::memory_order_relaxed)) {
+                if (++spins < 20000) relax();
+                else { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return job.load(std::memory_order_acquire) != seen || quit.load(); }); spins = 0; }
+            }
+            if (quit.load()) return;
+            for (const Item &it : items) memcpy(it.dst, it.src, it.len);
+            seen = j;
+            done.store(j, std::memory_order_release);
+        }
+    }
+    bool start() {
+        if (th.joinable()) return true;
+        try { th = std::thread([this] { run(); }); } catch (...) { return false; }
+        return true;
+    }
+    void submit() {
+        job.fetch_add(1, std::memory_order_release);
+        { std::lock_guard<std::mutex> lk(m); }
+        cv.notify_one();
+    }
+    void wait() { while (done.load(std::memory_order_acquire) != job.load(std::memory_order_relaxed)) relax(); }
+    ~StageHelper() {
+        if (th.joinable()) { quit.store(true); { std::lock_guard<std::mutex> lk(m); } cv.notify_one(); th.join(); }
+    }
+};
+}  // namespace
+
 // ================================================================================================
 // batch receive chain
 // ================================================================================================
@@ -964,6 +1015,7 @@ struct wenet_rx {
     DevBuf d_live_tab, d_live_arrive;       // live ticks: channel table | deframer table | new-sample counts | gather list (one upload); the channels' arrival words (WrChan::arrive)
     int live_gathered = 0;                  // chunks of the last tick the device read where the caller keeps them (pinned host memory)
     void *h_stage = nullptr; size_t h_stage_cap = 0;      // live ticks: pinned staging block for chunks in pageable memory
+    StageHelper stage_helper;                             // ... and the second thread that fills it (started with the first tick that has enough to copy)
     const char *d_stage_view = nullptr;     // the address the device reads it at
     hipEvent_t live_ev[2] = {nullptr, nullptr};           // [0] the compaction has run (main stream), [1] the tick's chunks have landed (copy stream)
     bool stage_reserve(size_t bytes) {
@@ -1941,13 +1993,27 @@ extern "C" long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *c
     }
     // chunks in pageable memory: the host copies piece p of every such chunk into the pinned staging block, the device fetches it from there -- while the host copies piece p + 1
     auto stage_and_gather = [&]() -> long long {
+        // (two threads from 4 MB on, unless WENET_RX_LIVE_ONE_STAGER is set: a wake-up costs more than a small tick's copies)
+        const bool two = npage >= 4 && stage_bytes >= (4u << 20) && getenv("WENET_RX_LIVE_ONE_STAGER") == nullptr && rx->stage_helper.start();
+        const size_t k_split = two ? npage / 2 : npage;
         for (int pc = 0; pc < P && npage > 0; pc++) {
-            for (size_t k = 0; k < npage; k++) {
+            if (two) {
+                rx->stage_helper.items.clear();
+                for (size_t k = k_split; k < npage; k++) {
+                    const WrGather &g = gl[npin + k];
+                    long long lo, hi;
+                    live_piece(g.bytes, (unsigned)((uintptr_t)g.dst & 15u), P, pc, first_units, lo, hi);
+                    if (hi > lo) rx->stage_helper.items.push_back(StageHelper::Item{(char *)rx->h_stage + stage_off[k] + lo, (const char *)chunk[page_ch[k]] + lo, (size_t)(hi - lo)});
+                }
+                rx->stage_helper.submit();
+            }
+            for (size_t k = 0; k < k_split; k++) {
                 const WrGather &g = gl[npin + k];
                 long long lo, hi;
                 live_piece(g.bytes, (unsigned)((uintptr_t)g.dst & 15u), P, pc, first_units, lo, hi);
                 if (hi > lo) memcpy((char *)rx->h_stage + stage_off[k] + lo, (const char *)chunk[page_ch[k]] + lo, (size_t)(hi - lo));
             }
+            if (two) rx->stage_helper.wait();
             hipLaunchKernelGGL(wenet_live_gather_kernel, dim3((unsigned)std::min<size_t>(16, npage)), dim3(gather_nt), 0, cstream, d_tgl + npin, (int)npage, P, pc, pc + 1, first_units, seq, nullptr);
             WR_LIVE_CHECK(hipGetLastError(), -4);
         }
