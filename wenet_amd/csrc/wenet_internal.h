@@ -94,7 +94,10 @@ struct WrDemodCfg {
 #ifndef WO_PARK_W32
 #define WO_PARK_W32 4                 // (round 4: measured 2..7 at config 4, profiles/r04_park_w32.txt; development: tools/variant_build.sh ... -DWO_PARK_W32=<W> for demod_oct demod_oct_sliced wenet_rx)
 #endif
-constexpr int wo_park_halfwidth(int Ts) { return Ts >= 32 ? WO_PARK_W32 : 1; }
+#ifndef WO_PARK_W10
+#define WO_PARK_W10 1                 // (the small geometries: W = 2 measured again in round 5 under the run-ahead schedule)
+#endif
+constexpr int wo_park_halfwidth(int Ts) { return Ts >= 32 ? WO_PARK_W32 : WO_PARK_W10; }
 struct WoLayout { int FB, FW, TP, FE, CK, CT, PW, PK, stride, ntw, TW, HANN, DPHI, SRC, BACK, tab, nhb; };
 constexpr int wo_align16(int x) { return (x + 15) & ~15; }
 // hlp: the mix stage of ONE capture on M wavefronts (a tone each: the single-stream form of the large geometry): per-tone power rows and the
