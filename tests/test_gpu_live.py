@@ -214,6 +214,19 @@ def test_three_handles_tick_at_once_and_fill_the_device_together():
         assert all(both[i] == alone[i] for i in range(3)), rep
 
 
+@pytest.mark.parametrize("pinned", [True, "mixed"])
+def test_live_channels_through_the_three_capture_kernel(monkeypatch, pinned):
+    """the three-captures-per-workgroup pipelined kernel (what 1.5 - 3 channels per compute unit take) with carried state, its chunks arriving in pieces beside it
+    (round 5); 23 channels: the last workgroup carries two captures"""
+    monkeypatch.setenv("WENET_RX_TRI", "1")
+    cfg = siggen.config_v2()
+    rng = np.random.default_rng(15)
+    caps = [siggen.make_capture(cfg, 6, 8.5, seed=3300 + ch, ppm=(200.0 if ch % 5 == 0 else 0.0))[0] for ch in range(23)]
+    cuts = [_ragged_cuts(rng, c.size // 2, 90000) for c in caps]
+    out, frames, _ = _run_live(cfg, caps, "cu8", cuts, pinned=pinned)
+    assert _check(cfg, caps, "cu8", out, frames) > 0
+
+
 def test_live_many_channels_through_the_batch_demodulator(monkeypatch):
     """enough channels that the per-tick launch takes the batch demodulator (one wavefront per capture) with carried state"""
     monkeypatch.setenv("WENET_RX_OCT", "7")

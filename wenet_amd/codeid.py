@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "wenet_amd", "csrc")
 # everything that is compiled into the demodulator / decoder kernels (the host-only files wenet_rx.hip, cli_*.cpp are not)
 _KERNEL_SOURCES = ("Makefile", "demod_common.h", "wenet_internal.h", "glibc_atan2f.h", "x87emu.h", "demod_oct_impl.h", "demod_oct.hip", "demod_oct_sliced.hip",
-                   "demod_pipe_impl.h", "demod_tri_impl.h", "demod_chain_split.h", "demod_pipe_shared_1.inc", "demod_pipe_shared_2.inc",
+                   "demod_pipe_impl.h", "demod_tri_impl.h", "demod_chain_split.h", "demod_pipe_arrive.inc", "demod_pipe_shared_1.inc", "demod_pipe_shared_2.inc",
                    "demod_pipe_shared_3.inc", "demod_pipe_shared_4.inc", "demod_pipe_kernel.hip", "demod_pipe_raw.hip", "demod_pipe_tri.hip",
                    "demod_kernel.hip", "ldpc_kernel.hip", "ldpc_host_tables.h", "tables/ldpc_vpos.inc")
 

@@ -127,40 +127,11 @@ __global__ __launch_bounds__(WP_THREADS, RAW ? 6 : 5) void wenet_demod_pipe_kern
     if (tid < M) { PHE[2 * 4 + tid] = hdr->phi_c[tid]; CT[CT_FBIN + 3 * 4 + tid] = hdr->f_bin[tid]; }   // frame -1 -> slots 2 / 3
     if (tid == 0) { CT[CT_CNT] = 0; CT[CT_NIN_NEXT] = hdr->nin; }
     int nin = __builtin_amdgcn_readfirstlane(hdr->nin);
-    // Live ticks: a chunk still crossing PCIe (WrChan::arrive).  Every wavefront that reads samples from global memory keeps its own count of what is in place and
-    // looks at the next piece's word only when its read-ahead gets there (a dozen times per launch).  The pieces' samples were written on other compute units, through
-    // their L2 (agent-scope stores); they are READ at agent scope too (load_raw_agent) -- an acquire fence behind every word instead would invalidate this XCD's whole L2
-    // eighty times per piece and workgroup round (measured: +0.43 ms on a 1.04 ms launch).
-    long long arr_ready = C.arrive ? C.arrive_have : C.nsamples;
-    int arr_p = 0;
-    auto await_samples = [&](long long need) {
-        if (need > C.nsamples) need = C.nsamples;
-        while (arr_ready < need) {                                       // (wave-uniform)
-            if (arr_p >= C.arrive_n) { arr_ready = C.nsamples; break; }
-            const long long t0 = (long long)wall_clock64();
-            unsigned long long w;
-            for (;;) {
-                w = __hip_atomic_load(&C.arrive[arr_p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                w = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(w >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)w);
-                if ((unsigned)(w >> 32) == C.arrive_seq) break;
-                __builtin_amdgcn_s_sleep(8);
-                if ((long long)wall_clock64() - t0 > 200000000LL) {      // 2 s at 100 MHz: the gather never ran -- say so and go on (the host discards the tick)
-                    if (lane == 0 && C.arrive_err) *C.arrive_err = 1u;
-                    w = ((unsigned long long)C.arrive_seq << 32) | (unsigned long long)(unsigned)C.nsamples;
-                    break;
-                }
-            }
-            asm volatile("" ::: "memory");                              // (the samples' loads stay behind the word's)
-            if (lane == 0 && wave == 3 && C.arrive_err) {                // development statistics (WENET_RX_LIVE_TIMING): ticks of 10 ns this workgroup's first D wave waited, longest wait
-                const unsigned dt = (unsigned)((long long)wall_clock64() - t0);
-                atomicAdd(C.arrive_err + 1, dt); atomicMax(C.arrive_err + 2, dt); atomicAdd(C.arrive_err + 3, arr_p == 0 ? dt : 0u);
-            }
-            arr_ready = (long long)(unsigned)w;
-            arr_p++;
-        }
-    };
-    const bool arr_live = C.arrive != nullptr;
-    auto load_sample = [&](long long i) -> uint2 { return arr_live ? load_raw_agent(C.raw, fmt_k, i) : load_raw(C.raw, fmt_k, i); };
+#define WP_ARRIVE_STAT (wave == 3)
+#define WP_ARRIVE_ON true
+#include "demod_pipe_arrive.inc"
+#undef WP_ARRIVE_ON
+#undef WP_ARRIVE_STAT
     // first 4*Nmax samples into the ring
     await_samples(4LL * Nmax);
     {

@@ -67,7 +67,9 @@ enum { CT_NIN_NEXT = 0, CT_CNT = 1, CT_CONT = 2 /* this capture has another fram
 // sample; (u8-127)/128 is exact, so converting at each read gives the same floats) and the timing-product
 // phasors stay in global memory.  That brings the workgroup under a third of a CU's LDS and, with the register
 // bound below, lets THREE captures share a CU instead of two.
-template <int M>
+// LIVE: the instantiation for live ticks whose chunks arrive beside the launch (demod_pipe_arrive.inc; in the batch instantiation none of that is compiled:
+// its waits, words and agent-scope loads cost the three-capture kernel 3 % per frame even when unused -- 27 more scalar registers spilled)
+template <int M, bool LIVE>
 __global__ __launch_bounds__(WP_THREADS, 4) void wenet_demod_tri_kernel(WrDemodCfg cfg, const WrChan *chans, int nchan) {
     constexpr bool RAW = true;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -139,6 +141,11 @@ __global__ __launch_bounds__(WP_THREADS, 4) void wenet_demod_tri_kernel(WrDemodC
         for (int i = tid; i < Ndft; i += WP_THREADS) { tw_w[i] = cfg.tw[i]; hann_w[i] = cfg.hann[i]; src_w[i] = cfg.fft_src[i]; }
         for (int i = tid; i < NH; i += WP_THREADS) dphi_w[i] = cfg.dphi_tab[i];
     }
+#define WP_ARRIVE_STAT (is_d && dwave == 0)
+#define WP_ARRIVE_ON LIVE
+#include "demod_pipe_arrive.inc"
+#undef WP_ARRIVE_ON
+#undef WP_ARRIVE_STAT
     int nin = N;
     if (!is_chain) {                                                     // every capture is loaded by its own five waves
         for (int i = ctid; i < NH; i += WT_CTHREADS) FEr[3 * NH + i] = present ? st_fft[i] : 0.f;       // "after frame -1" lives in slot 3
@@ -152,8 +159,9 @@ __global__ __launch_bounds__(WP_THREADS, 4) void wenet_demod_tri_kernel(WrDemodC
         if (ctid == 0) { CT[CT_CNT] = 0; CT[30] = 0; CT[CT_NIN_NEXT] = nin; CT[CT_CONT] = (present && (long long)nin <= C.nsamples && C.cap_frames > 0) ? 1 : 0; }
         // first 4*Nmax samples into the ring
         const long long last = C.nsamples - 1;
+        if constexpr (LIVE) await_samples(4LL * Nmax);
         for (long long i = ctid; i < 4LL * Nmax; i += WT_CTHREADS)
-#define WP_LOAD_SAMPLE(i_) load_raw(C.raw, fmt_k, (i_))
+#define WP_LOAD_SAMPLE(i_) (LIVE ? load_sample(i_) : load_raw(C.raw, fmt_k, (i_)))
 #include "demod_pipe_shared_1.inc"
     auto chain = [&](int j, int nin_j, int capmask) {                   // C(j) of the captures in capmask (lanes 4c..4c+3 carry capture c)
         // (the packed form of the one-capture kernel -- one lane per capture and tone, shorter dependent path -- measured 9 % slower
@@ -303,8 +311,9 @@ __global__ __launch_bounds__(WP_THREADS, 4) void wenet_demod_tri_kernel(WrDemodC
     for (int k = 0; k < WP_KP; k++) pre[k] = make_uint2(0u, 0u);
     if (is_d && mine0) {
         const long long last = C.nsamples - 1;
+        if constexpr (LIVE) await_samples(filled + WP_KP * WP_DSP_THREADS);
 #pragma unroll
-        for (int k = 0; k < WP_KP; k++) { long long i = filled + t + WP_DSP_THREADS * k; pre[k] = load_raw(C.raw, fmt_k, i < last ? i : last); }
+        for (int k = 0; k < WP_KP; k++) { long long i = filled + t + WP_DSP_THREADS * k; pre[k] = LIVE ? load_sample(i < last ? i : last) : load_raw(C.raw, fmt_k, i < last ? i : last); }
     }
 
     // ================================ frame loop ===============================================
@@ -384,8 +393,9 @@ __global__ __launch_bounds__(WP_THREADS, 4) void wenet_demod_tri_kernel(WrDemodC
 #pragma unroll
                        for (int k = 0; k < WP_KP; k++) { const int i = t + WP_DSP_THREADS * k; if (i < nin) ring_put_raw(RIDX(filled + i), pre[k], fmt_k); }
                        const long long nf = filled + nin, last = C.nsamples - 1;
+                       if constexpr (LIVE) await_samples(nf + WP_KP * WP_DSP_THREADS);
 #pragma unroll
-                       for (int k = 0; k < WP_KP; k++) { long long i = nf + t + WP_DSP_THREADS * k; pre[k] = load_raw(C.raw, fmt_k, i < last ? i : last); }
+                       for (int k = 0; k < WP_KP; k++) { long long i = nf + t + WP_DSP_THREADS * k; pre[k] = LIVE ? load_sample(i < last ? i : last) : load_raw(C.raw, fmt_k, i < last ? i : last); }
                        dstage(kf + 1, off1, N);                          // D(k+1), speculative
                    },
                    nothing, nothing,

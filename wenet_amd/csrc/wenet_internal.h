@@ -63,6 +63,7 @@ struct WrDemodCfg {
     int p_tsum_split;                    // timing sum with re/im in separate lanes and plain adds (less SIMD time, more latency): batch launches
     unsigned tri_role, tri_cap, tri_dw;  // three-capture kernel: role (0 chain, 1 estimator, 2 timing, 3 mix/integrate), capture and D-wave index of each of the 16 wavefronts, two bits each
     int p_tri, p_cap_stride;             // three captures per workgroup (demod_tri_impl.h): this copy carries that layout; bytes between the captures' LDS blocks
+    int p_live, p_pad_live;              // a live tick whose chunks arrive beside the launch (WrChan::arrive): the three-capture kernel has an instantiation of its own for that
     int p_raw;                           // this copy of the configuration carries the raw-cu8-ring layout (3 captures per CU)
     int p_off_CK, p_off_CKD, p_off_TP;
     int p_off_XR, p_off_PH, p_off_FI, p_off_FB, p_off_FE, p_off_FW, p_off_SD, p_off_SC, p_off_PHE, p_off_CT;

@@ -1891,9 +1891,9 @@ extern "C" long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *c
     rx->cap_frames = capf;
     const DemodChoice dcs = choose_demod(rx, nchan, fmt);
     rx->last_kernel = dcs.use_oct ? "wenet_demod_oct_kernel" : (dcs.launch_cfg.p_tri ? "wenet_demod_tri_kernel" : (dcs.launch_cfg.pipe_ok && !dcs.launch_cfg.big ? "wenet_demod_pipe_kernel" : "wenet_demod_kernel"));
-    // the pipelined kernel takes the chunks as they arrive (WrChan::arrive); the other demodulators start when the gather has finished
+    // the pipelined kernels (one capture per workgroup, three per workgroup) take the chunks as they arrive (WrChan::arrive); the batch demodulator starts when the gather has finished
     const bool no_overlap = getenv("WENET_RX_NO_LIVE_OVERLAP") != nullptr;
-    const bool overlap = !no_overlap && !dcs.use_oct && !dcs.launch_cfg.p_tri && dcs.launch_cfg.pipe_ok && !dcs.launch_cfg.big && (unsigned long long)(rx->live_in_stride / (long long)bps) < 0xffffffffull;
+    const bool overlap = !no_overlap && !dcs.use_oct && dcs.launch_cfg.pipe_ok && !dcs.launch_cfg.big && (unsigned long long)(rx->live_in_stride / (long long)bps) < 0xffffffffull;
     const int P = WR_LIVE_PIECES;
     const long long first_units = ((long long)(6 * (c.N + c.Ts / 2) + 640 + 64) * (long long)bps + 15) / 16;      // the prologue reads 4 frames of the longest kind, the first frame's prefetch two more and 640 samples
     const unsigned seq = (unsigned)(rx->live_ticks + 1);
@@ -1978,7 +1978,7 @@ extern "C" long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *c
         }
         // LDS the gather's workgroups reserve: what a compute unit has, less what a demodulator workgroup needs, and a little -- neither fits beside the other.  Only while
         // the demodulator's workgroups (one per channel) leave compute units free: a gather that found none would never start, and the demodulator would wait for it.
-        const size_t need = (size_t)dcs.launch_cfg.p_lds_bytes, free_cu = ncu > (size_t)nchan ? ncu - (size_t)nchan : 0;
+        const size_t need = (size_t)dcs.launch_cfg.p_lds_bytes, demod_wgs = dcs.launch_cfg.p_tri ? ((size_t)nchan + 2) / 3 : (size_t)nchan, free_cu = ncu > demod_wgs ? ncu - demod_wgs : 0;      // (the three-capture kernel: a workgroup per three channels)
         if (lds_cu > need && free_cu >= 8) {
             gather_lds = std::min(lds_wg, ((lds_cu - need + 1024 + 255) & ~(size_t)255));
             if (gather_lds + need <= lds_cu) gather_lds = 0;          // (the device does not let one workgroup reserve that much: shared compute units then)
@@ -2036,7 +2036,11 @@ extern "C" long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *c
     }
     WR_LIVE_CHECK(hipEventRecord(e.ev[0], stream), -4);
     if (dcs.use_oct) WR_LIVE_CHECK(wr_launch_demod_oct(&dcs.oct_cfg, d_tchans, nchan, stream), -4);
-    else WR_LIVE_CHECK(wr_launch_demod_ex(&dcs.launch_cfg, d_tchans, nchan, stream, 0), -4);
+    else {
+        WrDemodCfg lc = dcs.launch_cfg;
+        lc.p_live = overlap ? 1 : 0;                                     // (the three-capture kernel's instantiation that takes chunks as they arrive)
+        WR_LIVE_CHECK(wr_launch_demod_ex(&lc, d_tchans, nchan, stream, 0), -4);
+    }
     WR_LIVE_CHECK(hipMemsetAsync(rx->d_census.p, 0, cen_bytes - 16, stream), -3);
     if (overlap && !dbg_ordered) {                                       // the demodulator is running: feed it
         if (const long long rc = stage_and_gather()) return rc;
