@@ -942,14 +942,21 @@ __global__ __launch_bounds__(256) void wenet_advance_kernel(WrChan *chans, WrSli
 }  // namespace
 
 // Live ticks from PAGEABLE host memory: the chunks are copied into the handle's pinned staging block by the CPU, and one core moves 24 GB/s -- 1.25 ms for a tick's
-// 29.5 MB, longer than the demodulator runs.  A second thread takes half of every piece's copies.  It spins for work while a tick is in progress (a piece every ~40 us)
-// and sleeps on a condition variable between ticks; it touches host memory only, never the HIP runtime.
+// 29.5 MB, longer than the demodulator runs.  A second thread helps: the copies of a piece are a list both threads take items from (one atomic ticket word), so the
+// calling thread never waits for the helper to WAKE -- a helper that sleeps through a piece has simply not helped (it sleeps on a condition variable between ticks and
+// spins for work while pieces keep coming).  It touches host memory only, never the HIP runtime.
 namespace {
 struct StageHelper {
     struct Item { char *dst; const char *src; size_t len; };
-    std::vector<Item> items;                    // the job: written by the owner before submit(), read by the helper until it reports done
-    std::atomic<unsigned long long> job{0}, done{0};
-    std::atomic<bool> quit{false};
+    std::vector<Item> items;                    // the piece's copies: written by the owner while no ticket of the piece is out, read by both threads
+    // ticket word: [63:48] piece number (wraps), [47:24] items of the piece, [23:0] next item -- one fetch_add hands out an item of the piece the word describes,
+    // whichever piece the taker thought it was working on
+    // (an item of the ticket is a BATCH of `grain` copies: a ticket costs two cache-line transfers between the cores, ~0.5 us -- per 14 KB copy that was more than the copy)
+    alignas(64) std::atomic<unsigned long long> ticket{0};
+    alignas(64) std::atomic<unsigned> finished{0};
+    alignas(64) std::atomic<bool> quit{false};
+    std::atomic<bool> asleep{false};
+    unsigned piece = 0, grain = 1;
     std::mutex m;
     std::condition_variable cv;
     std::thread th;
@@ -958,19 +965,28 @@ struct StageHelper {
         __builtin_ia32_pause();
 #endif
     }
+    static inline bool has_work(unsigned long long t) { return (unsigned)(t & 0xffffffu) < (unsigned)((t >> 24) & 0xffffffu); }
+    bool take() {                               // copy one item if there is one
+        unsigned long long t = ticket.load(std::memory_order_acquire);
+        if (!has_work(t)) return false;
+        t = ticket.fetch_add(1, std::memory_order_acq_rel);
+        if (!has_work(t)) return false;
+        const size_t lo = (size_t)(t & 0xffffffu) * grain, hi = std::min(items.size(), lo + grain);
+        for (size_t i = lo; i < hi; i++) memcpy(items[i].dst, items[i].src, items[i].len);
+        finished.fetch_add(1, std::memory_order_release);
+        return true;
+    }
     void run() {
-        unsigned long long seen = 0;
+        int idle = 0;
         for (;;) {
-            unsigned long long j;
-            int spins = 0;
-            while ((j = job.load(std::memory_order_acquire)) == seen && !quit.load(std::memory_order_relaxed)) {
-                if (++spins < 20000) relax();
-                else { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return job.load(std::memory_order_acquire) != seen || quit.load(); }); spins = 0; }
-            }
-            if (quit.load()) return;
-            for (const Item &it : items) memcpy(it.dst, it.src, it.len);
-            seen = j;
-            done.store(j, std::memory_order_release);
+            if (quit.load(std::memory_order_relaxed)) return;
+            if (take()) { idle = 0; continue; }
+            if (++idle < 200000) { relax(); continue; }      // ~3 ms of looking for work, then sleep until a piece is published
+            std::unique_lock<std::mutex> lk(m);
+            asleep.store(true, std::memory_order_seq_cst);
+            cv.wait(lk, [&] { return has_work(ticket.load(std::memory_order_acquire)) || quit.load(); });
+            asleep.store(false, std::memory_order_seq_cst);
+            idle = 0;
         }
     }
     bool start() {
@@ -978,12 +994,18 @@ struct StageHelper {
         try { th = std::thread([this] { run(); }); } catch (...) { return false; }
         return true;
     }
-    void submit() {
-        job.fetch_add(1, std::memory_order_release);
-        { std::lock_guard<std::mutex> lk(m); }
-        cv.notify_one();
+    // the owner: publish the piece whose copies are in `items`, copy alongside, return when every item has been copied
+    void copy_all() {
+        if (items.size() < 8) { for (const Item &it : items) memcpy(it.dst, it.src, it.len); return; }
+        grain = (unsigned)((items.size() + 15) / 16);                      // sixteen batches per piece (no ticket is out: the helper reads `grain` behind its ticket)
+        const unsigned n = (unsigned)((items.size() + grain - 1) / grain);
+        finished.store(0, std::memory_order_relaxed);
+        piece++;
+        ticket.store(((unsigned long long)(piece & 0xffffu) << 48) | ((unsigned long long)n << 24), std::memory_order_seq_cst);
+        if (asleep.load(std::memory_order_seq_cst)) { { std::lock_guard<std::mutex> lk(m); } cv.notify_one(); }
+        while (take()) {}
+        while (finished.load(std::memory_order_acquire) != n) relax();      // (an item the helper is still copying: microseconds)
     }
-    void wait() { while (done.load(std::memory_order_acquire) != job.load(std::memory_order_relaxed)) relax(); }
     ~StageHelper() {
         if (th.joinable()) { quit.store(true); { std::lock_guard<std::mutex> lk(m); } cv.notify_one(); th.join(); }
     }
@@ -1993,27 +2015,19 @@ extern "C" long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *c
     }
     // chunks in pageable memory: the host copies piece p of every such chunk into the pinned staging block, the device fetches it from there -- while the host copies piece p + 1
     auto stage_and_gather = [&]() -> long long {
-        // (two threads from 4 MB on, unless WENET_RX_LIVE_ONE_STAGER is set: a wake-up costs more than a small tick's copies)
+        // (two threads from 4 MB on, unless WENET_RX_LIVE_ONE_STAGER is set: below that a tick's copies take less than a wake-up)
         const bool two = npage >= 4 && stage_bytes >= (4u << 20) && getenv("WENET_RX_LIVE_ONE_STAGER") == nullptr && rx->stage_helper.start();
-        const size_t k_split = two ? npage / 2 : npage;
         for (int pc = 0; pc < P && npage > 0; pc++) {
-            if (two) {
-                rx->stage_helper.items.clear();
-                for (size_t k = k_split; k < npage; k++) {
-                    const WrGather &g = gl[npin + k];
-                    long long lo, hi;
-                    live_piece(g.bytes, (unsigned)((uintptr_t)g.dst & 15u), P, pc, first_units, lo, hi);
-                    if (hi > lo) rx->stage_helper.items.push_back(StageHelper::Item{(char *)rx->h_stage + stage_off[k] + lo, (const char *)chunk[page_ch[k]] + lo, (size_t)(hi - lo)});
-                }
-                rx->stage_helper.submit();
-            }
-            for (size_t k = 0; k < k_split; k++) {
+            std::vector<StageHelper::Item> &items = rx->stage_helper.items;      // (no ticket of an earlier piece is out: copy_all returned)
+            items.clear();
+            for (size_t k = 0; k < npage; k++) {
                 const WrGather &g = gl[npin + k];
                 long long lo, hi;
                 live_piece(g.bytes, (unsigned)((uintptr_t)g.dst & 15u), P, pc, first_units, lo, hi);
-                if (hi > lo) memcpy((char *)rx->h_stage + stage_off[k] + lo, (const char *)chunk[page_ch[k]] + lo, (size_t)(hi - lo));
+                if (hi > lo) items.push_back(StageHelper::Item{(char *)rx->h_stage + stage_off[k] + lo, (const char *)chunk[page_ch[k]] + lo, (size_t)(hi - lo)});
             }
-            if (two) rx->stage_helper.wait();
+            if (two) rx->stage_helper.copy_all();
+            else for (const StageHelper::Item &it : items) memcpy(it.dst, it.src, it.len);
             hipLaunchKernelGGL(wenet_live_gather_kernel, dim3((unsigned)std::min<size_t>(16, npage)), dim3(gather_nt), 0, cstream, d_tgl + npin, (int)npage, P, pc, pc + 1, first_units, seq, nullptr);
             WR_LIVE_CHECK(hipGetLastError(), -4);
         }
