@@ -42,5 +42,7 @@ for kind in kinds:
     sys.stderr.flush()
     rx.flush(); rx.close()
     lat = np.array(lat) * 1e3
+    top = np.argsort(lat)[-4:][::-1]
+    print("   slowest ticks:", ", ".join(f"#{int(i)} {lat[i]:.2f} ms" for i in top), flush=True)
     print(f"{nch} channels, {kind}: {len(lat)} ticks, mean {lat.mean():.3f} ms, median {np.median(lat):.3f}, best {lat.min():.3f}, worst {lat.max():.3f}; kernels per tick: demod {kms[0] / len(lat):.3f} "
           f"deframe {kms[1] / len(lat):.3f} decode {kms[2] / len(lat):.3f}; packets {pk}; chunks gathered {g}", flush=True)

@@ -1845,7 +1845,7 @@ extern "C" long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *c
     lap();
     // (2) room for this tick: carried + new samples per channel, carried + new symbols; growing keeps what is carried
     const long long min_nin = c.N - c.Ts / 2;
-    long long need_smp = 0, need_sym = 0, max_pk = 1;
+    long long need_smp = 0, need_sym = 0, max_pk = 1, room_smp = 0, room_sym = 0;
     std::vector<long long> capf(nchan);
     for (int i = 0; i < nchan; i++) {
         const long long have = rx->live_carry_smp[i] + nsamples[i];
@@ -1853,7 +1853,13 @@ extern "C" long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *c
         const long long sym = rx->live_carry_sym[i] + capf[i] * c.Nbits;
         need_smp = std::max(need_smp, have); need_sym = std::max(need_sym, sym);
         max_pk = std::max(max_pk, sym / rx->spp + 1);
+        // (room as if the channel already carried what it can carry at most -- samples short of a frame, symbols short of a packet: the second and third tick of a set of
+        //  streams, the first with leftovers, then fit the blocks of the first; growing them cost each 1.3 ms)
+        const long long have_most = nsamples[i] + 2LL * (c.N + c.Ts / 2), sym_most = (have_most / min_nin + 1) * c.Nbits + rx->spp + 64;
+        room_smp = std::max(room_smp, have_most); room_sym = std::max(room_sym, sym_most);
     }
+    need_smp = std::max(need_smp, room_smp); need_sym = std::max(need_sym, room_sym);
+    const long long max_pk_room = std::max(max_pk, need_sym / rx->spp + 1);
     const long long in_stride = (((need_smp + need_smp / 4) * (long long)bps + 255) & ~255LL) + 256, sd_stride = ((need_sym + need_sym / 4 + 63) & ~63LL) + 64;
     lap();
     // (1) what the previous tick left undone moves to the front of the blocks (the device works on it while the host prepares the tick's tables)
@@ -1888,7 +1894,7 @@ extern "C" long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *c
     {   // (the slot count per channel creeps up by one or two over the first ticks: room for that at once -- a reallocation costs a tick half a millisecond)
         const size_t need_slots = (size_t)nchan * max_pk;
         if (need_slots * 8 > rx->d_starts.cap || need_slots * sizeof(WrPacketOut) > rx->d_out.cap || wr_dec_scratch_bytes(need_slots) > rx->d_esn0.cap) {
-            const size_t room = (size_t)nchan * (2 * max_pk + 2);
+            const size_t room = (size_t)nchan * (size_t)(max_pk_room + 2);
             if (!rx->d_starts.reserve(room * 8) || !rx->d_out.reserve(room * sizeof(WrPacketOut)) || !rx->d_esn0.reserve(wr_dec_scratch_bytes(room))) { live_close(rx); return -2; }
         }
     }
@@ -1903,7 +1909,7 @@ extern "C" long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *c
     const size_t n_slots = (size_t)nchan * max_pk, out_bytes = n_slots * sizeof(WrPacketOut), st_bytes = n_slots * 8, cen_bytes = (size_t)nchan * WR_CENSUS_CLASSES * 4 + 16;      // (+ the arrival error word and three statistics words)
     const size_t o_starts = al64(out_bytes), o_hdr = al64(o_starts + st_bytes), o_dst = al64(o_hdr + sizeof(WrChanHdr) * nchan), o_cen = al64(o_dst + sizeof(WrDeframeState) * nchan),
                  o_chans = al64(o_cen + cen_bytes), o_dch = o_chans + t_dch, o_new = o_chans + t_new, o_gl = o_chans + t_gl, pin_total = o_chans + t_total + 64;
-    if (pin_total > rx->h_pin_cap && !rx->pin_reserve(pin_total + (size_t)nchan * (size_t)(max_pk + 2) * (sizeof(WrPacketOut) + 8))) { live_close(rx); return -2; }      // (room for the slot count's creep: pinning is slow)
+    if (pin_total > rx->h_pin_cap && !rx->pin_reserve(pin_total + (size_t)nchan * (size_t)(max_pk_room - max_pk + 2) * (sizeof(WrPacketOut) + 8))) { live_close(rx); return -2; }      // (room for the slot count's creep: pinning is slow)
     if (!rx->d_census.reserve(cen_bytes)) { live_close(rx); return -2; }
     char *hp = (char *)rx->h_pin;
     WrChan *chans = (WrChan *)(hp + o_chans);
