@@ -253,7 +253,10 @@ __device__ __forceinline__ double packet_symbol(const WrDecodeArgs &A, unsigned 
 // LDS with coalesced loads (two packets x 128 B per instruction, the next chunk in flight while this one is
 // summed) and the lanes then read their column conflict-free.
 // Output: estEsN0 per packet slot, with the reference's x87 rounding (x87emu.h).
-#define WR_ST_CHUNK 32
+#ifndef WR_ST_CHUNK
+#define WR_ST_CHUNK 64                                           // symbols of a packet per step: 64 = a load instruction fetches 256 consecutive bytes of ONE packet (round 5, late: 1.36 -> 1.13 ms per 244 k
+                                                                 // packets against 32 = two packets' 128 bytes each -- longer bursts per packet; 128 = 512 bytes, four wavefronts per CU: 1.79)
+#endif
 #define WR_ST_PITCH 65                                           // row pitch in elements: the transposing writes spread over the banks
 #ifndef WR_ST_BUFS
 #define WR_ST_BUFS 1
@@ -261,7 +264,8 @@ __device__ __forceinline__ double packet_symbol(const WrDecodeArgs &A, unsigned 
 template <bool SD64>                                             // SD64: double input of the sd_to_llr API; else the float sd stream
 __global__ __launch_bounds__(64) void wenet_llr_stats_kernel(WrDecodeArgs A) {
     typedef typename std::conditional<SD64, double, float>::type elt;
-    __shared__ elt buf[WR_ST_BUFS][WR_ST_CHUNK * WR_ST_PITCH];      // (round 5: ONE staging buffer -- chunk c + 1 is stashed only after chunk c has been summed, so a second one bought nothing and cost half the resident wavefronts: the kernel is bound by the bytes it keeps in flight)
+    constexpr int CH = SD64 ? 32 : WR_ST_CHUNK;                  // symbols of a packet per step (the double-precision entry keeps 32: its rows are twice as wide)
+    __shared__ elt buf[WR_ST_BUFS][CH * WR_ST_PITCH];      // (round 5: ONE staging buffer -- chunk c + 1 is stashed only after chunk c has been summed, so a second one bought nothing and cost half the resident wavefronts: the kernel is bound by the bytes it keeps in flight)
     __shared__ unsigned long long pbase[64];                     // per packet: address of its symbol 0
     __shared__ uint8_t scr[128];
     const int lane = threadIdx.x;
@@ -291,32 +295,43 @@ __global__ __launch_bounds__(64) void wenet_llr_stats_kernel(WrDecodeArgs A) {
     if (!SD64 && A.mode == 2) { scr[lane] = A.scramble[lane]; if (lane + 64 < 125) scr[lane + 64] = A.scramble[lane + 64]; }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    const int sub = lane >> 5, col = lane & 31;                  // load phase: lanes 0-31 fetch packet 2g, lanes 32-63 packet 2g+1
-    const int nchunks = (n + WR_ST_CHUNK - 1) / WR_ST_CHUNK;
-    elt pre[32];
+    // load phase: a load instruction fetches 64 consecutive symbols -- of two packets (CH 32: lanes 0-31 packet 2g, lanes 32-63 packet 2g+1), of one (CH 64), or half of one's
+    // step (CH 128: LPK = 2 instructions per packet)
+    constexpr int PPI = CH < 64 ? 64 / CH : 1, LPK = CH > 64 ? CH / 64 : 1, NGP = 64 / PPI, NG = NGP * LPK;
+    const int sub = CH < 64 ? lane / CH : 0;
+    const int nchunks = (n + CH - 1) / CH;
+    elt pre[NG];
     // raw loads only (nothing here waits for them): pre[g] = stored symbol of packet 2g+sub that becomes symbol c*32+col
     auto fetch = [&](int c) {
-        const int i = c * WR_ST_CHUNK + col;
-        long long off;                                           // element offset inside the packet's storage
-        if (SD64 || A.mode != 1) off = i;
-        else off = 10 * (i >> 3) + 8 - (i & 7);                  // RS232 strip: out[8b+j] = in[10b + 8 - j] (drs232_ldpc.c:220-225)
 #pragma unroll
-        for (int g = 0; g < 32; g++) {
-            const unsigned long long pb = pbase[2 * g + sub];
-            elt v = 0;
-            // (global address space: a FLAT load would count on lgkmcnt too, and the wait for the LDS writes below would wait for it)
-            if (pb != 0ull && i < n) v = ((const __attribute__((address_space(1))) elt *)pb)[off];
-            pre[g] = v;
+        for (int part = 0; part < LPK; part++) {
+            const int col = CH < 64 ? lane % CH : part * 64 + lane;
+            const int i = c * CH + col;
+            long long off;                                       // element offset inside the packet's storage
+            if (SD64 || A.mode != 1) off = i;
+            else off = 10 * (i >> 3) + 8 - (i & 7);              // RS232 strip: out[8b+j] = in[10b + 8 - j] (drs232_ldpc.c:220-225)
+#pragma unroll
+            for (int g = 0; g < NGP; g++) {
+                const unsigned long long pb = pbase[PPI * g + sub];
+                elt v = 0;
+                // (global address space: a FLAT load would count on lgkmcnt too, and the wait for the LDS writes below would wait for it)
+                if (pb != 0ull && i < n) v = ((const __attribute__((address_space(1))) elt *)pb)[off];
+                pre[part * NGP + g] = v;
+            }
         }
     };
     auto stash = [&](int c) {                                    // registers -> LDS [symbol][packet], v2 descrambling applied here
-        elt sg = 1;
-        if (!SD64 && A.mode == 2) {                              // symbol * scramble_code[ind % 1000] (wenet_ldpc.c:207)
-            const int kb = (c * WR_ST_CHUNK + col) % 1000;
-            if ((scr[kb >> 3] >> (7 - (kb & 7))) & 1) sg = -1;
-        }
 #pragma unroll
-        for (int g = 0; g < 32; g++) buf[c % WR_ST_BUFS][col * WR_ST_PITCH + 2 * g + sub] = pre[g] * sg;
+        for (int part = 0; part < LPK; part++) {
+            const int col = CH < 64 ? lane % CH : part * 64 + lane;
+            elt sg = 1;
+            if (!SD64 && A.mode == 2) {                          // symbol * scramble_code[ind % 1000] (wenet_ldpc.c:207)
+                const int kb = (c * CH + col) % 1000;
+                if ((scr[kb >> 3] >> (7 - (kb & 7))) & 1) sg = -1;
+            }
+#pragma unroll
+            for (int g = 0; g < NGP; g++) buf[c % WR_ST_BUFS][col * WR_ST_PITCH + PPI * g + sub] = pre[part * NGP + g] * sg;
+        }
     };
     double mean = 0.0, sum = 0.0, sumsq = 0.0;
     // Second pass, s / mean (mpdecode_core.c:585): the divisor is the packet's, so its correctly rounded reciprocal y = 1.0 / mean is formed once and every quotient is
@@ -333,18 +348,18 @@ __global__ __launch_bounds__(64) void wenet_llr_stats_kernel(WrDecodeArgs A) {
             if (c + 1 < nchunks) fetch(c + 1);                   // in flight while chunk c is summed
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
-            const int cnt = (n - c * WR_ST_CHUNK) < WR_ST_CHUNK ? (n - c * WR_ST_CHUNK) : WR_ST_CHUNK;
+            const int cnt = (n - c * CH) < CH ? (n - c * CH) : CH;
             const elt *colp = &buf[c % WR_ST_BUFS][lane];
             // (whole chunks -- all but a packet's last -- run unrolled: the column's LDS reads go out together and the loop's counter, address step and per-element
             //  wait disappear; the sums stay in the reference's order)
-            if (pass == 0 && cnt == WR_ST_CHUNK) {
+            if (pass == 0 && cnt == CH) {
 #pragma unroll
-                for (int i = 0; i < WR_ST_CHUNK; i++) sum += fabs((double)colp[i * WR_ST_PITCH]);
+                for (int i = 0; i < CH; i++) sum += fabs((double)colp[i * WR_ST_PITCH]);
             } else if (pass == 0) {
                 for (int i = 0; i < cnt; i++) sum += fabs((double)colp[i * WR_ST_PITCH]);
-            } else if (fastdiv && cnt == WR_ST_CHUNK) {
+            } else if (fastdiv && cnt == CH) {
 #pragma unroll
-                for (int i = 0; i < WR_ST_CHUNK; i++) {
+                for (int i = 0; i < CH; i++) {
                     const double s = (double)colp[i * WR_ST_PITCH];
                     const double sign = (double)((s > 0.0) - (s < 0.0));
                     const double q0 = s * ymean, e = __builtin_fma(-q0, mean, s), q = __builtin_fma(e, ymean, q0);
