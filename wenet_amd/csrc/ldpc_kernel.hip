@@ -35,10 +35,11 @@
 // =============================================================================================
 // deframer
 // =============================================================================================
-__global__ __launch_bounds__(64) void wenet_deframe_kernel(const WrDeframeChan *chans, int nchan, int mode) {
+__global__ __launch_bounds__(64) void wenet_deframe_kernel(const WrDeframeChan *chans, int nchan, int mode, unsigned *census_clear) {
     const int ch = blockIdx.x;
     if (ch >= nchan) return;
     const int lane = threadIdx.x;
+    if (census_clear && lane < WR_CENSUS_CLASSES) census_clear[(size_t)ch * WR_CENSUS_CLASSES + lane] = 0u;      // (live ticks: the channel's census row, counted into by the CRC kernel later in the stream -- one fill launch less)
     const WrDeframeChan C = chans[ch];
     const long long n = C.nframes_src ? C.nsym + (*C.nframes_src) * (long long)C.nbits_per_frame : C.nsym;      // (live channels: carried symbols + this tick's frames)
 
@@ -449,6 +450,10 @@ __global__ __launch_bounds__(256) void wenet_llr_stats_small_kernel(WrDecodeArgs
         }
     }
     if (tid == 0) A.pbase[slot] = live ? base : 0ull;
+    if (A.zero_in_stats) {                                                      // (what wr_launch_decode otherwise clears with a fill launch: this slot's agreement records; slot 0: the work counter and the list's count)
+        if (A.agree && tid < WR_DEC_THREADS / 64) A.agree[slot * (WR_DEC_THREADS / 64) + tid] = 0u;
+        if (slot == 0 && tid == 32) { A.work[0] = 0u; if (A.redo) A.redo[0] = 0u; }
+    }
     if (!live) return;
     const __attribute__((address_space(1))) elt *src = (const __attribute__((address_space(1))) elt *)base;
     for (int i = tid; i < n; i += 256) {
@@ -1028,22 +1033,28 @@ extern "C" hipError_t wr_launch_phi0(const uint4 *d_lut, const float *d_x, float
     return hipGetLastError();
 }
 
-extern "C" hipError_t wr_launch_deframe(const WrDeframeChan *d_chans, int nchan, int mode, hipStream_t stream) {
+extern "C" hipError_t wr_launch_deframe_ex(const WrDeframeChan *d_chans, int nchan, int mode, hipStream_t stream, unsigned *census_clear) {
     if (nchan <= 0) return hipSuccess;
-    hipLaunchKernelGGL(wenet_deframe_kernel, dim3(nchan), dim3(64), 0, stream, d_chans, nchan, mode);
+    hipLaunchKernelGGL(wenet_deframe_kernel, dim3(nchan), dim3(64), 0, stream, d_chans, nchan, mode, census_clear);
     return hipGetLastError();
 }
+extern "C" hipError_t wr_launch_deframe(const WrDeframeChan *d_chans, int nchan, int mode, hipStream_t stream) { return wr_launch_deframe_ex(d_chans, nchan, mode, stream, nullptr); }
 
 extern "C" hipError_t wr_launch_decode(const WrDecodeArgs *args, hipStream_t stream) {
     if (args->nchan <= 0 || args->max_pk <= 0) return hipSuccess;
     const long long slots = (long long)args->nchan * args->max_pk;
+    bool cleared_by_stats = false;
     if (args->input_kind != WR_DEC_IN_LLR && args->phase != 2)
     {
         const char *ev = getenv("WENET_RX_SMALL_STATS_SLOTS");                                  // (tests: 0 = the one-lane-per-packet kernel for every batch)
         const long long small_max = ev ? atoll(ev) : (long long)WR_ST_SMALL_SLOTS;
         if (slots <= small_max) {
-            if (args->input_kind == WR_DEC_IN_SD64) hipLaunchKernelGGL(wenet_llr_stats_small_kernel<true>, dim3((unsigned)slots), dim3(256), 0, stream, *args);
-            else hipLaunchKernelGGL(wenet_llr_stats_small_kernel<false>, dim3((unsigned)slots), dim3(256), 0, stream, *args);
+            // a launch that decodes too (phase 0), first pass of the guard: the statistics kernel clears what the decode kernel counts in -- its workgroups are the packet slots
+            WrDecodeArgs as = *args;
+            as.zero_in_stats = (args->phase == 0 && !args->redo_in && !args->stop_after_llr) ? 1 : 0;
+            cleared_by_stats = as.zero_in_stats != 0;
+            if (args->input_kind == WR_DEC_IN_SD64) hipLaunchKernelGGL(wenet_llr_stats_small_kernel<true>, dim3((unsigned)slots), dim3(256), 0, stream, as);
+            else hipLaunchKernelGGL(wenet_llr_stats_small_kernel<false>, dim3((unsigned)slots), dim3(256), 0, stream, as);
         } else {
             const dim3 sgrid((unsigned)((slots + 63) / 64));
             if (args->input_kind == WR_DEC_IN_SD64) hipLaunchKernelGGL(wenet_llr_stats_kernel<true>, sgrid, dim3(64), 0, stream, *args);
@@ -1075,7 +1086,9 @@ extern "C" hipError_t wr_launch_decode(const WrDecodeArgs *args, hipStream_t str
     const unsigned grid = (unsigned)(slots < want ? slots : want);
     hipError_t e;
     const size_t agree_bytes = (size_t)slots * (WR_DEC_THREADS / 64) * sizeof(unsigned);
-    if (args->agree && !args->redo_in && (char *)args->work + 4096 == (char *)args->agree && (char *)args->agree + agree_bytes == (char *)args->redo) {
+    if (cleared_by_stats) {
+        // (work[0], the records of every slot and the list's count were cleared by the statistics kernel of this call)
+    } else if (args->agree && !args->redo_in && (char *)args->work + 4096 == (char *)args->agree && (char *)args->agree + agree_bytes == (char *)args->redo) {
         // the scratch block as carve_decode_scratch lays it out: work counters | records | the list's count -- one fill (three cost a live tick 10 us)
         e = hipMemsetAsync(args->work, 0, 4096 + agree_bytes + 256, stream);      // (the list's count and its first entries: a whole number of 256-byte units is ONE fill kernel)
         if (e != hipSuccess) return e;

@@ -282,6 +282,7 @@ struct WrDecodeArgs {
     const unsigned *redo_in;            // a repeat launch: the slots to decode (the work items), else null
     int             redo_n;
     int             dbg_inject;         // tests: wavefront 3 of every workgroup ignores the "all checks satisfied" stop of its (dbg_inject)-th packet (0 = off)
+    int             zero_in_stats;      // set by wr_launch_decode: the few-packet statistics kernel clears work counter, agreement records and the list's count (no fill launches in a live tick)
 };
 
 // ---- phi0 (reference src/phi0.c:13-218) as data ---------------------------------------------

@@ -36,6 +36,7 @@ extern "C" hipError_t wr_launch_demod_ex(const WrDemodCfg *cfg, const WrChan *d_
 extern "C" hipError_t wr_launch_demod_oct(const WrDemodCfg *cfg, const WrChan *d_chans, int nchan, hipStream_t stream);
 extern "C" hipError_t wr_launch_demod_oct_sliced(const WrDemodCfg *cfg, WrChan *d_chans, int nchan, WrSliceCtl *d_ctl, int nslices, hipStream_t stream);
 extern "C" hipError_t wr_launch_deframe(const WrDeframeChan *d_chans, int nchan, int mode, hipStream_t stream);
+extern "C" hipError_t wr_launch_deframe_ex(const WrDeframeChan *d_chans, int nchan, int mode, hipStream_t stream, unsigned *census_clear);
 extern "C" hipError_t wr_launch_decode(const WrDecodeArgs *args, hipStream_t stream);
 extern "C" int wr_decode_settle(const WrDecodeArgs *args, hipStream_t stream);
 extern "C" hipError_t wr_launch_phi0(const uint4 *d_lut, const float *d_x, float *d_y, long long n, hipStream_t stream);
@@ -1581,8 +1582,9 @@ struct WrLiveMeta { long long carry_smp, carry_sym; };                  // what 
 // (the spans may overlap their destinations by a few elements: every pass reads into registers, meets, then writes)
 __global__ __launch_bounds__(256) void wenet_live_compact_kernel(char *in_base, long long in_stride, float *sd_base, long long sd_stride,
                                                                  const float *states, int st_floats, const WrDeframeState *dst, WrLiveMeta *meta,
-                                                                 const long long *new_smp, int bps, int nbits) {
+                                                                 const long long *new_smp, int bps, int nbits, unsigned *zero4) {
     const int ch = blockIdx.x, tid = threadIdx.x;
+    if (zero4 && ch == 0 && tid < 4) zero4[tid] = 0u;                 // (the tick's arrival error word and wait statistics: one fill launch less in front of the demodulator)
     const WrChanHdr *h = (const WrChanHdr *)(states + (size_t)ch * st_floats);
     const long long have = meta[ch].carry_smp + new_smp[ch], used = h->consumed_call;
     const long long nsym = meta[ch].carry_sym + h->frames_call * nbits, res = dst[ch].resume;
@@ -1863,9 +1865,12 @@ extern "C" long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *c
     const long long in_stride = (((need_smp + need_smp / 4) * (long long)bps + 255) & ~255LL) + 256, sd_stride = ((need_sym + need_sym / 4 + 63) & ~63LL) + 64;
     lap();
     // (1) what the previous tick left undone moves to the front of the blocks (the device works on it while the host prepares the tick's tables)
+    const size_t cen_bytes = (size_t)nchan * WR_CENSUS_CLASSES * 4 + 16;      // (+ the arrival error word and three statistics words)
+    if (!rx->d_census.reserve(cen_bytes)) { live_close(rx); return -2; }
+    unsigned *d_arrive_err = (unsigned *)(rx->d_census.as<char>() + cen_bytes - 16);
     if (rx->live_ticks > 0) {
         hipLaunchKernelGGL(wenet_live_compact_kernel, dim3(nchan), dim3(256), 0, stream, rx->d_live_in.as<char>(), rx->live_in_stride, rx->d_sd.as<float>(),
-                           rx->live_sd_stride, rx->d_states.as<float>(), c.st_floats, rx->d_dstates.as<WrDeframeState>(), d_meta, d_newsmp, (int)bps, c.Nbits);
+                           rx->live_sd_stride, rx->d_states.as<float>(), c.st_floats, rx->d_dstates.as<WrDeframeState>(), d_meta, d_newsmp, (int)bps, c.Nbits, d_arrive_err);
         WR_LIVE_CHECK(hipGetLastError(), -4);
     }
     lap();
@@ -1906,11 +1911,10 @@ extern "C" long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *c
     lap();
     // (3) this tick's samples behind the carried ones; tables.  Everything the host hands over or takes back in a tick except the samples themselves lives in ONE pinned
     //     block (the copies are real DMA, none is staged by the runtime): packet slots | start offsets | state headers | deframer states | census + arrival error || tables in
-    const size_t n_slots = (size_t)nchan * max_pk, out_bytes = n_slots * sizeof(WrPacketOut), st_bytes = n_slots * 8, cen_bytes = (size_t)nchan * WR_CENSUS_CLASSES * 4 + 16;      // (+ the arrival error word and three statistics words)
+    const size_t n_slots = (size_t)nchan * max_pk, out_bytes = n_slots * sizeof(WrPacketOut), st_bytes = n_slots * 8;
     const size_t o_starts = al64(out_bytes), o_hdr = al64(o_starts + st_bytes), o_dst = al64(o_hdr + sizeof(WrChanHdr) * nchan), o_cen = al64(o_dst + sizeof(WrDeframeState) * nchan),
                  o_chans = al64(o_cen + cen_bytes), o_dch = o_chans + t_dch, o_new = o_chans + t_new, o_gl = o_chans + t_gl, pin_total = o_chans + t_total + 64;
     if (pin_total > rx->h_pin_cap && !rx->pin_reserve(pin_total + (size_t)nchan * (size_t)(max_pk_room - max_pk + 2) * (sizeof(WrPacketOut) + 8))) { live_close(rx); return -2; }      // (room for the slot count's creep: pinning is slow)
-    if (!rx->d_census.reserve(cen_bytes)) { live_close(rx); return -2; }
     char *hp = (char *)rx->h_pin;
     WrChan *chans = (WrChan *)(hp + o_chans);
     WrDeframeChan *dch = (WrDeframeChan *)(hp + o_dch);
@@ -1944,7 +1948,6 @@ extern "C" long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *c
     npage = page_ch.size();
     if (npage > 0 && !rx->stage_reserve(stage_bytes + 64)) { live_close(rx); return -2; }
     unsigned long long *d_arrive = rx->d_live_arrive.as<unsigned long long>();
-    unsigned *d_arrive_err = (unsigned *)(rx->d_census.as<char>() + cen_bytes - 16);
     std::vector<size_t> stage_off(npage);
     {
         size_t kp = 0, kg = npin, cur = 0;
@@ -1989,7 +1992,7 @@ extern "C" long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *c
     // (the new samples land where it reads the leftover from) and the list, the chunks that lie in pinned memory
     memcpy(hp + o_new, nsamples, 8 * (size_t)nchan);
     WR_LIVE_CHECK(hipMemcpyAsync(rx->d_live_tab.p, hp + o_chans, t_total, hipMemcpyHostToDevice, stream), -3);
-    WR_LIVE_CHECK(hipMemsetAsync(rx->d_census.as<char>() + cen_bytes - 16, 0, 16, stream), -3);      // (the arrival error word: the demodulator may write it; the census itself is cleared behind the launch)
+    if (rx->live_ticks == 0) WR_LIVE_CHECK(hipMemsetAsync(rx->d_census.as<char>() + cen_bytes - 16, 0, 16, stream), -3);      // (the arrival error word, which the demodulator may write: later ticks' compaction kernel clears it; the census rows are cleared by the deframer)
     WR_LIVE_CHECK(hipEventRecord(rx->live_ev[0], stream), -4);
     WR_LIVE_CHECK(hipStreamWaitEvent(cstream, rx->live_ev[0], 0), -4);
     // the gather's shape: few fat workgroups that keep their compute units to themselves (see the kernel) -- as many as the demodulator's workgroups surely leave free
@@ -2061,13 +2064,12 @@ extern "C" long long wenet_rx_push(wenet_rx *rx, int nchan, const void *const *c
         lc.p_live = overlap ? 1 : 0;                                     // (the three-capture kernel's instantiation that takes chunks as they arrive)
         WR_LIVE_CHECK(wr_launch_demod_ex(&lc, d_tchans, nchan, stream, 0), -4);
     }
-    WR_LIVE_CHECK(hipMemsetAsync(rx->d_census.p, 0, cen_bytes - 16, stream), -3);
     if (overlap && !dbg_ordered) {                                       // the demodulator is running: feed it
         if (const long long rc = stage_and_gather()) return rc;
         WR_LIVE_CHECK(hipStreamWaitEvent(stream, rx->live_ev[1], 0), -4);     // (a channel that stopped at its frame cap has not waited for its last pieces: the tick ends behind them)
     }
     WR_LIVE_CHECK(hipEventRecord(e.ev[1], stream), -4);
-    WR_LIVE_CHECK(wr_launch_deframe(d_tdch, nchan, rx->mode, stream), -4);
+    WR_LIVE_CHECK(wr_launch_deframe_ex(d_tdch, nchan, rx->mode, stream, rx->d_census.as<unsigned>()), -4);
     WR_LIVE_CHECK(hipEventRecord(e.ev[2], stream), -4);
     WrDecodeArgs a;
     memset(&a, 0, sizeof(a));
