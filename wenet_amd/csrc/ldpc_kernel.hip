@@ -613,6 +613,22 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
 #pragma unroll
         for (int k = 0; k < 3; k++) ea[t][k] = (k < deg[t]) ? var_edge(v, k, A.vedge) : 0;
     }
+    // The edge addresses of the positions t = 4 (sockets 1, 2) and t = 5 are NOT held in registers: they are needed in the variable pass only, and four registers that
+    // idle through the check pass -- where fourteen messages are live -- were the ones the 64-register budget lacked (21 spilled registers, no room for any second use
+    // of the addresses).  A thread loads its two packed words from a 4 KB table (the vector memory path idles during the iterations) before the pass that uses them.
+#if WR_DEC_THREADS == 512 && !defined(WR_DEC_NO_EA45)
+#define WR_DEC_EA45 1
+    auto load45 = [&]() __attribute__((always_inline)) -> uint2 { int i = tid; asm volatile("" : "+v"(i)); return A.ea45[i]; };      // (the asm: the load is not hoisted out of the loops)
+    auto MP = [&](int t, int k, const uint2 &q) __attribute__((always_inline)) -> float * {
+        if (t < 4 || (t == 4 && k == 0)) return &msg[ea[t][k]];
+        const unsigned w = (t == 4) ? q.x : q.y;
+        const bool lo = (t == 4) ? (k == 1) : (k == 0);
+        return (float *)(smem + (lo ? (w & 0xffffu) : (w >> 16)));
+    };
+#else
+    auto load45 = [&]() __attribute__((always_inline)) -> uint2 { return make_uint2(0u, 0u); };
+    auto MP = [&](int t, int k, const uint2 &) __attribute__((always_inline)) -> float * { return &msg[ea[t][k]]; };
+#endif
     const bool data4 = var_at(WR_VARS_ALLDATA) < WR_NDATA;                                      // position t = 4 holds a data bit (positions t < 4 always do, t = 5 never)
     // Where this thread's six soft symbols sit in a stored packet, and which of them the v2 scrambler negates: functions of the thread's variables alone,
     // so they are formed once here -- the per-packet prologue is then six loads issued together and six products (round 3 walked, per packet and variable,
@@ -755,6 +771,7 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
     if (A.stop_after_llr) { put_claim(); continue; }
 
     if (tid == 0) msg[13 * WR_NPAR] = 0.f;                      // check 0 has 13 edges: its 14th slot stays a neutral +0
+    uint2 q45 = load45();
     WR_LDS_BARRIER();
 
     // ---- initial variable->check messages: phi0(|llr|), sign = llr<0 (mpdecode_core.c:353-359)
@@ -762,7 +779,7 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
     for (int t = 0; t < WR_VARS_PER_THREAD; t++) {
         const float m0 = with_sign(phi0_dev(fabsf(llr[t]), lut), llr[t] < 0.f);
 #pragma unroll
-        for (int k = 0; k < 3; k++) if (t < WR_VARS_ALLDATA || k < deg[t]) msg[ea[t][k]] = m0;
+        for (int k = 0; k < 3; k++) if (t < WR_VARS_ALLDATA || k < deg[t]) *MP(t, k, q45) = m0;
     }
     if (tid < 4) red[tid] = 0;
     WR_LDS_BARRIER();
@@ -869,6 +886,7 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
         // to the cell of this iteration's parity before the barrier, everyone reads it after, and the cell of the other parity is
         // cleared for the next iteration.  (__syncthreads_count / __syncthreads_or cost three barriers each.)
         const int par = iter & 1;
+        q45 = load45();                                             // (in flight across the barrier)
         {
             const unsigned long long bal = __ballot(ok & 1), bal2 = __ballot(ok & 2);     // ok = number of satisfied checks of this thread (0..3)
             if ((tid & 63) == 0 && (bal | bal2)) atomicAdd(&red[par * 2 + 0], __popcll(bal) + 2 * __popcll(bal2));
@@ -890,6 +908,32 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
         // ---- update q: thread = variable (mpdecode_core.c:439-464) ---------------------------
         int any_data = 0;
         bits = 0;
+#ifndef WR_DEC_NO_LIGHT_LAST
+        // The iteration after which the loop is left whatever the variable pass finds -- every check satisfied (the count is known here, in a scalar register), or the
+        // iteration limit -- needs the pass's hard decisions only: the messages it would store are never read (mpdecode_core.c:439-483: q is an input of the NEXT
+        // iteration's r update alone).  Same sums in the same order for Qi, so the same bits, `any`, iteration count and pcc; three phi0 evaluations and three stores
+        // per variable less on one iteration in ~6.
+        const bool last_pass = (ssum == WR_NPAR && !(A.dbg_inject && (blockIdx.x & 7) == 0 && __builtin_amdgcn_readfirstlane(tid >> 6) == 3 && inj_seq == A.dbg_inject)) || iter + 1 >= A.max_iter;
+        if (last_pass) {
+            float lc[WR_VARS_PER_THREAD][3];                       // (all the reads in flight together, then the sums in the reference's order)
+#pragma unroll
+            for (int t = 0; t < WR_VARS_PER_THREAD; t++) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) lc[t][k] = (t < WR_VARS_ALLDATA || k < deg[t]) ? *MP(t, k, q45) : 0.f;
+            }
+#pragma unroll
+            for (int t = 0; t < WR_VARS_PER_THREAD; t++) {
+                if (t < WR_VARS_ALLDATA || deg[t] > 0) {
+                    float Qi = llr[t];
+#pragma unroll
+                    for (int k = 0; k < 3; k++) if (t < WR_VARS_ALLDATA || k < deg[t]) Qi += lc[t][k];
+                    const int b = Qi < 0.f;
+                    bits |= (unsigned)b << t;
+                    if (b && (t < WR_VARS_ALLDATA || (t == WR_VARS_ALLDATA && data4))) any_data = 1;
+                }
+            }
+        } else
+#endif
 #pragma unroll
         for (int t = 0; t < WR_VARS_PER_THREAD; t++) {
             if (t < WR_VARS_ALLDATA || deg[t] > 0) {
@@ -898,7 +942,7 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
 #pragma unroll
                 for (int k = 0; k < 3; k++) {
                     if (t < WR_VARS_ALLDATA || k < deg[t]) {
-                        cm[k] = msg[ea[t][k]];
+                        cm[k] = *MP(t, k, q45);
                         Qi += cm[k];
                     }
                 }
@@ -912,7 +956,7 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
                     for (int k = 0; k < 3; k++) { ts[k] = Qi - cm[k]; xa[k] = fabsf(ts[k]); }
                     phi0_iter_n<3>(xa, ma, lut, big_llr);
 #pragma unroll
-                    for (int k = 0; k < 3; k++) if (t < WR_VARS_ALLDATA || k < deg[t]) msg[ea[t][k]] = with_sign(ma[k], !(ts[k] > 0.f));
+                    for (int k = 0; k < 3; k++) if (t < WR_VARS_ALLDATA || k < deg[t]) *MP(t, k, q45) = with_sign(ma[k], !(ts[k] > 0.f));
                 }
 #else
 #pragma unroll
@@ -924,7 +968,7 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
 #else
                         const float mag = phi0_dev(fabsf(temp_sum), lut);
 #endif
-                        msg[ea[t][k]] = with_sign(mag, !(temp_sum > 0.f));
+                        *MP(t, k, q45) = with_sign(mag, !(temp_sum > 0.f));
                     }
                 }
 #endif

@@ -458,6 +458,7 @@ struct LdpcTables {
     DevBuf blob;
     const uint16_t *d_vedge = nullptr;
     const uint16_t *d_vpos = nullptr;
+    const uint2 *d_ea45 = nullptr;
     int place_cost0 = 0, place_cost = 0;                // bank overload of the variable pass before / after the placement search
     const uint4 *d_lut = nullptr;
     const uint8_t *d_scramble = nullptr;
@@ -479,13 +480,34 @@ struct LdpcTables {
 #else
         if (!phi0_build_lut(lut, false)) return false;
 #endif
-        size_t a_v = 0, a_l = (WR_NDATA * 3 * 2 + 255) & ~255, a_s = a_l + ((WR_PHI0_LDS_BYTES + 255) & ~255), a_p = a_s + 256;
-        if (!blob.reserve(a_p + WR_NCODE * 2 + 256)) return false;
+        size_t a_v = 0, a_l = (WR_NDATA * 3 * 2 + 255) & ~255, a_s = a_l + ((WR_PHI0_LDS_BYTES + 255) & ~255), a_p = a_s + 256, a_e = (a_p + WR_NCODE * 2 + 255) & ~(size_t)255;
+        if (!blob.reserve(a_e + 512 * 8 + 256)) return false;
+        // the edges of a thread's positions t = 4 (sockets 1, 2) and t = 5 (sockets 0, 1) as byte addresses in the message array, 16 bits each (same arithmetic as the
+        // kernel's var_degree / var_edge: mpdecode_core.c:296-303, 334-341)
+        std::vector<uint32_t> ea45(512 * 2, 0u);
+        {
+            auto edge_bytes = [&](int p, int k) -> uint32_t {
+                if (p >= WR_NCODE) return 0u;
+                const int v = vpos[p];
+                const int deg = v < WR_NDATA ? 3 : (v == WR_NCODE - 1 ? 1 : 2);
+                if (k >= deg) return 0u;
+                int e;
+                if (v < WR_NDATA) e = vedge[v * 3 + k];
+                else { const int c = v - WR_NDATA; e = (k == 0) ? ((c == 0) ? 12 : 13) * WR_NPAR + c : 12 * WR_NPAR + (c + 1); }
+                return (uint32_t)e * 4u;
+            };
+            for (int tid = 0; tid < 512; tid++) {
+                ea45[2 * tid] = edge_bytes(tid + 4 * 512, 1) | (edge_bytes(tid + 4 * 512, 2) << 16);
+                ea45[2 * tid + 1] = edge_bytes(tid + 5 * 512, 0) | (edge_bytes(tid + 5 * 512, 1) << 16);
+            }
+        }
         char *base = blob.as<char>();
         WR_CHECK(hipMemcpy(base + a_v, vedge.data(), WR_NDATA * 3 * 2, hipMemcpyHostToDevice), false);
         WR_CHECK(hipMemcpy(base + a_l, lut.data(), WR_PHI0_LDS_BYTES, hipMemcpyHostToDevice), false);
         WR_CHECK(hipMemcpy(base + a_s, kScramble, 125, hipMemcpyHostToDevice), false);
         WR_CHECK(hipMemcpy(base + a_p, vpos.data(), WR_NCODE * 2, hipMemcpyHostToDevice), false);
+        WR_CHECK(hipMemcpy(base + a_e, ea45.data(), 512 * 8, hipMemcpyHostToDevice), false);
+        d_ea45 = (const uint2 *)(base + a_e);
         d_vpos = (const uint16_t *)(base + a_p);
         d_vedge = (const uint16_t *)(base + a_v);
         d_lut = (const uint4 *)(base + a_l);
@@ -510,7 +532,7 @@ LdpcTables *ldpc_tables() {                                            // the co
 }
 
 void fill_decode_tables(WrDecodeArgs &a, const LdpcTables *t) {
-    a.vedge = t->d_vedge; a.vpos = t->d_vpos; a.phi0_lut = t->d_lut; a.scramble = t->d_scramble;
+    a.vedge = t->d_vedge; a.vpos = t->d_vpos; a.ea45 = t->d_ea45; a.phi0_lut = t->d_lut; a.scramble = t->d_scramble;
 }
 // the decoder's scratch block (wr_dec_scratch_bytes): estimates | work counters | packet addresses | exit records | two repeat lists
 void carve_decode_scratch(WrDecodeArgs &a, char *base, size_t nslots) {
