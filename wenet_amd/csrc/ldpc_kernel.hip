@@ -585,7 +585,10 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
     int      *red = (int *)(smem + WR_DEC_OFF_RED);                                // [parity of the iteration][0: satisfied checks, 1: any data bit set]
     // packet claims: the slot this workgroup decodes now and the one it decodes next.  The next slot is taken from the shared counter while THIS packet is
     // decoded (thread 0: the atomic at the packet's start, its value into LDS behind the last iteration), so the atomic's latency is not on a packet's path.
-    int *claim = (int *)(smem + WR_DEC_OFF_CLAIM);                                 // [2] (plain LDS words: the workgroup barriers order them)
+    //   A claim is a record {slot, -, address of the packet's first stored symbol (two words), estEsN0 (two words)}: thread 0 fetches the slot's record from the statistics
+    //   kernel's arrays while the packet before is packed and stored, so a packet's symbol loads do not wait behind a global load of their address (one memory round trip
+    //   less on every packet's path).
+    int *claim = (int *)(smem + WR_DEC_OFF_CLAIM);                                 // [2][8] (plain LDS words: the workgroup barriers order them)
     const long long nslots = (long long)A.nchan * A.max_pk;
     const long long nwork = A.redo_in ? (long long)A.redo_n : nslots;                 // work items: every slot, or (a repeat launch of the agreement guard) the listed ones
     // ---- once per workgroup: phi0 LUT into LDS; this thread's variables (LdpcTables::place_variables: the data variables are dealt
@@ -653,7 +656,32 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
             soff[t >> 1] |= o << (16 * (t & 1));
         }
     }
-    if (tid == 0) { const unsigned s0 = atomicAdd(A.work, 1u); claim[0] = (long long)s0 < nwork ? (A.redo_in ? (int)A.redo_in[s0] : (int)s0) : -1; }     // the first packet: taken here, synchronously
+    auto slot_of = [&](unsigned w) __attribute__((always_inline)) -> int { return (long long)w < nwork ? (A.redo_in ? (int)A.redo_in[w] : (int)w) : -1; };
+    // the slot's record -- where the packet's first stored symbol is (0: no packet in this slot) and its estEsN0 (round 3: channel table -> deframer state -> start offset,
+    // three dependent loads; round 4: one load per packet by every thread; now thread 0's, a packet ahead)
+    auto fetch_record = [&](int sl, unsigned long long &b, double &e) __attribute__((always_inline)) {
+        b = 0ull; e = 0.0;
+        if (sl < 0 || (long long)sl >= nslots) return;
+        if (A.input_kind == WR_DEC_IN_LLR) {                                       // (dense LLR input: no statistics kernel has run)
+            const int chs = sl / A.max_pk, pks = sl - chs * A.max_pk;
+            if (pks < A.npk_direct[chs]) b = (unsigned long long)(uintptr_t)(A.llr_in + (long long)sl * WR_NCODE);
+        } else {
+            b = A.pbase[sl];
+            e = A.esn0[sl];
+        }
+    };
+    auto post_claim = [&](int cell, int sl, unsigned long long b, double e) __attribute__((always_inline)) {
+        int *r = claim + cell * 8;
+        r[0] = sl; r[2] = (int)(unsigned)b; r[3] = (int)(unsigned)(b >> 32);
+        const unsigned long long eu = (unsigned long long)__double_as_longlong(e);
+        r[4] = (int)(unsigned)eu; r[5] = (int)(unsigned)(eu >> 32);
+    };
+    if (tid == 0) {                                                                // the first packet: taken here, synchronously
+        const int s0 = slot_of(atomicAdd(A.work, 1u));
+        unsigned long long b0; double e0;
+        fetch_record(s0, b0, e0);
+        post_claim(0, s0, b0, e0);
+    }
     int cur = 0;
 
 #ifdef WR_DEC_STAMPS
@@ -678,23 +706,17 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
     if (st_t) DSTAMP(5);                                                           // [5] end of the previous packet -> everyone at the top
     st_t = (long long)__builtin_readcyclecounter();
 #endif                                                               // (the previous packet's staging is read out; LUT and this packet's claim are in place)
-    const int slot_i = __builtin_amdgcn_readfirstlane(claim[cur]);
+    const int *crec = claim + cur * 8;
+    const int slot_i = __builtin_amdgcn_readfirstlane(crec[0]);
     if (slot_i < 0 || (long long)slot_i >= nslots) break;                // (>= nslots: never written by thread 0 -- a wavefront that reads that is better gone; the agreement guard lists what it leaves undone)
     const long long slot = slot_i;
     unsigned nxt = 0;
     if (tid == 0) nxt = atomicAdd(A.work, 1u);                                     // the NEXT packet's slot: the value is not waited for here
-    auto put_claim = [&]() __attribute__((always_inline)) { if (tid == 0) claim[cur ^ 1] = (long long)nxt < nwork ? (A.redo_in ? (int)A.redo_in[nxt] : (int)nxt) : -1; };
-    // the slot's record from the statistics kernel -- where the packet's first stored symbol is (0: no packet in this slot) and its estEsN0: ONE load
-    // (round 3: channel table -> deframer state -> start offset, three dependent ones)
-    unsigned long long base = 0ull;
-    double estEsN0 = 0.0;
-    if (A.input_kind == WR_DEC_IN_LLR) {                                           // (dense LLR input: no statistics kernel has run)
-        const int chs = slot_i / A.max_pk, pks = slot_i - chs * A.max_pk;
-        if (pks < A.npk_direct[chs]) base = (unsigned long long)(uintptr_t)(A.llr_in + slot * WR_NCODE);
-    } else {
-        base = (unsigned long long)uni64((long long)A.pbase[slot]);
-        estEsN0 = __longlong_as_double(uni64(__double_as_longlong(A.esn0[slot])));
-    }
+    auto put_claim = [&]() __attribute__((always_inline)) {                      // (the paths that leave the packet early: fetched and posted in place)
+        if (tid == 0) { const int ns = slot_of(nxt); unsigned long long nb; double ne; fetch_record(ns, nb, ne); post_claim(cur ^ 1, ns, nb, ne); }
+    };
+    const unsigned long long base = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(crec[3]) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(crec[2]);
+    const double estEsN0 = __longlong_as_double((long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(crec[5]) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(crec[4])));
     if (base == 0ull) { put_claim(); continue; }                                   // nothing in this slot
     const int n = (A.input_kind == WR_DEC_IN_SD64) ? A.n_sd : WR_NCODE;
 
@@ -994,12 +1016,14 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
     }
 
     DSTAMP(2);                                                      // [2] the iterations
-    put_claim();                                                    // (the atomic has returned long ago)
+    int nslot = -1; unsigned long long nbase = 0ull; double nesn0 = 0.0;
+    if (tid == 0) { nslot = slot_of(nxt); fetch_record(nslot, nbase, nesn0); }     // (the atomic has returned long ago; the record's loads fly while the packet is packed, posted at the end)
 #ifdef WR_DEC_STAMPS
     st_acc[6] += 1; st_acc[7] += result;
 #endif
 #ifdef WR_DBG_NO_EPI                                                             // development (timing only, wrong results): no packing, no output
     if (result < 0) bitbuf[tid] = (uint8_t)bits;
+    if (tid == 0) post_claim(cur ^ 1, nslot, nbase, nesn0);
     continue;
 #endif
     // ---- pack MSB-first, CRC-16/CCITT-FALSE gate (drs232_ldpc.c:234-257) ----------------------
@@ -1045,6 +1069,7 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
     }
     cn_seq++;
 #endif
+    if (tid == 0) post_claim(cur ^ 1, nslot, nbase, nesn0);
     DSTAMP(3);                                              // [3] bits -> bytes -> packet slot
   }
 #ifdef WR_DEC_STAMPS
