@@ -919,6 +919,7 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
         WR_LDS_BARRIER();
+        DSTAMP(4);                                                  // [4] the check passes (with their barrier)
 #ifdef WR_DEC_VECTOR_DECISION
         const int ssum = red[par * 2 + 0];
 #else
@@ -1003,6 +1004,7 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
 #else
         const int any = __builtin_amdgcn_readfirstlane(red[par * 2 + 1]);
 #endif
+        DSTAMP(2);                                                  // [2] the variable passes (with their barrier)
 #ifndef WR_GUARD_NO_HASH
         seen = seen * 33u + (unsigned)ssum * 2u + (unsigned)(any != 0);          // agreement guard: what this wavefront read, iteration by iteration
 #endif
@@ -1027,10 +1029,13 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
     continue;
 #endif
     // ---- pack MSB-first, CRC-16/CCITT-FALSE gate (drs232_ldpc.c:234-257) ----------------------
+    int vout[WR_VARS_PER_THREAD];                                   // (which variables these bits are: the table reads fly while the wavefronts gather at the barrier -- decode step -1.1 %)
+#pragma unroll
+    for (int t = 0; t < WR_VARS_PER_THREAD; t++) vout[t] = var_at(t);
     WR_LDS_BARRIER();
 #pragma unroll
     for (int t = 0; t < WR_VARS_PER_THREAD; t++) {
-        const int v = var_at(t);
+        const int v = vout[t];
         if (v < WR_NCODE) {
             bitbuf[v] = (uint8_t)((bits >> t) & 1u);
             if (A.bits_out) A.bits_out[(long long)slot * WR_NCODE + v] = (uint8_t)((bits >> t) & 1u);

@@ -2223,7 +2223,8 @@ extern "C" int wenet_rx_collect(wenet_rx *rx) {
         long long d[8];
         if (rx->d_prof.p && hipMemcpy(d, rx->d_prof.p, 64, hipMemcpyDeviceToHost) == hipSuccess && d[6] > 0)
             fprintf(stderr, "decode stamps (cycles per packet, wave 0): load+llr %.0f | init %.0f | iterations %.0f (%.2f per packet: %.0f each) | pack+store %.0f | to the next top %.0f | packets %lld\n",
-                    (double)d[0] / d[6], (double)d[1] / d[6], (double)d[2] / d[6], (double)d[7] / d[6], (double)d[2] / (d[7] > 0 ? d[7] : 1), (double)d[3] / d[6], (double)d[5] / d[6], d[6]);
+                    (double)d[0] / d[6], (double)d[1] / d[6], (double)(d[2] + d[4]) / d[6], (double)d[7] / d[6], (double)(d[2] + d[4]) / (d[7] > 0 ? d[7] : 1), (double)d[3] / d[6], (double)d[5] / d[6], d[6]);
+        if (rx->d_prof.p && d[6] > 0) fprintf(stderr, "   of the iterations: check passes %.0f (%.0f each), variable passes + stop rules %.0f\n", (double)d[4] / d[6], (double)d[4] / (d[7] > 0 ? d[7] : 1), (double)d[2] / d[6]);
     }
 #endif
     // packet slots + start offsets were copied to the pinned host buffer behind each decode launch (rx_enqueue)
