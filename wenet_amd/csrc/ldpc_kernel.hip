@@ -633,9 +633,15 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
     auto MP = [&](int t, int k, const uint2 &) __attribute__((always_inline)) -> float * { return &msg[ea[t][k]]; };
 #endif
     const bool data4 = var_at(WR_VARS_ALLDATA) < WR_NDATA;                                      // position t = 4 holds a data bit (positions t < 4 always do, t = 5 never)
-    // Where this thread's six soft symbols sit in a stored packet, and which of them the v2 scrambler negates: functions of the thread's variables alone,
-    // so they are formed once here -- the per-packet prologue is then six loads issued together and six products (round 3 walked, per packet and variable,
-    // the chain placement table -> symbol -> scramble byte: a dozen dependent global loads, ~10 us per packet = two iterations' worth).
+    // Where this thread's six soft symbols sit in a stored packet, and which of them the v2 scrambler negates: functions of the thread's variables and the input layout alone
+    // (round 3 walked, per packet and variable, the chain placement table -> symbol -> scramble byte; round 4 formed them once per workgroup and held them in registers --
+    // which the 64-register budget spilled: each of the six symbol loads then waited for its offset's reload AND, the memory counter being in order, for the load before it:
+    // six HBM round trips in a row, the whole of the prologue).  Now one 16-byte read of a per-thread table per packet (LdpcTables: symtab), issued before the barrier at the
+    // top, then six loads in flight together.
+#if WR_DEC_THREADS == 512 && !defined(WR_DEC_NO_SYMTAB)
+#define WR_DEC_SYMTAB 1
+    const int skind = (A.input_kind == WR_DEC_IN_STREAM && (A.mode == 1 || A.mode == 2)) ? A.mode : 0;
+#else
     unsigned soff[(WR_VARS_PER_THREAD + 1) / 2], sneg = 0u, svalid = 0u;
     for (int i = 0; i < (WR_VARS_PER_THREAD + 1) / 2; i++) soff[i] = 0u;              // 16-bit offsets packed in pairs; bit t: negate / position holds a variable
     {
@@ -656,6 +662,7 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
             soff[t >> 1] |= o << (16 * (t & 1));
         }
     }
+#endif
     auto slot_of = [&](unsigned w) __attribute__((always_inline)) -> int { return (long long)w < nwork ? (A.redo_in ? (int)A.redo_in[w] : (int)w) : -1; };
     // the slot's record -- where the packet's first stored symbol is (0: no packet in this slot) and its estEsN0 (round 3: channel table -> deframer state -> start offset,
     // three dependent loads; round 4: one load per packet by every thread; now thread 0's, a packet ahead)
@@ -697,6 +704,10 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
 #endif
   int inj_seq = 0;
   for (;; cur ^= 1) {
+#ifdef WR_DEC_SYMTAB
+    uint4 sy;
+    { int i = skind * WR_DEC_THREADS + tid; asm volatile("" : "+v"(i)); sy = A.symtab[i]; }        // (the asm: not hoisted out of the packet loop into registers it does not have)
+#endif
     WR_LDS_BARRIER_TOP();
     inj_seq++;
 #ifdef WR_DEC_CANARY
@@ -738,11 +749,21 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
         //      llr = (float)(4.0L*estEsN0*sd) with estEsN0 from wenet_llr_stats_kernel (mpdecode_core.c:593-594), or the dense LLR input as it is
         const __attribute__((address_space(1))) float *sdp = (const __attribute__((address_space(1))) float *)base;
         float raw[WR_VARS_PER_THREAD];
-#pragma unroll
+#ifdef WR_DEC_SYMTAB
+        const unsigned sneg = sy.w & 0xffu, svalid = (sy.w >> 8) & 0xffu;
+        const unsigned soff[3] = {sy.x, sy.y, sy.z};
+#endif
 #ifdef WR_DBG_NO_SD                                                              // development (timing only, wrong results): no symbol loads
+#pragma unroll
         for (int t = 0; t < WR_VARS_PER_THREAD; t++) raw[t] = 0.25f + 0.001f * (float)((tid + t) & 15);
         (void)sdp;
+#elif defined(WR_DEC_SYMTAB)
+#pragma unroll
+        for (int t = 0; t < WR_VARS_PER_THREAD; t++) raw[t] = sdp[(soff[t >> 1] >> (16 * (t & 1))) & 0xffffu];       // (all six in flight: a position without a variable reads symbol 0)
+#pragma unroll
+        for (int t = 0; t < WR_VARS_PER_THREAD; t++) if (!((svalid >> t) & 1u)) raw[t] = 0.f;
 #else
+#pragma unroll
         for (int t = 0; t < WR_VARS_PER_THREAD; t++) raw[t] = ((svalid >> t) & 1u) ? sdp[(soff[t >> 1] >> (16 * (t & 1))) & 0xffffu] : 0.f;
 #endif
         if (A.input_kind == WR_DEC_IN_LLR) {

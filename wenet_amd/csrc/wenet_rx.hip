@@ -459,6 +459,7 @@ struct LdpcTables {
     const uint16_t *d_vedge = nullptr;
     const uint16_t *d_vpos = nullptr;
     const uint2 *d_ea45 = nullptr;
+    const uint4 *d_symtab = nullptr;
     int place_cost0 = 0, place_cost = 0;                // bank overload of the variable pass before / after the placement search
     const uint4 *d_lut = nullptr;
     const uint8_t *d_scramble = nullptr;
@@ -480,8 +481,8 @@ struct LdpcTables {
 #else
         if (!phi0_build_lut(lut, false)) return false;
 #endif
-        size_t a_v = 0, a_l = (WR_NDATA * 3 * 2 + 255) & ~255, a_s = a_l + ((WR_PHI0_LDS_BYTES + 255) & ~255), a_p = a_s + 256, a_e = (a_p + WR_NCODE * 2 + 255) & ~(size_t)255;
-        if (!blob.reserve(a_e + 512 * 8 + 256)) return false;
+        size_t a_v = 0, a_l = (WR_NDATA * 3 * 2 + 255) & ~255, a_s = a_l + ((WR_PHI0_LDS_BYTES + 255) & ~255), a_p = a_s + 256, a_e = (a_p + WR_NCODE * 2 + 255) & ~(size_t)255, a_y = a_e + 512 * 8;
+        if (!blob.reserve(a_y + 3 * 512 * 16 + 256)) return false;
         // the edges of a thread's positions t = 4 (sockets 1, 2) and t = 5 (sockets 0, 1) as byte addresses in the message array, 16 bits each (same arithmetic as the
         // kernel's var_degree / var_edge: mpdecode_core.c:296-303, 334-341)
         std::vector<uint32_t> ea45(512 * 2, 0u);
@@ -507,6 +508,26 @@ struct LdpcTables {
         WR_CHECK(hipMemcpy(base + a_s, kScramble, 125, hipMemcpyHostToDevice), false);
         WR_CHECK(hipMemcpy(base + a_p, vpos.data(), WR_NCODE * 2, hipMemcpyHostToDevice), false);
         WR_CHECK(hipMemcpy(base + a_e, ea45.data(), 512 * 8, hipMemcpyHostToDevice), false);
+        // where a thread's six variables' symbols sit in a stored packet, per input layout (0: symbol i = variable i; 1: RS232 strip, out[8b+j] = in[10b + 8 - j],
+        // drs232_ldpc.c:220-225; 2: v2, symbol * scramble_code[ind % 1000], wenet_ldpc.c:207), and which of them the scrambler negates
+        std::vector<uint32_t> symtab(3 * 512 * 4, 0u);
+        for (int kind = 0; kind < 3; kind++)
+            for (int tid = 0; tid < 512; tid++) {
+                uint32_t off[6] = {0, 0, 0, 0, 0, 0}, neg = 0u, valid = 0u;
+                for (int t = 0; t < 6; t++) {
+                    const int p = tid + 512 * t;
+                    if (p >= WR_NCODE) continue;
+                    const int v = vpos[p];
+                    valid |= 1u << t;
+                    off[t] = (uint32_t)v;
+                    if (kind == 1) off[t] = (uint32_t)(10 * (v >> 3) + 8 - (v & 7));
+                    if (kind == 2) { const int kb = v % 1000; if ((kScramble[kb >> 3] >> (7 - (kb & 7))) & 1) neg |= 1u << t; }
+                }
+                uint32_t *e = &symtab[((size_t)kind * 512 + tid) * 4];
+                e[0] = off[0] | (off[1] << 16); e[1] = off[2] | (off[3] << 16); e[2] = off[4] | (off[5] << 16); e[3] = neg | (valid << 8);
+            }
+        WR_CHECK(hipMemcpy(base + a_y, symtab.data(), 3 * 512 * 16, hipMemcpyHostToDevice), false);
+        d_symtab = (const uint4 *)(base + a_y);
         d_ea45 = (const uint2 *)(base + a_e);
         d_vpos = (const uint16_t *)(base + a_p);
         d_vedge = (const uint16_t *)(base + a_v);
@@ -532,7 +553,7 @@ LdpcTables *ldpc_tables() {                                            // the co
 }
 
 void fill_decode_tables(WrDecodeArgs &a, const LdpcTables *t) {
-    a.vedge = t->d_vedge; a.vpos = t->d_vpos; a.ea45 = t->d_ea45; a.phi0_lut = t->d_lut; a.scramble = t->d_scramble;
+    a.vedge = t->d_vedge; a.vpos = t->d_vpos; a.ea45 = t->d_ea45; a.symtab = t->d_symtab; a.phi0_lut = t->d_lut; a.scramble = t->d_scramble;
 }
 // the decoder's scratch block (wr_dec_scratch_bytes): estimates | work counters | packet addresses | exit records | two repeat lists
 void carve_decode_scratch(WrDecodeArgs &a, char *base, size_t nslots) {
