@@ -621,14 +621,27 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
     // of the addresses).  A thread loads its two packed words from a 4 KB table (the vector memory path idles during the iterations) before the pass that uses them.
 #if WR_DEC_THREADS == 512 && !defined(WR_DEC_NO_EA45)
 #define WR_DEC_EA45 1
-    auto load45 = [&]() __attribute__((always_inline)) -> uint2 { int i = tid; asm volatile("" : "+v"(i)); return A.ea45[i]; };      // (the asm: the load is not hoisted out of the loops)
+#ifdef WR_DEC_EA345                                               // (development: position 3's three addresses from the table too)
+    typedef uint4 wr_q45_t;
+    auto load45 = [&]() __attribute__((always_inline)) -> uint4 { int i = tid; asm volatile("" : "+v"(i)); return A.ea45[i]; };
+    auto MP = [&](int t, int k, const uint4 &q) __attribute__((always_inline)) -> float * {
+        if (t < 3 || (t == 4 && k == 0)) return &msg[ea[t][k]];
+        const unsigned w = (t == 4) ? q.x : (t == 5 ? q.y : (k < 2 ? q.z : q.w));
+        const bool lo = (t == 4) ? (k == 1) : (t == 5 ? (k == 0) : (k != 1));
+        return (float *)(smem + (lo ? (w & 0xffffu) : (w >> 16)));
+    };
+#else
+    typedef uint2 wr_q45_t;
+    auto load45 = [&]() __attribute__((always_inline)) -> uint2 { int i = tid; asm volatile("" : "+v"(i)); const uint2 *tb = (const uint2 *)A.ea45; return tb[2 * i]; };      // (the asm: the load is not hoisted out of the loops)
     auto MP = [&](int t, int k, const uint2 &q) __attribute__((always_inline)) -> float * {
         if (t < 4 || (t == 4 && k == 0)) return &msg[ea[t][k]];
         const unsigned w = (t == 4) ? q.x : q.y;
         const bool lo = (t == 4) ? (k == 1) : (k == 0);
         return (float *)(smem + (lo ? (w & 0xffffu) : (w >> 16)));
     };
+#endif
 #else
+    typedef uint2 wr_q45_t;
     auto load45 = [&]() __attribute__((always_inline)) -> uint2 { return make_uint2(0u, 0u); };
     auto MP = [&](int t, int k, const uint2 &) __attribute__((always_inline)) -> float * { return &msg[ea[t][k]]; };
 #endif
@@ -814,7 +827,7 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
     if (A.stop_after_llr) { put_claim(); continue; }
 
     if (tid == 0) msg[13 * WR_NPAR] = 0.f;                      // check 0 has 13 edges: its 14th slot stays a neutral +0
-    uint2 q45 = load45();
+    wr_q45_t q45 = load45();
     WR_LDS_BARRIER();
 
     // ---- initial variable->check messages: phi0(|llr|), sign = llr<0 (mpdecode_core.c:353-359)
@@ -1051,8 +1064,18 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
 #endif
     // ---- pack MSB-first, CRC-16/CCITT-FALSE gate (drs232_ldpc.c:234-257) ----------------------
     int vout[WR_VARS_PER_THREAD];                                   // (which variables these bits are: the table reads fly while the wavefronts gather at the barrier -- decode step -1.1 %)
+#ifdef WR_DEC_SYMTAB
+    {   // (layout 0 of the symbol table holds the variable numbers themselves: one 16-byte read instead of six reads behind reloaded addresses)
+        int i = tid; asm volatile("" : "+v"(i));
+        const uint4 vy = A.symtab[i];
+        const unsigned vo[3] = {vy.x, vy.y, vy.z};
+#pragma unroll
+        for (int t = 0; t < WR_VARS_PER_THREAD; t++) vout[t] = ((vy.w >> (8 + t)) & 1u) ? (int)((vo[t >> 1] >> (16 * (t & 1))) & 0xffffu) : WR_NCODE;
+    }
+#else
 #pragma unroll
     for (int t = 0; t < WR_VARS_PER_THREAD; t++) vout[t] = var_at(t);
+#endif
     WR_LDS_BARRIER();
 #pragma unroll
     for (int t = 0; t < WR_VARS_PER_THREAD; t++) {

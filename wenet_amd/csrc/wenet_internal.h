@@ -272,8 +272,8 @@ struct WrDecodeArgs {
     const uint16_t *vpos;               // [2580] variable handled at position tid + 512 t of the variable pass (LdpcTables::place_variables)
     const uint4    *symtab;             // [3][512] per thread and input layout (0: symbol i of the packet is variable i; 1: v1 RS232 strip; 2: v2 descramble): where its six variables'
                                         //       symbols sit in a stored packet (16 bits each in .x .y .z; 0 where the position holds no variable) and .w = negate mask | valid mask << 8
-    const uint2    *ea45;               // [512] per thread: the byte addresses (in the message array) of the edges of its positions t = 4 (sockets 1, 2) and t = 5 (sockets 0, 1),
-                                        //       16 bits each (0 where the position has no such edge): loaded per pass instead of held in registers through the check pass
+    const uint4    *ea45;               // [512] per thread: the byte addresses (in the message array) of the edges of its positions t = 4 (sockets 1, 2: .x), t = 5 (sockets 0, 1: .y)
+                                        //       and t = 3 (.z, .w), 16 bits each (0 where the position has no such edge): loaded per pass instead of held in registers through the check pass
     unsigned       *work;               // persistent decode workgroups: next packet slot to take (zeroed before the launch)
     const uint4    *phi0_lut;           // [90]
     int             phase;              // wr_launch_decode: 0 = everything, 1 = LLR statistics only, 2 = decode + CRC only (statistics done by an earlier call)

@@ -458,7 +458,7 @@ struct LdpcTables {
     DevBuf blob;
     const uint16_t *d_vedge = nullptr;
     const uint16_t *d_vpos = nullptr;
-    const uint2 *d_ea45 = nullptr;
+    const uint4 *d_ea45 = nullptr;
     const uint4 *d_symtab = nullptr;
     int place_cost0 = 0, place_cost = 0;                // bank overload of the variable pass before / after the placement search
     const uint4 *d_lut = nullptr;
@@ -481,11 +481,11 @@ struct LdpcTables {
 #else
         if (!phi0_build_lut(lut, false)) return false;
 #endif
-        size_t a_v = 0, a_l = (WR_NDATA * 3 * 2 + 255) & ~255, a_s = a_l + ((WR_PHI0_LDS_BYTES + 255) & ~255), a_p = a_s + 256, a_e = (a_p + WR_NCODE * 2 + 255) & ~(size_t)255, a_y = a_e + 512 * 8;
+        size_t a_v = 0, a_l = (WR_NDATA * 3 * 2 + 255) & ~255, a_s = a_l + ((WR_PHI0_LDS_BYTES + 255) & ~255), a_p = a_s + 256, a_e = (a_p + WR_NCODE * 2 + 255) & ~(size_t)255, a_y = a_e + 512 * 16;
         if (!blob.reserve(a_y + 3 * 512 * 16 + 256)) return false;
         // the edges of a thread's positions t = 4 (sockets 1, 2) and t = 5 (sockets 0, 1) as byte addresses in the message array, 16 bits each (same arithmetic as the
         // kernel's var_degree / var_edge: mpdecode_core.c:296-303, 334-341)
-        std::vector<uint32_t> ea45(512 * 2, 0u);
+        std::vector<uint32_t> ea45(512 * 4, 0u);
         {
             auto edge_bytes = [&](int p, int k) -> uint32_t {
                 if (p >= WR_NCODE) return 0u;
@@ -498,8 +498,10 @@ struct LdpcTables {
                 return (uint32_t)e * 4u;
             };
             for (int tid = 0; tid < 512; tid++) {
-                ea45[2 * tid] = edge_bytes(tid + 4 * 512, 1) | (edge_bytes(tid + 4 * 512, 2) << 16);
-                ea45[2 * tid + 1] = edge_bytes(tid + 5 * 512, 0) | (edge_bytes(tid + 5 * 512, 1) << 16);
+                ea45[4 * tid] = edge_bytes(tid + 4 * 512, 1) | (edge_bytes(tid + 4 * 512, 2) << 16);
+                ea45[4 * tid + 1] = edge_bytes(tid + 5 * 512, 0) | (edge_bytes(tid + 5 * 512, 1) << 16);
+                ea45[4 * tid + 2] = edge_bytes(tid + 3 * 512, 0) | (edge_bytes(tid + 3 * 512, 1) << 16);      // (position 3 too: for builds that keep fewer addresses in registers)
+                ea45[4 * tid + 3] = edge_bytes(tid + 3 * 512, 2);
             }
         }
         char *base = blob.as<char>();
@@ -507,7 +509,7 @@ struct LdpcTables {
         WR_CHECK(hipMemcpy(base + a_l, lut.data(), WR_PHI0_LDS_BYTES, hipMemcpyHostToDevice), false);
         WR_CHECK(hipMemcpy(base + a_s, kScramble, 125, hipMemcpyHostToDevice), false);
         WR_CHECK(hipMemcpy(base + a_p, vpos.data(), WR_NCODE * 2, hipMemcpyHostToDevice), false);
-        WR_CHECK(hipMemcpy(base + a_e, ea45.data(), 512 * 8, hipMemcpyHostToDevice), false);
+        WR_CHECK(hipMemcpy(base + a_e, ea45.data(), 512 * 16, hipMemcpyHostToDevice), false);
         // where a thread's six variables' symbols sit in a stored packet, per input layout (0: symbol i = variable i; 1: RS232 strip, out[8b+j] = in[10b + 8 - j],
         // drs232_ldpc.c:220-225; 2: v2, symbol * scramble_code[ind % 1000], wenet_ldpc.c:207), and which of them the scrambler negates
         std::vector<uint32_t> symtab(3 * 512 * 4, 0u);
@@ -528,7 +530,7 @@ struct LdpcTables {
             }
         WR_CHECK(hipMemcpy(base + a_y, symtab.data(), 3 * 512 * 16, hipMemcpyHostToDevice), false);
         d_symtab = (const uint4 *)(base + a_y);
-        d_ea45 = (const uint2 *)(base + a_e);
+        d_ea45 = (const uint4 *)(base + a_e);
         d_vpos = (const uint16_t *)(base + a_p);
         d_vedge = (const uint16_t *)(base + a_v);
         d_lut = (const uint4 *)(base + a_l);
