@@ -165,11 +165,21 @@ __device__ __forceinline__ float phi0_iter(float xf, const uint4 *lut, bool big)
 }
 // N evaluations with their table reads in flight TOGETHER (one LDS round trip instead of N: a result costs one register, so the batch fits the 64-register budget the
 // three-word results of the earlier form did not), one test for marked cells over the batch
-template <int N>
+// ABS (the decode kernel, whose dynamic LDS block starts at address 0 -- wr_launch_decode checks that once per process): the cell's LDS address is formed as an integer,
+// (key << 2) + (the table's offset - 4 KLO) -- shift, clamp, one shift-and-add; through the pointer the compiler adds the block's (zero) base and the folded constant in
+// two instructions: one VALU instruction in fifteen of the iterations.
+template <int N, bool ABS = false>
 __device__ __forceinline__ void phi0_iter_n(const float (&x)[N], float (&v)[N], const uint4 *lut, bool big) {
     const float *t1 = (const float *)lut;
 #pragma unroll
-    for (int j = 0; j < N; j++) v[j] = t1[min(max(__float_as_int(x[j]) >> 16, WR_PHI0_T7_KLO), WR_PHI0_T7_KHI) - WR_PHI0_T7_KLO];
+    for (int j = 0; j < N; j++) {
+        const int key = min(max(__float_as_int(x[j]) >> 16, WR_PHI0_T7_KLO), WR_PHI0_T7_KHI);
+        if (ABS) {
+            unsigned a;                                             // (written out so that the constant sits in a scalar register: the compiler kept it in a vector register the loop does not have)
+            asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(a) : "v"(key), "s"((unsigned)(WR_DEC_OFF_LUT - 4 * WR_PHI0_T7_KLO)));
+            v[j] = *(const __attribute__((address_space(3))) float *)(a);
+        } else v[j] = t1[key - WR_PHI0_T7_KLO];
+    }
     bool mk = false;
 #pragma unroll
     for (int j = 0; j < N; j++) mk = mk || (v[j] != v[j]);
@@ -870,6 +880,13 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
             for (int k = 1; k < 14; k++) phi_sum = phi_sum + fabsf(mr[k]);
             ok += (par_bit == 0) ? 1 : 0;
 #if WR_PHI0_FORM == 4
+#ifndef WR_DEC_ABS_LUT
+#ifdef WR_DEC_STATIC_LDS
+#define WR_DEC_ABS_LUT false
+#else
+#define WR_DEC_ABS_LUT true
+#endif
+#endif
 #ifndef WR_DEC_CHK_BATCH
 #define WR_DEC_CHK_BATCH 2                  // (measured 1 / 2 / 3 / 4 / 7 with the three of a variable together: 10.92 / 10.85 / 10.98 / slower / slower ms per 244 k packets)
 #endif
@@ -881,7 +898,7 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
               float xa[WR_DEC_CHK_BATCH], ra[WR_DEC_CHK_BATCH];
 #pragma unroll
               for (int j = 0; j < WR_DEC_CHK_BATCH; j++) xa[j] = phi_sum - fabsf(mr[k0 + j < 14 ? k0 + j : 13]);    // (a sum of table values minus one of them: 0 .. 140)
-              phi0_iter_n<WR_DEC_CHK_BATCH>(xa, ra, lut, false);
+              phi0_iter_n<WR_DEC_CHK_BATCH, WR_DEC_ABS_LUT>(xa, ra, lut, false);
 #pragma unroll
               for (int j = 0; j < WR_DEC_CHK_BATCH; j++) {
                 const int k = k0 + j;
@@ -1011,7 +1028,7 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
                     float ts[3], xa[3], ma[3];
 #pragma unroll
                     for (int k = 0; k < 3; k++) { ts[k] = Qi - cm[k]; xa[k] = fabsf(ts[k]); }
-                    phi0_iter_n<3>(xa, ma, lut, big_llr);
+                    phi0_iter_n<3, WR_DEC_ABS_LUT>(xa, ma, lut, big_llr);
 #pragma unroll
                     for (int k = 0; k < 3; k++) if (t < WR_VARS_ALLDATA || k < deg[t]) *MP(t, k, q45) = with_sign(ma[k], !(ts[k] > 0.f));
                 }
