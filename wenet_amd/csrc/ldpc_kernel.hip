@@ -180,9 +180,10 @@ __device__ __forceinline__ void phi0_iter_n(const float (&x)[N], float (&v)[N], 
             v[j] = *(const __attribute__((address_space(3))) float *)(a);
         } else v[j] = t1[key - WR_PHI0_T7_KLO];
     }
-    bool mk = false;
+    bool mk = false;                                                // (marked cells are NaNs: one unordered comparison tests two results)
 #pragma unroll
-    for (int j = 0; j < N; j++) mk = mk || (v[j] != v[j]);
+    for (int j = 0; j + 1 < N; j += 2) mk = mk || __builtin_isunordered(v[j], v[j + 1]);
+    if (N & 1) mk = mk || (v[N - 1] != v[N - 1]);
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(mk) != 0ull, 0)) {
 #pragma unroll
         for (int j = 0; j < N; j++) {
@@ -867,6 +868,12 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
             const int chk = tid + cj * WR_DEC_THREADS;          // the whole checks: one per thread (512 threads; two with -DWR_DEC_THREADS=256)
             // messages stay signed in their registers: |m| is a free source modifier of the adds, the parity of the signs is the
             // top bit of the XOR of the raw words, and an edge's new sign is its own sign XOR that parity
+#if !defined(WR_DEC_NO_ADDTID) && WR_PHI0_FORM == 4
+            // M0 = the wavefront's lane-0 byte offset in a row, written once per check for its fourteen add-TID stores below (until late in round 5: in front of each of
+            // them).  Nothing else in this kernel touches M0 -- tests/test_isa_audit.py checks that in the code object -- and the asm blocks keep their order (volatile).
+            // (s_nop: a write of M0 needs a wait state before an add-TID LDS instruction, and the compiler's hazard recogniser does not look into an asm block)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" : : "s"(wave_base4 + cj * WR_DEC_THREADS * 4) : "memory", "m0");
+#endif
             float mr[14];
             unsigned px = 0;
 #pragma unroll
@@ -909,7 +916,7 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
                 // the check pass stores lane-linearly (check = thread): ds_write_addtid_b32 -- address = M0 + offset + 4 lane, no address register -- costs the LDS
                 // two cycles where ds_write_b32 costs four (the address VGPR's transfer).  (s_nop: a write of M0 needs a wait state before an add-TID LDS instruction, and
                 // the compiler's hazard recogniser does not look into an asm block)
-                asm volatile(WR_ADDTID_PRE "s_mov_b32 m0, %1\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:%2" : : "v"(rs), "s"(wave_base4 + cj * WR_DEC_THREADS * 4), "n"(k * WR_NPAR * 4) : "memory", "m0");
+                asm volatile(WR_ADDTID_PRE "ds_write_addtid_b32 %0 offset:%1" : : "v"(rs), "n"(k * WR_NPAR * 4) : "memory");
 #else
                 msg[k * WR_NPAR + chk] = rs;
 #endif
