@@ -168,12 +168,15 @@ __device__ __forceinline__ float phi0_iter(float xf, const uint4 *lut, bool big)
 // ABS (the decode kernel, whose dynamic LDS block starts at address 0 -- wr_launch_decode checks that once per process): the cell's LDS address is formed as an integer,
 // (key << 2) + (the table's offset - 4 KLO) -- shift, clamp, one shift-and-add; through the pointer the compiler adds the block's (zero) base and the folded constant in
 // two instructions: one VALU instruction in fifteen of the iterations.
-template <int N, bool ABS = false>
+// SGN: the arguments are |x[j]| -- the key is then one bit-field extract of the signed word (bits 16..30) instead of a mask and a shift; the magnitude's bits are formed
+// only on the rare paths that compare them.
+template <int N, bool ABS = false, bool SGN = false>
 __device__ __forceinline__ void phi0_iter_n(const float (&x)[N], float (&v)[N], const uint4 *lut, bool big) {
     const float *t1 = (const float *)lut;
 #pragma unroll
     for (int j = 0; j < N; j++) {
-        const int key = min(max(__float_as_int(x[j]) >> 16, WR_PHI0_T7_KLO), WR_PHI0_T7_KHI);
+        const int key = SGN ? min(max((int)((__float_as_uint(x[j]) >> 16) & 0x7fffu), WR_PHI0_T7_KLO), WR_PHI0_T7_KHI)
+                            : min(max(__float_as_int(x[j]) >> 16, WR_PHI0_T7_KLO), WR_PHI0_T7_KHI);
         if (ABS) {
             unsigned a;                                             // (written out so that the constant sits in a scalar register: the compiler kept it in a vector register the loop does not have)
             asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(a) : "v"(key), "s"((unsigned)(WR_DEC_OFF_LUT - 4 * WR_PHI0_T7_KLO)));
@@ -190,13 +193,13 @@ __device__ __forceinline__ void phi0_iter_n(const float (&x)[N], float (&v)[N], 
             if (v[j] != v[j]) {
                 const uint4 e = ((const uint4 *)((const char *)lut + WR_PHI0_T7_BYTES))[__float_as_uint(v[j]) & 15u];
                 T2_KEEP128(e);
-                v[j] = __uint_as_float(__float_as_int(x[j]) >= (int)e.x ? e.z : e.y);
+                v[j] = __uint_as_float((int)(__float_as_uint(x[j]) & (SGN ? 0x7fffffffu : 0xffffffffu)) >= (int)e.x ? e.z : e.y);
             }
         }
     }
     if (__builtin_expect(big, 0)) {
 #pragma unroll
-        for (int j = 0; j < N; j++) v[j] = __float_as_int(x[j]) >= WR_PHI0_BIG_BITS ? 10.0f : v[j];
+        for (int j = 0; j < N; j++) v[j] = (int)(__float_as_uint(x[j]) & (SGN ? 0x7fffffffu : 0xffffffffu)) >= WR_PHI0_BIG_BITS ? 10.0f : v[j];
     }
 }
 #endif
@@ -1034,10 +1037,11 @@ __global__ __launch_bounds__(WR_DEC_THREADS, WR_DEC_WAVES_PER_EU) void wenet_dec
                 {
                     float ts[3], xa[3], ma[3];
 #pragma unroll
-                    for (int k = 0; k < 3; k++) { ts[k] = Qi - cm[k]; xa[k] = fabsf(ts[k]); }
-                    phi0_iter_n<3, WR_DEC_ABS_LUT>(xa, ma, lut, big_llr);
+                    for (int k = 0; k < 3; k++) { ts[k] = Qi - cm[k]; xa[k] = ts[k]; }
+                    phi0_iter_n<3, WR_DEC_ABS_LUT, true>(xa, ma, lut, big_llr);
+                    // (a table value has a clear sign bit: the select with a negated source is the OR of the sign, in one instruction less)
 #pragma unroll
-                    for (int k = 0; k < 3; k++) if (t < WR_VARS_ALLDATA || k < deg[t]) *MP(t, k, q45) = with_sign(ma[k], !(ts[k] > 0.f));
+                    for (int k = 0; k < 3; k++) if (t < WR_VARS_ALLDATA || k < deg[t]) *MP(t, k, q45) = !(ts[k] > 0.f) ? -ma[k] : ma[k];
                 }
 #else
 #pragma unroll
